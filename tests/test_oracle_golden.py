@@ -1,0 +1,124 @@
+"""The oracle (oracle/) against the golden vectors generated from the imported reference
+(tests/golden/make_golden.py) and against the only known-answer vector the reference itself holds
+(the anchor table, lib/model/rpn/generate_anchors.py:12-37).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nafae_amd import synthetic as syn
+from oracle import detector as OD
+from oracle import dvsa as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DVSA_CASES = ["c1", "c1b", "ragged", "na1", "full", "big"]
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def test_anchor_known_answer():
+    # generate_anchors.py:29-37: Matlab (1-based) table; the Python function returns it minus 1
+    matlab = np.array([[-83, -39, 100, 56], [-175, -87, 192, 104], [-359, -183, 376, 200], [-55, -55, 72, 72],
+                       [-119, -119, 136, 136], [-247, -247, 264, 264], [-35, -79, 52, 96], [-79, -167, 96, 184],
+                       [-167, -343, 184, 360]], dtype=np.float64)
+    a = OD.generate_anchors()
+    assert np.array_equal(a, matlab - 1)
+    g = load("anchors")
+    assert np.array_equal(a, g["default"])
+    b = OD.generate_anchors(scales=(4, 8, 16, 32), ratios=(0.5, 1, 2))
+    assert np.array_equal(b, g["vgg16_yml"])
+    assert b.shape == (12, 4) and b[0].tolist() == [-38, -16, 53, 31] and b[-1].tolist() == [-168, -344, 183, 359]
+
+
+@pytest.mark.parametrize("name", DVSA_CASES)
+@pytest.mark.parametrize("phase", ["train", "eval"])
+def test_dvsa_matches_reference(name, phase):
+    g = load("dvsa_" + name)
+    Na, Ns, Nb, Ne, D = [int(x) for x in g["shape"]]
+    V = torch.from_numpy(g["V"]).requires_grad_()
+    W = torch.from_numpy(g["W"]).requires_grad_()
+    Di, Ds, L = O.dvsa_forward(V, W, g["lens"].tolist(), Na, Nb, Ne, float(g["Delta"]), float(g["vis_lam"]), phase)
+    L.backward()
+    assert np.array_equal(Di.numpy(), g["D_ind_" + phase])
+    assert np.array_equal(Ds.detach().numpy(), g["D_sim_" + phase])
+    np.testing.assert_allclose(L.item(), g["loss_" + phase], rtol=1e-6)
+    np.testing.assert_allclose(V.grad.numpy(), g["dV_" + phase], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(W.grad.numpy(), g["dW_" + phase], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", DVSA_CASES)
+def test_postprocess_matches_reference(name):
+    g = load("dvsa_" + name)
+    Na, Ns, Nb, Ne, D = [int(x) for x in g["shape"]]
+    Dp, Sp = O.postprocess(g["D_ind_eval"], g["D_sim_eval"], Na, Ns, Nb, Ne)
+    assert np.array_equal(Dp, g["post_D"])
+    np.testing.assert_array_equal(Sp, g["post_sim"])
+
+
+def test_degenerate_shapes():
+    # Na=1 => ranking term == 2*Delta (loss 200 at Delta=10 in eval)
+    g = load("dvsa_na1")
+    assert abs(float(g["loss_eval"]) - 200.0) < 1e-4
+    # Ns=2 => vis_loss == 1 exactly with zero gradient from the clustering term
+    g = load("dvsa_c1")
+    assert abs((float(g["loss_train"]) - float(g["loss_eval"])) / 10.0 / float(g["vis_lam"]) - 1.0) < 1e-5
+
+
+def test_embed_matches_reference():
+    g = load("embed")
+    Na, Ns, Nb, Ne, D, FC, Gd = [int(x) for x in g["shape"]]
+    t = lambda k: torch.from_numpy(g[k]).clone()
+    ve_w, ve_b, we_w, we_b, bn_w, bn_b = [t(k).requires_grad_() for k in ("ve_w", "ve_b", "we_w", "we_b", "bn_w", "bn_b")]
+    rm, rv = torch.zeros(D), torch.ones(D)
+    V = O.vis_ebd(t("fc7"), ve_w, ve_b)
+    W = O.word_ebd(t("glove"), we_w, we_b, bn_w, bn_b, rm, rv, training=True)
+    np.testing.assert_allclose(V.detach().numpy(), g["V_train"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(W.detach().numpy(), g["W_train"], rtol=1e-5, atol=1e-6)
+    Di, Ds, L = O.dvsa_forward(V, W, g["lens"].tolist(), Na, Nb, Ne, 10.0, 4.13, "train")
+    L.backward()
+    np.testing.assert_allclose(L.item(), g["loss_train"], rtol=1e-6)
+    assert np.array_equal(Di.numpy(), g["D_ind_train"])
+    for p, k in ((ve_w, "g_ve_w"), (ve_b, "g_ve_b"), (we_w, "g_we_w"), (we_b, "g_we_b"), (bn_w, "g_bn_w"), (bn_b, "g_bn_b")):
+        np.testing.assert_allclose(p.grad.numpy(), g[k], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(rm.numpy(), g["run_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rv.numpy(), g["run_var"], rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        V = O.vis_ebd(t("fc7"), ve_w, ve_b)
+        W = O.word_ebd(t("glove"), we_w, we_b, bn_w, bn_b, rm, rv, training=False)
+        Di, Ds, L = O.dvsa_forward(V, W, g["lens"].tolist(), Na, Nb, Ne, 10.0, 4.13, "eval")
+    np.testing.assert_allclose(W.numpy(), g["W_eval"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(L.item(), g["loss_eval"], rtol=1e-6)
+    assert np.array_equal(Di.numpy(), g["D_ind_eval"])
+
+
+def test_proposal_layer_matches_reference():
+    g = load("proposal")
+    cls, deltas, im_info = [torch.from_numpy(g[k]) for k in ("cls", "deltas", "im_info")]
+    A = 12
+    B, C2, H, W = cls.shape
+    prob = torch.softmax(cls.view(B, 2, C2 * H // 2, W), 1).view(B, C2, H, W)
+    np.testing.assert_array_equal(prob.numpy(), g["prob"])
+    s, props = OD.decode_proposals(prob, deltas, im_info, 16, g["scales"].tolist(), g["ratios"].tolist())
+    order = OD.sort_desc(s)
+    rois, roi_scores, n_keep = OD.select_proposals(s, props, order, 6000, int(g["post_nms_topN"]), 0.7)
+    np.testing.assert_array_equal(rois.numpy(), g["rois"])
+    np.testing.assert_array_equal(roi_scores.numpy(), g["roi_scores"])
+
+
+def test_detector_matches_reference():
+    g = load("detector")
+    sd = syn.detector_state(seed=int(g["seed"]), heads=False)
+    h, w = [int(x) for x in g["frames_hw"]]
+    im, im_info = syn.frames(2, h, w, seed=int(g["seed"]))
+    cfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
+               RPN_POST_NMS_TOP_N=int(g["post_nms_topN"]), RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
+    base = OD.vgg16_features(im, sd)
+    np.testing.assert_allclose(base.numpy(), g["base_feat"], rtol=1e-5, atol=1e-5)
+    rois, roi_scores, pooled, fc7 = OD.detector_forward(im, im_info, sd, cfg)
+    np.testing.assert_array_equal(rois.numpy(), g["rois"])
+    np.testing.assert_allclose(roi_scores.numpy(), g["roi_scores"], rtol=1e-6)
+    np.testing.assert_allclose(pooled[:, ::37].numpy(), g["pooled_sub"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fc7.numpy(), g["fc7"], rtol=1e-4, atol=1e-4)

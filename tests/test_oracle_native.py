@@ -1,0 +1,103 @@
+"""Hand-checkable pins for the C restatement of the reference's CUDA-only NMS / ROI-Align
+(oracle/native.c).  The reference ships no vectors for these ops ("parity unpinned"), so the
+cases below are ones whose answer can be derived by hand from the CUDA source."""
+import numpy as np
+import torch
+
+from oracle import native as N
+
+
+def test_iou_plus_one_convention():
+    # nms_cuda_kernel.cu:31-39: widths are (x2-x1+1)
+    assert N.iou([0, 0, 9, 9], [0, 0, 9, 9]) == 1.0
+    # 10x10 boxes shifted by 5 px: inter 5x10=50, union 150
+    assert abs(N.iou([0, 0, 9, 9], [5, 0, 14, 9]) - 50.0 / 150.0) < 1e-7
+    # touching boxes still overlap by one pixel column under the +1 convention
+    assert abs(N.iou([0, 0, 9, 9], [9, 0, 18, 9]) - 10.0 / 190.0) < 1e-7
+    assert N.iou([0, 0, 9, 9], [20, 20, 29, 29]) == 0.0
+
+
+def test_nms_small_cases():
+    # identical boxes: only the first survives
+    d = np.array([[0, 0, 9, 9, .9]] * 5, np.float32)
+    assert N.nms(d, 0.7).tolist() == [0]
+    # n = 1
+    assert N.nms(d[:1], 0.7).tolist() == [0]
+    # disjoint: all survive
+    d = np.array([[i * 20, 0, i * 20 + 9, 9, 1 - i * .01] for i in range(70)], np.float32)
+    assert N.nms(d, 0.7).tolist() == list(range(70))
+    # strict '>' (nms_cuda_kernel.cu:78): IoU exactly == thresh is NOT suppressed
+    a = [0, 0, 9, 9, .9]
+    b = [0, 0, 9, 4, .8]           # inter 50, union 100 -> IoU 0.5 exactly
+    d = np.array([a, b], np.float32)
+    assert N.nms(d, 0.5).tolist() == [0, 1]
+    assert N.nms(d, 0.49).tolist() == [0]
+    # suppression is by KEPT boxes only: c overlaps b (suppressed by a) but not a -> c survives
+    a = [0, 0, 99, 99, .9]
+    b = [10, 0, 109, 99, .8]       # IoU(a,b) = 90*100/(110*100) = .818 > .7 -> suppressed
+    c = [35, 0, 134, 99, .7]       # IoU(b,c) = 75/125 = .6 ; IoU(a,c) = 65/135 = .48
+    d = np.array([a, b, c], np.float32)
+    assert N.nms(d, 0.7).tolist() == [0, 2]
+    c2 = [25, 0, 124, 99, .7]      # IoU(b,c2)=85/115=.739 > .7 but b is not kept; IoU(a,c2)=75/125=.6
+    assert N.nms(np.array([a, b, c2], np.float32), 0.7).tolist() == [0, 2]
+
+
+def test_nms_matches_bitmask_formulation():
+    """The reference computes a 64-wide bitmask matrix then sweeps (nms_cuda_kernel.cu:41-144);
+    check the direct greedy form against a literal restatement of mask + sweep, n not a multiple of 64."""
+    rs = np.random.RandomState(0)
+    n = 200
+    xy = rs.rand(n, 2) * 60
+    wh = rs.rand(n, 2) * 40 + 4
+    d = np.concatenate([xy, xy + wh, np.sort(rs.rand(n, 1), 0)[::-1]], 1).astype(np.float32)
+    cb = (n + 63) // 64
+    mask = np.zeros((n, cb), dtype=np.uint64)
+    for i in range(n):
+        for j in range(n):
+            if (i // 64 == j // 64 and j <= i):
+                continue                      # :74-76 upper triangle inside the diagonal tile
+            if N.iou(d[i], d[j]) > 0.7:
+                mask[i, j // 64] |= np.uint64(1) << np.uint64(j % 64)
+    remv = np.zeros(cb, dtype=np.uint64)
+    keep = []
+    for i in range(n):
+        if not (remv[i // 64] >> np.uint64(i % 64)) & np.uint64(1):
+            keep.append(i)
+            for j in range(i // 64, cb):
+                remv[j] |= mask[i, j]
+    assert keep == N.nms(d, 0.7).tolist()
+    assert 1 < len(keep) < n
+
+
+def test_roi_align_hand_cases():
+    H = W = 14
+    f = np.arange(H * W, dtype=np.float32).reshape(1, 1, H, W)   # f[y,x] = 14y + x (bilinear-exact)
+    # whole-map ROI: x2 = 223 -> end = 13.9375, width = 14.9375, bin = 14.9375/7; last sample at w = 14.9375 >= W -> 0
+    out = N.roi_align_forward(f, np.array([[0, 0, 0, 223, 223]], np.float32), 8, 8, 1 / 16.)
+    assert out[0, 0, 0, 0] == 0.0                                   # h=w=0 -> f[0,0]
+    assert np.all(out[0, 0, 7, :] == 0) and np.all(out[0, 0, :, 7] == 0)   # out-of-range -> 0 (roi_align_kernel.cu:54-55)
+    b = np.float32(np.float32(14.9375) / np.float32(7))
+    assert abs(out[0, 0, 1, 2] - (14 * float(b) + 2 * float(b))) < 1e-4
+    # zero-padded ROI (i,0,0,0,0) from the proposal layer: width = 1, bin = 1/7, all samples inside cell (0,0)
+    out = N.roi_align_forward(f, np.array([[0, 0, 0, 0, 0]], np.float32), 8, 8, 1 / 16.)
+    assert abs(out[0, 0, 7, 7] - (14 * 1.0 + 1.0)) < 1e-5
+    # degenerate ROI x2 < x1 by more than one cell: width clamps to 0 -> every column samples at w = x1*scale
+    out = N.roi_align_forward(f, np.array([[0, 160, 0, 16, 15]], np.float32), 8, 8, 1 / 16.)
+    assert np.allclose(out[0, 0, 0, :], 10.0)
+    # h in [H-1, H): hstart = min(floor(h), H-2) = H-2 and h_ratio in [1,2) -> linear EXTRAPOLATION (:48-58)
+    out = N.roi_align_forward(f, np.array([[0, 0, 13.5 * 16, 0, 13.5 * 16]], np.float32), 8, 8, 1 / 16.)
+    assert abs(out[0, 0, 0, 0] - 14 * 13.5) < 1e-4
+    # batch index selects the image
+    f2 = np.stack([f[0], f[0] + 1000])
+    out = N.roi_align_forward(f2, np.array([[1, 0, 0, 0, 0]], np.float32), 8, 8, 1 / 16.)
+    assert out[0, 0, 0, 0] == 1000.0
+
+
+def test_roi_align_avg_is_avgpool_of_8x8():
+    rs = np.random.RandomState(1)
+    f = rs.randn(2, 6, 14, 14).astype(np.float32)
+    rois = np.array([[0, 3.3, 7.1, 150.2, 99.9], [1, 100, 100, 223, 223], [1, 0, 0, 0, 0]], np.float32)
+    a = N.roi_align_forward(f, rois, 8, 8, 1 / 16.)
+    b = N.roi_align_avg(f, rois, 7, 1 / 16.)
+    t = torch.nn.functional.avg_pool2d(torch.from_numpy(a), kernel_size=2, stride=1).numpy()
+    assert np.array_equal(t, b)           # modules/roi_align.py:26-29
