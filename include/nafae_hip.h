@@ -1,0 +1,184 @@
+/* nafae_hip.h -- C ABI of libnafae_hip.so: the MI355X (gfx950) native ops behind NAFAE's per-frame
+ * grounding hot path (VGG16 conv features -> RPN proposals + NMS -> ROI-Align -> fc6/fc7 -> visual
+ * embedding -> region x query similarity -> contextual-similarity + visual-clustering loss).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller allocates every
+ *     buffer (outputs need not be pre-zeroed) and keeps ownership; nothing is allocated, freed or
+ *     synchronised inside, so every call is hipGraph-capturable;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *   - return value: 0 = launched, negative = NAFAE_E* argument error (nothing launched);
+ *     kernel-side failures surface through hipGetLastError()/stream sync of the caller, like any
+ *     HIP launch.  (The reference prints-and-continues in NMS, nms_cuda_kernel.cu:14-26, and
+ *     exit(-1)s in ROI-Align, roi_align_kernel.cu:84-88; a library must do neither.)
+ *   - all tensors are dense row-major fp32 unless stated; index outputs are int32 except where the
+ *     reference's Python boundary hands out int64 (D_ind).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference
+ * root).  The reference-side binding (ctypes stub replacing torch.utils.ffi) is in INTEGRATION.md.
+ */
+#ifndef NAFAE_HIP_H
+#define NAFAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAFAE_OK 0
+#define NAFAE_EINVAL (-1)   /* bad size / null pointer / unsupported shape */
+#define NAFAE_ELIMIT (-2)   /* shape exceeds a compiled limit (stated per function) */
+
+#define NAFAE_ACT_NONE 0
+#define NAFAE_ACT_RELU 1
+#define NAFAE_ACT_TANH 2
+
+/* Library / device identification; fills at most `cap` bytes of `buf` (host) with a 0-terminated
+ * string like "nafae_hip 0.1 gfx950".  Callable without a GPU. */
+int nafae_version(char *buf_host, int cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * B2 drop-ins: same argument meaning as the reference's torch.utils.ffi entry points.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces  int nms_cuda(THCudaIntTensor *keep_out, THCudaTensor *boxes_host, THCudaIntTensor *num_out,
+ *                        float nms_overlap_thresh)          lib/model/nms/src/nms_cuda.c:8-18
+ * and       void nms_cuda_compute(int*, int*, float*, int boxes_num, int boxes_dim, float thresh)
+ *                                                           lib/model/nms/src/nms_cuda_kernel.cu:87-161
+ * boxes: [n, dim] (dim >= 4; x1,y1,x2,y2[,score]) already sorted by descending score.
+ * keep_out: int32[n] -- first *num_out entries are the kept positions, ascending; the rest is 0.
+ * Device-resident: no host copies, no allocation (the reference does 2 cudaMalloc, a 696 KB D2H,
+ * a host sweep and 2 H2D per frame).  Limit: n <= 16384.  */
+int nafae_nms(int32_t *keep_out, int32_t *num_out, const float *boxes, int n, int dim, float thresh,
+              void *stream);
+
+/* Replaces  int roi_align_forward_cuda(int aligned_height, int aligned_width, float spatial_scale,
+ *                THCudaTensor *features, THCudaTensor *rois, THCudaTensor *output)
+ *                                                           lib/model/roi_align/src/roi_align_cuda.c:7-40
+ * features [B,C,H,W], rois [N,5] = (batch_ind, x1,y1,x2,y2), output [N,C,AH,AW] -- element-for-element
+ * the arithmetic of ROIAlignForward (roi_align_kernel.cu:15-70), including out-of-range -> 0.  */
+int nafae_roi_align_forward(int aligned_height, int aligned_width, float spatial_scale,
+                            const float *features, int B, int C, int H, int W, const float *rois,
+                            int N, float *output, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused / batched hot-path ops (what the Python host mirror in nafae_amd/ calls).
+ * Internal activation layout is NHWC ("pixel-major, channel-contiguous") so that the K dimension of
+ * every contraction is contiguous in HBM; weights are re-laid-out once at load.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* C[M,N] = act(alpha * A[M,K] * B[N,K]^T + bias[N])     (both operands K-contiguous)
+ * Replaces torch `F.linear` at vgg16_rpn.py:56-61 (fc6/fc7), model.py:626 (VisEbd.fc1, alpha = 1/100),
+ * model.py:641 (WordEbd.fc1) and the two 1x1 RPN convs (rpn/rpn.py:65,72).  fp32 MFMA (exact fp32 FMA
+ * chain).  K % 4 == 0; lda, ldb, ldc in elements, 16-byte aligned rows; bias may be NULL.  */
+int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
+                  int M, int N, int K, float alpha, int act, void *stream);
+
+/* C[M,N] = alpha * A[K,M]^T * B[K,N] (+ C if accumulate)   (both operands K-major)
+ * Weight-gradient contraction of VisEbd.fc1 / WordEbd.fc1 (autograd of model.py:626,641).
+ * M % 4 == 0, N % 4 == 0.  */
+int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
+                  float alpha, int accumulate, void *stream);
+
+/* First VGG layer: 3x3 conv (pad 1) + bias + ReLU, Cin = 3, Cout = 64.  in: NCHW [F,3,H,W] exactly as
+ * the reference feeds it (model.py:692-698); w: [64, 27] (= OIHW flattened); out: NHWC [F,H,W,64].
+ * Replaces RCNN_base[0:2] (vgg16_rpn.py:38).  */
+int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias, float *out_nhwc, int F,
+                         int H, int W, void *stream);
+
+/* 3x3 conv (pad 1, stride 1) + bias + ReLU as an implicit GEMM on fp32 MFMA.
+ * in: NHWC [F,H,W,Cin]; w: [Cout, 3,3,Cin] (tap-major, channel-contiguous; re-laid-out from OIHW at
+ * load); out: NHWC [F,H,W,Cout].  Cin % 32 == 0, Cout % 4 == 0.
+ * Replaces the remaining 12 convs of RCNN_base and RPN_Conv (vgg16_rpn.py:38, rpn/rpn.py:63).  */
+int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float *out, int F, int H, int W,
+                       int Cin, int Cout, int relu, void *stream);
+
+/* 2x2 stride-2 max-pool on NHWC.  H, W even; C % 4 == 0.  (RCNN_base pools, vgg16_rpn.py:38.)  */
+int nafae_maxpool2x2(const float *in, float *out, int F, int H, int W, int C, void *stream);
+
+/* RPN score pairing + anchor decode + clip (rpn/rpn.py:67-69, proposal_layer.py:67-109,
+ * bbox_transform.py:77-103,125-133).  head: NHWC [F, H*W, 6A] = [bg scores A | fg scores A | deltas 4A]
+ * (the two 1x1 convs evaluated as one GEMM); anchors: [A,4] base anchors (generate_anchors.py:45-56);
+ * im_info: [F,3] = (h, w, scale).  Outputs in the reference's (h, w, a) order:
+ * scores [F, H*W*A] (fg probability), boxes [F, H*W*A, 4].  */
+int nafae_rpn_decode(const float *head, const float *anchors, const float *im_info, float *scores,
+                     float *boxes, int F, int H, int W, int A, int feat_stride, void *stream);
+
+/* Per-frame descending sort of proposal scores (proposal_layer.py:125; ties -> ascending index, which is
+ * torch's stable CPU order).  order: int32 [F, n].  Limit: n <= 16384.  */
+int nafae_sort_desc(const float *scores, int32_t *order, int F, int n, void *stream);
+
+/* Batched proposal selection = the per-image loop of proposal_layer.py:130-163 for all frames at once:
+ * gather by `order`, greedy NMS (IoU with +1 widths, strict > thresh), first post_nms_topN kept, zero pad.
+ * n_sorted = number of sorted candidates considered per frame (pre_nms_topN rule applied by the caller).
+ * rois [F, post_nms_topN, 5] (col 0 = frame index), roi_scores [F, post_nms_topN], n_keep int32 [F].  */
+int nafae_proposals(const float *boxes, const float *scores, const int32_t *order, int F, int n, int n_sorted,
+                    float nms_thresh, int post_nms_topN, float *rois, float *roi_scores, int32_t *n_keep,
+                    void *stream);
+
+/* Fused RoIAlignAvg (modules/roi_align.py:26-29): 8x8 bilinear samples (ROIAlignForward semantics) and the
+ * 2x2 stride-1 mean, never materialising the 8x8 map.  feat: NHWC [F,H,W,C]; rois [N,5];
+ * out: [N, 7, 7, C] (bin-major, channel-contiguous == the fc6 A-operand after the load-time permutation of
+ * RCNN_top.0.weight).  C % 2 == 0, C <= 1024.  */
+int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, const float *rois, int N,
+                             float spatial_scale, float *out, void *stream);
+
+/* Layout helpers (weight re-layout at load; API-parity views): [N,C,H,W] <-> [N,H,W,C].  */
+int nafae_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream);
+int nafae_nhwc_to_nchw(const float *in, float *out, int N, int C, int H, int W, void *stream);
+
+/* ---- similarity + loss (DVSA.forward, model.py:517-614) ---------------------------------------- */
+
+/* S_ = V W^T with masked query slots, reduced on the fly to per-frame max / arg-max over the Nb proposals
+ * (model.py:548-551, 580-583, 610-612); S_ is never written to HBM.
+ * V [Na*Ns*Nb, D], W [Na*Ne, D], ent_len int32 [Na].
+ * S_max f32 [F, Q], D_ind int64 [F, Q] (F = Na*Ns, Q = Na*Ne).  D % 4 == 0.  */
+int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, int Na, int Ns, int Nb, int Ne,
+                      int D, float *S_max, int64_t *D_ind, void *stream);
+
+/* Bytes of workspace nafae_loss_fwd_bwd needs.  */
+int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D);
+
+/* Loss tail: ranking term with min-max frame attention (model.py:585-603), visual-clustering term
+ * (model.py:553-577, train only, including the reference's frame-0 gather quirk) and their gradient wrt
+ * S_max and wrt the gathered rows of V.
+ *   train != 0: margin_loss = 10*(mean(frame_score) + vis_lam*vis_loss)     (model.py:606)
+ *   train == 0: margin_loss = 10* mean(frame_score)
+ * loss_out: f32[4] = (margin_loss, mean frame_score, vis_loss, dem).
+ * dS: f32 [F,Q] = d margin_loss / d S_max.  The clustering gradient stays in `workspace` for
+ * nafae_sim_bwd.  */
+int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V, const int32_t *ent_len,
+                       int Na, int Ns, int Nb, int Ne, int D, float Delta, float vis_lam, int train,
+                       float *loss_out, float *dS, void *workspace, void *stream);
+
+/* Backward of the similarity: dV [R,D] (dense, arg-max rows + clustering rows), dW [Q,D].
+ * If pre_scale != NULL the VisEbd tail is fused: dV is multiplied elementwise by pre_scale [R,D]
+ * (= (1 - V^2) * dropout_mask * dropout_scale, the tanh/dropout backward of model.py:627-628).  */
+int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const float *W,
+                  const int32_t *ent_len, int Na, int Ns, int Nb, int Ne, int D, int train,
+                  const void *workspace, const float *pre_scale, float *dV, float *dW, void *stream);
+
+/* ---- small embedding-tail ops (model.py:624-642) ------------------------------------------------ */
+
+/* y = tanh(x * mask * scale) elementwise (mask may be NULL); n % 4 == 0.  VisEbd/WordEbd dropout+tanh.  */
+int nafae_dropout_tanh(const float *x, const uint8_t *mask, float scale, float *y, int64_t n, void *stream);
+/* g_in = g_out * (1 - y^2) * mask * scale.  */
+int nafae_dropout_tanh_bwd(const float *g_out, const float *y, const uint8_t *mask, float scale, float *g_in,
+                           int64_t n, void *stream);
+/* BatchNorm1d over rows of x [Q, D] (model.py:638,641).  training: batch statistics (biased variance for
+ * the normalisation, unbiased for the running update, momentum 0.1) else running statistics.
+ * save_mean / save_invstd: f32 [D] (written in training, used by the backward).  */
+int nafae_batchnorm_fwd(const float *x, const float *weight, const float *bias, float *running_mean,
+                        float *running_var, float *y, float *save_mean, float *save_invstd, int Q, int D,
+                        int training, float momentum, float eps, void *stream);
+int nafae_batchnorm_bwd(const float *g_y, const float *x, const float *weight, const float *save_mean,
+                        const float *save_invstd, float *g_x, float *g_weight, float *g_bias, int Q, int D,
+                        void *stream);
+/* out[j] = sum_i x[i, j]  (bias gradients).  */
+int nafae_colsum(const float *x, float *out, int rows, int cols, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAFAE_HIP_H */

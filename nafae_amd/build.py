@@ -1,0 +1,67 @@
+"""Ahead-of-time build of libnafae_hip.so (hipcc, gfx950 only; cross-compiles without a GPU).
+
+    python -m nafae_amd.build [--force]
+
+The shared library sits in-tree (nafae_amd/csrc/libnafae_hip.so) so that it travels to the GPU box with the
+repository snapshot; it links only against the HIP runtime (no torch types cross the C ABI).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(CSRC, "libnafae_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  proposal.hip must not fuse multiply-adds: its integer outputs (sort order, NMS keep
+# lists) are compared bit-for-bit with the CPU oracle.
+SOURCES = [
+    ("gemm.hip", []),
+    ("proposal.hip", ["-ffp-contract=off"]),
+    ("simloss.hip", []),
+]
+COMMON = ["-O3", "-fPIC", "--offload-arch=" + ARCH, "-fhip-fp32-correctly-rounded-divide-sqrt", "-std=c++17",
+          "-Wall", "-Wno-unused-function"]
+DEPS = ["mfma_tile.h", os.path.join(ROOT, "include", "nafae_hip.h")]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    deps_common = [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
+    objs = []
+    rebuilt = False
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + deps_common):
+            cmd = [_hipcc()] + COMMON + extra + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            rebuilt = True
+        objs.append(o)
+    if force or rebuilt or _stale(LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

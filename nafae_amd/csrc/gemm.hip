@@ -1,0 +1,499 @@
+// gemm.hip -- fp32-MFMA contractions of the detector and embedding layers (gfx950).
+//
+//   gemm_nt_kernel      C = act(alpha * A B^T + bias)      fc6 / fc7 / VisEbd.fc1 / WordEbd.fc1 / RPN 1x1 heads
+//   conv3x3_kernel      implicit GEMM over NHWC activations: M = F*H*W pixels, N = Cout, K = 9*Cin
+//   gemm_tn_kernel      C = alpha * A^T B (K-major operands): weight gradients of the two embedding layers
+//   conv1 / maxpool / layout kernels (bandwidth-bound, vector ALU)
+//
+// Reference call sites are cited next to each extern "C" entry point (declared in include/nafae_hip.h).
+#include "mfma_tile.h"
+#include "../../include/nafae_hip.h"
+
+using namespace nafae;
+
+namespace {
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == NAFAE_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == NAFAE_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+__device__ __forceinline__ f32x4 ldg4(const float *p, bool ok) {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return ok ? *reinterpret_cast<const f32x4 *>(p) : z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = act(alpha * A[M,K] B[N,K]^T + bias)
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const float *__restrict__ A, int lda,
+                                                           const float *__restrict__ B, int ldb,
+                                                           float *__restrict__ C, int ldc,
+                                                           const float *__restrict__ bias, int M, int N, int K,
+                                                           float alpha, int act, int tiles_m, int tiles_n) {
+  using E = Engine<BM, BN, WM, WN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = (K + BK - 1) / BK;
+
+  const float *pa[E::NA];
+  const float *pb[E::NB];
+  bool va[E::NA], vb[E::NB];
+#pragma unroll
+  for (int i = 0; i < E::NA; i++) {
+    int m = m0 + e.srow + 32 * i;
+    va[i] = m < M;
+    pa[i] = A + (size_t)(va[i] ? m : 0) * lda + e.slot * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < E::NB; i++) {
+    int n = n0 + e.srow + 32 * i;
+    vb[i] = n < N;
+    pb[i] = B + (size_t)(vb[i] ? n : 0) * ldb + e.slot * 4;
+  }
+  f32x4 ra[E::NA], rb[E::NB];
+  auto fetch = [&](int kt) {
+    const int k = kt * BK + e.slot * 4;
+    const bool kin = k < K;
+#pragma unroll
+    for (int i = 0; i < E::NA; i++) ra[i] = ldg4(pa[i] + kt * BK, va[i] && kin);
+#pragma unroll
+    for (int i = 0; i < E::NB; i++) rb[i] = ldg4(pb[i] + kt * BK, vb[i] && kin);
+  };
+
+  fetch(0);
+  e.store_stage(smem, ra, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    float *cur = smem + (kt & 1) * E::STAGE;
+    float *nxt = smem + ((kt + 1) & 1) * E::STAGE;
+    if (kt + 1 < nk) fetch(kt + 1);
+    e.compute(cur);
+    if (kt + 1 < nk) e.store_stage(nxt, ra, rb);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < E::TN; j++) {
+    const int n = n0 + e.acc_col(j);
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < E::TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + e.acc_row(i, r);
+        if (m < M) C[(size_t)m * ldc + n] = apply_act(alpha * e.acc[i][j][r] + bv, act);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv, pad 1, stride 1, NHWC, as implicit GEMM.  k-tile kt <-> (tap = kt / (Cin/32), 32 channels).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restrict__ in,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ bias,
+                                                           float *__restrict__ out, int F, int H, int W, int Cin,
+                                                           int Cout, int relu, int tiles_m, int tiles_n) {
+  using E = Engine<BM, BN, WM, WN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int M = F * H * W;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int cpt = Cin / BK;  // k-tiles per tap
+  const int nk = 9 * cpt;
+  const int K = 9 * Cin;
+
+  int py[E::NA], px[E::NA];
+  const float *pa[E::NA];
+  bool va[E::NA];
+#pragma unroll
+  for (int i = 0; i < E::NA; i++) {
+    int m = m0 + e.srow + 32 * i;
+    va[i] = m < M;
+    int mm = va[i] ? m : 0;
+    int x = mm % W;
+    int y = (mm / W) % H;
+    px[i] = x;
+    py[i] = y;
+    pa[i] = in + (size_t)mm * Cin + e.slot * 4;
+  }
+  const float *pb[E::NB];
+  bool vb[E::NB];
+#pragma unroll
+  for (int i = 0; i < E::NB; i++) {
+    int n = n0 + e.srow + 32 * i;
+    vb[i] = n < Cout;
+    pb[i] = w + (size_t)(vb[i] ? n : 0) * K + e.slot * 4;
+  }
+  f32x4 ra[E::NA], rb[E::NB];
+  auto fetch = [&](int kt) {
+    const int tap = kt / cpt;
+    const int cc = kt - tap * cpt;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int aoff = (dy * W + dx) * Cin + cc * BK;
+#pragma unroll
+    for (int i = 0; i < E::NA; i++) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = va[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      ra[i] = ldg4(pa[i] + aoff, ok);
+    }
+#pragma unroll
+    for (int i = 0; i < E::NB; i++) rb[i] = ldg4(pb[i] + kt * BK, vb[i]);
+  };
+
+  fetch(0);
+  e.store_stage(smem, ra, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    float *cur = smem + (kt & 1) * E::STAGE;
+    float *nxt = smem + ((kt + 1) & 1) * E::STAGE;
+    if (kt + 1 < nk) fetch(kt + 1);
+    e.compute(cur);
+    if (kt + 1 < nk) e.store_stage(nxt, ra, rb);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < E::TN; j++) {
+    const int n = n0 + e.acc_col(j);
+    if (n >= Cout) continue;
+    const float bv = bias[n];
+#pragma unroll
+    for (int i = 0; i < E::TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + e.acc_row(i, r);
+        if (m < M) {
+          float v = e.acc[i][j][r] + bv;
+          out[(size_t)m * Cout + n] = (relu && v < 0.f) ? 0.f : v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = alpha * A[K,M]^T B[K,N] (+C).  LDS tiles are [32 k][BM] / [32 k][BN] (the HBM layout); each MFMA
+// operand is one ds_read_b32 per lane (consecutive lanes -> consecutive m: conflict-free).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const float *__restrict__ A, int lda,
+                                                           const float *__restrict__ B, int ldb,
+                                                           float *__restrict__ C, int ldc, int M, int N, int K,
+                                                           float alpha, int accumulate, int tiles_m, int tiles_n,
+                                                           int k_chunk) {
+  constexpr int TM = BM / 64, TN = BN / 64;  // waves 2 x 2
+  constexpr int NA = BM / 32, NB = BN / 32;  // float4 chunks per thread per tile (32*BM/4/256)
+  constexpr int STAGE = (BM + BN) * BK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  const int tiles = tiles_m * tiles_n;
+  const int ks = blockIdx.x / tiles;  // split-K slice (atomic accumulate when > 1 slice)
+  tile_coords(blockIdx.x - ks * tiles, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int k_begin = ks * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  f32x4 ra[NA], rb[NB];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      int c = tid + NTHREADS * i;
+      int kr = c / (BM / 4), mc = c % (BM / 4);
+      int k = k_begin + kt * BK + kr, m = m0 + mc * 4;
+      ra[i] = ldg4(A + (size_t)k * lda + m, k < k_end && m < M);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      int c = tid + NTHREADS * i;
+      int kr = c / (BN / 4), nc = c % (BN / 4);
+      int k = k_begin + kt * BK + kr, n = n0 + nc * 4;
+      rb[i] = ldg4(B + (size_t)k * ldb + n, k < k_end && n < N);
+    }
+  };
+  auto store = [&](float *stage) {
+#pragma unroll
+    for (int i = 0; i < NA; i++) *reinterpret_cast<f32x4 *>(&stage[(tid + NTHREADS * i) * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; i++) *reinterpret_cast<f32x4 *>(&stage[BM * BK + (tid + NTHREADS * i) * 4]) = rb[i];
+  };
+  auto compute = [&](const float *stage) {
+    const float *sA = stage, *sB = stage + BM * BK;
+    const int r31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; kp++) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a[i] = sA[(kp * 2 + hi) * BM + wm * (TM * 32) + i * 32 + r31];
+#pragma unroll
+      for (int j = 0; j < TN; j++) b[j] = sB[(kp * 2 + hi) * BN + wn * (TN * 32) + j * 32 + r31];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) {
+    fetch(0);
+    store(smem);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    float *cur = smem + (kt & 1) * STAGE;
+    float *nxt = smem + ((kt + 1) & 1) * STAGE;
+    if (kt + 1 < nk) fetch(kt + 1);
+    compute(cur);
+    if (kt + 1 < nk) store(nxt);
+    __syncthreads();
+  }
+  const bool atomic = gridDim.x > (unsigned)tiles;
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) {
+          float *p = &C[(size_t)m * ldc + n];
+          float v = alpha * acc[i][j][r];
+          if (atomic) atomicAdd(p, v);
+          else *p = accumulate ? (*p + v) : v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First VGG layer (Cin = 3): direct conv on the vector ALU.  One thread = one pixel x 16 output channels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                    const float *__restrict__ bias, float *__restrict__ out,
+                                                    int F, int H, int W) {
+  __shared__ float sw[27 * 64];  // [k][cout]
+  __shared__ float sb[64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    int co = i & 63, k = i >> 6;
+    sw[i] = w[co * 27 + k];
+  }
+  if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const long total = (long)F * H * W;
+  // one pass per block (no grid-stride loop: the compiler would hoist all 27x16 LDS weights into registers)
+  const long p = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (p >= total) return;
+  const int cg = (threadIdx.x & 3) * 16;
+  const int x = p % W;
+  const int y = (p / W) % H;
+  const long n = p / ((long)W * H);
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) acc[c] = sb[cg + c];
+#pragma unroll
+  for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((n * 3 + ci) * H + yy) * W + xx];
+        const float *wk = &sw[(ci * 9 + ky * 3 + kx) * 64 + cg];
+#pragma unroll
+        for (int c = 0; c < 16; c++) acc[c] = fmaf(v, wk[c], acc[c]);
+      }
+  f32x4 *o = reinterpret_cast<f32x4 *>(out + p * 64 + cg);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    f32x4 v = {fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
+               fmaxf(acc[4 * q + 3], 0.f)};
+    o[q] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                      int F, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const long total = (long)F * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C4;
+    long t = i / C4;
+    const int x = t % Wo;
+    t /= Wo;
+    const int y = t % Ho;
+    const long n = t / Ho;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(in + ((n * H + 2 * y) * W + 2 * x) * (long)C) + c;
+    f32x4 a = p[0], b = p[C4], d = p[(long)W * C4], e = p[(long)W * C4 + C4];
+    f32x4 m;
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(d[k], e[k]));
+    reinterpret_cast<f32x4 *>(out)[i] = m;
+  }
+}
+
+// [N, C, HW] <-> [N, HW, C] through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        int rows, int cols) {
+  // in: [batch][rows][cols] -> out: [batch][cols][rows]
+  __shared__ float t[32][33];
+  const long b = blockIdx.z;
+  const float *ib = in + b * (long)rows * cols;
+  float *ob = out + b * (long)rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) t[j][tx] = ib[(long)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, r = r0 + tx;
+    if (r < rows && c < cols) ob[(long)c * rows + r] = t[tx][j];
+  }
+}
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int BM, int BN, int WM, int WN>
+void launch_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M,
+                    int N, int K, float alpha, int act, hipStream_t st) {
+  using E = Engine<BM, BN, WM, WN>;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * E::STAGE * sizeof(float);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(NTHREADS), lds, st, A, lda, B,
+                     ldb, C, ldc, bias, M, N, K, alpha, act, tiles_m, tiles_n);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_conv(const float *in, const float *w, const float *bias, float *out, int F, int H, int W, int Cin,
+                 int Cout, int relu, hipStream_t st) {
+  using E = Engine<BM, BN, WM, WN>;
+  const int M = F * H * W;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
+  const size_t lds = 2 * E::STAGE * sizeof(float);
+  hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(NTHREADS), lds, st, in, w, bias,
+                     out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M,
+                  int N, int K, float alpha, int act, void *stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
+  if ((K & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
+  if (lda < K || ldb < K || ldc < N) return NAFAE_EINVAL;
+  if (N <= 64)
+    launch_gemm_nt<128, 64, 4, 1>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
+  else
+    launch_gemm_nt<128, 128, 2, 2>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
+  return NAFAE_OK;
+}
+
+int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
+                  float alpha, int accumulate, void *stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
+  if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
+  constexpr int BM = 128, BN = 128;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * (BM + BN) * BK * sizeof(float);
+  // split K so that ~2 workgroups per CU exist; slices accumulate with fp32 atomics into a zeroed C
+  int tiles = tiles_m * tiles_n;
+  int splits = 1;
+  const int nk_total = (K + BK - 1) / BK;
+  if (!accumulate) {
+    while (tiles * splits < 512 && nk_total / (splits * 2) >= 8) splits *= 2;
+  }
+  int k_chunk = ((nk_total + splits - 1) / splits) * BK;
+  splits = (K + k_chunk - 1) / k_chunk;
+  if (splits > 1) {
+    hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, S(stream));
+    if (e != hipSuccess) return NAFAE_EINVAL;
+  }
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tiles * splits), dim3(NTHREADS), lds, S(stream), A, lda, B, ldb, C,
+                     ldc, M, N, K, alpha, accumulate, tiles_m, tiles_n, k_chunk);
+  return NAFAE_OK;
+}
+
+int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias, float *out_nhwc, int F, int H,
+                         int W, void *stream) {
+  if (!in_nchw || !w || !bias || !out_nhwc || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
+  long total = (long)F * H * W;
+  if ((total + 63) / 64 > 0x7fffffffL) return NAFAE_ELIMIT;
+  int blocks = (int)((total + 63) / 64);
+  hipLaunchKernelGGL(conv1_kernel, dim3(blocks), dim3(256), 0, S(stream), in_nchw, w, bias, out_nhwc, F, H, W);
+  return NAFAE_OK;
+}
+
+int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float *out, int F, int H, int W, int Cin,
+                       int Cout, int relu, void *stream) {
+  if (!in || !w || !bias || !out || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
+  if (Cin % 32 || Cout % 4 || !aligned16(in) || !aligned16(w)) return NAFAE_EINVAL;
+  if ((long)F * H * W >= (1L << 31) / 1) return NAFAE_ELIMIT;
+  if (Cout <= 64)
+    launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
+  else
+    launch_conv<128, 128, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
+  return NAFAE_OK;
+}
+
+int nafae_maxpool2x2(const float *in, float *out, int F, int H, int W, int C, void *stream) {
+  if (!in || !out || F <= 0 || (H & 1) || (W & 1) || (C & 3)) return NAFAE_EINVAL;
+  long total = (long)F * (H / 2) * (W / 2) * (C / 4);
+  int blocks = (int)((total + 255) / 256 < 256 * 8 ? (total + 255) / 256 : 256 * 8);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, S(stream), in, out, F, H, W, C);
+  return NAFAE_OK;
+}
+
+int nafae_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535) return NAFAE_EINVAL;
+  int rows = C, cols = H * W;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, S(stream), in, out,
+                     rows, cols);
+  return NAFAE_OK;
+}
+
+int nafae_nhwc_to_nchw(const float *in, float *out, int N, int C, int H, int W, void *stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535) return NAFAE_EINVAL;
+  int rows = H * W, cols = C;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, S(stream), in, out,
+                     rows, cols);
+  return NAFAE_OK;
+}
+
+int nafae_version(char *buf, int cap) {
+  static const char v[] = "nafae_hip 0.1 gfx950";
+  if (!buf || cap <= 0) return NAFAE_EINVAL;
+  int i = 0;
+  for (; i < cap - 1 && v[i]; i++) buf[i] = v[i];
+  buf[i] = 0;
+  return NAFAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,746 @@
+// simloss.hip -- region x query similarity, contextual-similarity (ranking) loss, visual-clustering loss and
+// their backward, for gfx950.  Restates DVSA.forward (reference model.py:517-614) as five kernels:
+//
+//   sim_max_kernel     S_ = V W^T on fp32 MFMA, masked, reduced on the fly to per-frame max / arg-max over the Nb
+//                      proposals (model.py:548-551, 580-583, 610-612).  S_ never reaches HBM.
+//   loss_tail_kernel   O(F*Q) ranking term with min-max frame attention + its gradient wrt S_max
+//                      (model.py:585-603); one workgroup, everything stays in L2/LDS.
+//   cluster_kernel     visual-clustering term per (segment, entity) incl. the reference's frame-0 gather quirk
+//                      (model.py:553-577) and its gradient wrt the gathered rows.
+//   loss_final_kernel  dem / vis_loss / margin_loss (model.py:576-577, 606).
+//   sim_bwd_dv/dw      dV (arg-max rows + clustering rows, optional fused tanh/dropout backward) and dW.
+//
+// All reductions run in a fixed order (no float atomics), so results are bit-reproducible run to run.
+#include "mfma_tile.h"
+#include "../../include/nafae_hip.h"
+
+using namespace nafae;
+
+namespace {
+
+constexpr float EPS = 1e-5f;  // model.py:33
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ f32x4 ldg4(const float *p, bool ok) {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return ok ? *reinterpret_cast<const f32x4 *>(p) : z;
+}
+
+// ------------------------------------------------------------------------------------------------ sim + max
+// grid (ceil(Q/32), F); block 256 = 4 waves x (32 proposals x 32 queries) MFMA tiles; proposals of the frame are
+// walked in chunks of 128.
+__global__ __launch_bounds__(NTHREADS) void sim_max_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
+                                                           const int32_t *__restrict__ ent_len, int Nb, int Ne, int Q,
+                                                           int D, float *__restrict__ S_max,
+                                                           int64_t *__restrict__ D_ind) {
+  using E = Engine<128, 32, 4, 1>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *stile = smem + 2 * E::STAGE;                       // [128][33]
+  float *pv = stile + 128 * 33;                             // [8][32] partial max
+  int *pi = reinterpret_cast<int *>(pv + 8 * 32);           // [8][32] partial arg-max
+  E e;
+  e.init();
+  const int f = blockIdx.y, q0 = blockIdx.x * 32;
+  const int tid = threadIdx.x;
+  const int nk = (D + BK - 1) / BK;
+  const int col = tid & 31, grp = tid >> 5;
+  float best = -INFINITY;
+  int best_i = 0;
+
+  const int qrow = q0 + e.srow;  // B tile has 32 rows: thread (srow, slot) stages exactly one chunk
+  const bool vb = qrow < Q;
+  const float *pb = Wm + (size_t)(vb ? qrow : 0) * D + e.slot * 4;
+
+  for (int chunk = 0; chunk < Nb; chunk += 128) {
+    e.zero_acc();
+    const float *pa[E::NA];
+    bool va[E::NA];
+#pragma unroll
+    for (int i = 0; i < E::NA; i++) {
+      const int r = chunk + e.srow + 32 * i;
+      va[i] = r < Nb;
+      pa[i] = V + ((size_t)f * Nb + (va[i] ? r : 0)) * D + e.slot * 4;
+    }
+    f32x4 ra[E::NA], rb[E::NB];
+    auto fetch = [&](int kt) {
+      const bool kin = kt * BK + e.slot * 4 < D;
+#pragma unroll
+      for (int i = 0; i < E::NA; i++) ra[i] = ldg4(pa[i] + kt * BK, va[i] && kin);
+      rb[0] = ldg4(pb + kt * BK, vb && kin);
+    };
+    fetch(0);
+    e.store_stage(smem, ra, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+      float *cur = smem + (kt & 1) * E::STAGE;
+      float *nxt = smem + ((kt + 1) & 1) * E::STAGE;
+      if (kt + 1 < nk) fetch(kt + 1);
+      e.compute(cur);
+      if (kt + 1 < nk) e.store_stage(nxt, ra, rb);
+      __syncthreads();
+    }
+    const int c = e.acc_col(0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) stile[e.acc_row(0, r) * 33 + c] = e.acc[0][0][r];
+    __syncthreads();
+    // column scan: thread (grp, col) owns rows grp*16 .. grp*16+15 of the chunk, in ascending order
+#pragma unroll 4
+    for (int r = 0; r < 16; r++) {
+      const int row = grp * 16 + r;
+      if (chunk + row < Nb) {
+        const float v = stile[row * 33 + col];
+        if (v > best) {
+          best = v;
+          best_i = chunk + row;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  pv[grp * 32 + col] = best;
+  pi[grp * 32 + col] = best_i;
+  __syncthreads();
+  if (tid < 32) {
+    float bv = pv[tid];
+    int bi = pi[tid];
+#pragma unroll
+    for (int g = 1; g < 8; g++) {
+      const float v = pv[g * 32 + tid];
+      const int i = pi[g * 32 + tid];
+      if (v > bv || (v == bv && i < bi)) {  // first maximal index, like torch.max(dim)
+        bv = v;
+        bi = i;
+      }
+    }
+    const int q = q0 + tid;
+    if (q < Q) {
+      const int a = q / Ne, en = q - a * Ne;
+      if (en >= ent_len[a]) {  // masked query slot: the whole S_ column is 0 (model.py:551)
+        bv = 0.f;
+        bi = 0;
+      }
+      S_max[(size_t)f * Q + q] = bv;
+      D_ind[(size_t)f * Q + q] = (int64_t)bi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct LossWs {
+  // float offsets into the workspace
+  size_t mn, mx, amin, amax;    // [Na*Q]  (amin/amax are int32)
+  size_t Sf, dSf;               // [Na*Ns*Na]
+  size_t fs, cs1, rs2;          // [Na*Ns]
+  size_t scal;                  // [8]: rank, cscale, vis, dem
+  size_t part_sum, part_cnt;    // [Na*Ne]
+  size_t cidx;                  // [Na*Ne*Ns] int32
+  size_t dgc;                   // [Na*Ne*Ns*D]
+  size_t total;
+};
+
+__host__ __device__ inline LossWs loss_ws(int Na, int Ns, int Nb, int Ne, int D) {
+  LossWs w;
+  size_t o = 0;
+  const size_t Q = (size_t)Na * Ne;
+  auto take = [&](size_t n) {
+    size_t r = o;
+    o += (n + 3) & ~(size_t)3;
+    return r;
+  };
+  w.mn = take(Na * Q);
+  w.mx = take(Na * Q);
+  w.amin = take(Na * Q);
+  w.amax = take(Na * Q);
+  w.Sf = take((size_t)Na * Ns * Na);
+  w.dSf = take((size_t)Na * Ns * Na);
+  w.fs = take((size_t)Na * Ns);
+  w.cs1 = take((size_t)Na * Ns);
+  w.rs2 = take((size_t)Na * Ns);
+  w.scal = take(8);
+  w.part_sum = take(Q);
+  w.part_cnt = take(Q);
+  w.cidx = take(Q * Ns);
+  w.dgc = take(Q * Ns * D);
+  w.total = o;
+  (void)Nb;
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------ ranking term
+// S is S_max viewed as [Na, Ns, Q].  One workgroup of 1024 threads; phases separated by __syncthreads().
+__global__ __launch_bounds__(1024) void loss_tail_kernel(const float *__restrict__ Sm,
+                                                         const int32_t *__restrict__ ent_len, int Na, int Ns, int Ne,
+                                                         float Delta, float *__restrict__ dS, float *__restrict__ ws,
+                                                         LossWs L) {
+  const int Q = Na * Ne;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float *mn = ws + L.mn, *mx = ws + L.mx;
+  int *amin = reinterpret_cast<int *>(ws + L.amin), *amax = reinterpret_cast<int *>(ws + L.amax);
+  float *Sf = ws + L.Sf, *dSf = ws + L.dSf, *fs = ws + L.fs, *cs1 = ws + L.cs1, *rs2 = ws + L.rs2;
+  float *scal = ws + L.scal;
+
+  // A: per (a, q): min / max over the Ns frames of segment a, first-occurrence indices (model.py:587)
+  for (int i = tid; i < Na * Q; i += nt) {
+    const int a = i / Q, q = i - a * Q;
+    float lo = INFINITY, hi = -INFINITY;
+    int ilo = 0, ihi = 0;
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sm[((size_t)a * Ns + s) * Q + q];
+      if (v < lo) {
+        lo = v;
+        ilo = s;
+      }
+      if (v > hi) {
+        hi = v;
+        ihi = s;
+      }
+    }
+    mn[i] = lo;
+    mx[i] = hi;
+    amin[i] = ilo;
+    amax[i] = ihi;
+  }
+  __syncthreads();
+  // B: Sf[a,s,j] = sum_e S*att / max(len_j,1)   (model.py:588-592)
+  for (int i = tid; i < Na * Ns * Na; i += nt) {
+    const int j = i % Na;
+    const int as = i / Na;
+    const int a = as / Ns;
+    float acc = 0.f;
+    for (int en = 0; en < Ne; en++) {
+      const int q = j * Ne + en;
+      const float v = Sm[(size_t)as * Q + q];
+      const float lo = mn[a * Q + q], hi = mx[a * Q + q];
+      acc += v * ((v - lo) / (hi - lo + EPS));
+    }
+    const int l = ent_len[j];
+    Sf[i] = acc / (float)(l == 0 ? 1 : l);
+  }
+  __syncthreads();
+  // C: frame_score (model.py:603) and the hinge-active counts its backward needs
+  for (int i = tid; i < Na * Ns; i += nt) {
+    const int a = i / Ns, s = i - a * Ns;
+    const float diag = Sf[(a * Ns + s) * Na + a];
+    float t1 = 0.f, t2 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k = 0; k < Na; k++) {
+      const float u1 = Sf[(k * Ns + s) * Na + a] - diag + Delta;  // column a, rows k
+      const float u2 = Sf[(a * Ns + s) * Na + k] - diag + Delta;  // row a, columns k
+      if (u1 > 0.f) {
+        t1 += u1;
+        c1 += 1.f;
+      }
+      if (u2 > 0.f) {
+        t2 += u2;
+        c2 += 1.f;
+      }
+    }
+    fs[i] = t1 / (float)Na + t2 / (float)Na;
+    cs1[i] = c1;
+    rs2[i] = c2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < Na * Ns; i++) acc += fs[i];
+    scal[0] = acc / (float)(Na * Ns);
+  }
+  if (dS == nullptr) return;
+  // E: d(10 * mean fs) / dSf
+  const float cN = 10.0f / (float)(Na * Ns) / (float)Na;
+  for (int i = tid; i < Na * Ns * Na; i += nt) {
+    const int j = i % Na;
+    const int as = i / Na;
+    const int a = as / Ns, s = as - a * Ns;
+    const float v = Sf[i];
+    const float g1 = (v - Sf[(j * Ns + s) * Na + j] + Delta > 0.f) ? 1.f : 0.f;
+    const float g2 = (v - Sf[(a * Ns + s) * Na + a] + Delta > 0.f) ? 1.f : 0.f;
+    float g = cN * (g1 + g2);
+    if (a == j) g -= cN * (cs1[a * Ns + s] + rs2[a * Ns + s]);
+    dSf[i] = g;
+  }
+  __syncthreads();
+  // F: back through S*att with the min / max paths (model.py:587-588)
+  for (int i = tid; i < Na * Q; i += nt) {
+    const int a = i / Q, q = i - a * Q;
+    const int j = q / Ne, en = q - j * Ne;
+    const bool masked = en >= ent_len[j];
+    const int l = ent_len[j];
+    const float inv_div = 1.0f / (float)(l == 0 ? 1 : l);
+    const float lo = mn[i], hi = mx[i];
+    const float den = hi - lo + EPS;
+    float gmn = 0.f, gmx = 0.f;
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sm[((size_t)a * Ns + s) * Q + q];
+      const float dT = dSf[(a * Ns + s) * Na + j] * inv_div;
+      gmn += dT * v * (v - hi - EPS) / (den * den);
+      gmx -= dT * v * (v - lo) / (den * den);
+    }
+    const int ilo = amin[i], ihi = amax[i];
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sm[((size_t)a * Ns + s) * Q + q];
+      const float dT = dSf[(a * Ns + s) * Na + j] * inv_div;
+      float g = dT * ((v - lo) / den + v / den);
+      if (s == ilo) g += gmn;
+      if (s == ihi) g += gmx;
+      dS[((size_t)a * Ns + s) * Q + q] = masked ? 0.f : g;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ clustering term
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  // 256 threads; result broadcast to all
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grid Na*Ne, block 256.  Dynamic LDS: g[Ns][D] raw gathered rows, G[Ns][D] normalised * sn.
+__global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
+                                                      const float *__restrict__ V,
+                                                      const int32_t *__restrict__ ent_len, int Na, int Ns, int Ne,
+                                                      int D, float *__restrict__ ws, LossWs L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float red[4];
+  __shared__ float s_sn[64], s_nrm[64], s_dot[64];
+  __shared__ int s_idx[64];
+  float *g = sm, *G = sm + (size_t)Ns * D;
+  const int ae = blockIdx.x, a = ae / Ne, en = ae - a * Ne;
+  const int Q = Na * Ne, q = a * Ne + en;
+  const int tid = threadIdx.x;
+  float *part_sum = ws + L.part_sum, *part_cnt = ws + L.part_cnt;
+  int *cidx = reinterpret_cast<int *>(ws + L.cidx) + (size_t)ae * Ns;
+  float *dgc = ws + L.dgc + (size_t)ae * Ns * D;
+  if (en >= ent_len[a]) {  // padded entity slot: masked out of the loss (model.py:540-542)
+    if (tid == 0) {
+      part_sum[ae] = 0.f;
+      part_cnt[ae] = 0.f;
+    }
+    for (int s = tid; s < Ns; s += 256) cidx[s] = -1;
+    return;
+  }
+  const float lo = ws[L.mn + a * Q + q], hi = ws[L.mx + a * Q + q];
+  for (int s = tid; s < Ns; s += 256) {
+    const size_t o = ((size_t)a * Ns + s) * Q + q;
+    s_sn[s] = (Sm[o] - lo) / (hi - lo + EPS);  // model.py:567 (no grad)
+    const int ix = (int)D_ind[o];              // in [0, Nb): indexes V WITHOUT a frame offset (model.py:562-569)
+    s_idx[s] = ix;
+    cidx[s] = ix;
+  }
+  __syncthreads();
+  for (int s = 0; s < Ns; s++) {
+    float acc = 0.f;
+    for (int d = tid; d < D; d += 256) {
+      const float v = V[(size_t)s_idx[s] * D + d];
+      g[s * D + d] = v;
+      acc += v * v;
+    }
+    acc = block_sum(acc, red);
+    if (tid == 0) s_nrm[s] = sqrtf(acc);
+  }
+  __syncthreads();
+  for (int s = 0; s < Ns; s++) {
+    const float inv = 1.0f / (s_nrm[s] + EPS);  // (g / (norm + EPS)) * sn   (model.py:570-571)
+    for (int d = tid; d < D; d += 256) G[s * D + d] = (g[s * D + d] / (s_nrm[s] + EPS)) * s_sn[s];
+    (void)inv;
+  }
+  __syncthreads();
+  // gram: 1 - G_s . G_s' for s != s' (model.py:574-575); sum and count of non-zeros (model.py:576)
+  float lsum = 0.f, lcnt = 0.f;
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int p = wave; p < Ns * Ns; p += 4) {
+    const int s1 = p / Ns, s2 = p - s1 * Ns;
+    if (s1 == s2) continue;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) acc += G[s1 * D + d] * G[s2 * D + d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const float m = 1.0f - acc;
+    if (lane == 0) {
+      lsum += m;
+      if (m != 0.f) lcnt += 1.f;
+    }
+  }
+  // (lane 0 of each wave holds its partials; everyone else 0)
+  lsum = block_sum(lsum, red);
+  lcnt = block_sum(lcnt, red);
+  if (tid == 0) {
+    part_sum[ae] = lsum;
+    part_cnt[ae] = lcnt;
+  }
+  // gradient wrt the gathered rows, unscaled by 10*vis_lam/dem: dG_s = -2 (sum_s' G_s' - G_s)
+  for (int s = 0; s < Ns; s++) {
+    float acc = 0.f;
+    for (int d = tid; d < D; d += 256) {
+      float tot = 0.f;
+      for (int s2 = 0; s2 < Ns; s2++) tot += G[s2 * D + d];
+      const float dG = -2.0f * (tot - G[s * D + d]);
+      acc += g[s * D + d] * dG;
+    }
+    acc = block_sum(acc, red);
+    if (tid == 0) s_dot[s] = acc;
+  }
+  __syncthreads();
+  for (int s = 0; s < Ns; s++) {
+    const float n = s_nrm[s], ne = n + EPS, sn = s_sn[s];
+    // u = g/(n+EPS), G = sn*u;  dg = sn * ( dG/(n+EPS) - g * (g.dG) / (n * (n+EPS)^2) )
+    const float k2 = s_dot[s] / (n * ne * ne);
+    for (int d = tid; d < D; d += 256) {
+      float tot = 0.f;
+      for (int s2 = 0; s2 < Ns; s2++) tot += G[s2 * D + d];
+      const float dG = -2.0f * (tot - G[s * D + d]);
+      dgc[(size_t)s * D + d] = sn * (dG / ne - g[s * D + d] * k2);
+    }
+  }
+}
+
+__global__ void loss_final_kernel(float *__restrict__ ws, LossWs L, int Na, int Ne, float vis_lam, int train,
+                                  float *__restrict__ loss_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float *scal = ws + L.scal;
+  const float rank = scal[0];
+  float vis = 0.f, dem = 0.f, cscale = 0.f;
+  if (train) {
+    float sum = 0.f;
+    for (int i = 0; i < Na * Ne; i++) {
+      sum += ws[L.part_sum + i];
+      dem += ws[L.part_cnt + i];
+    }
+    vis = sum / dem;  // dem == 0 -> NaN/Inf exactly like the reference (model.py:577)
+    cscale = 10.0f * vis_lam / dem;
+  }
+  scal[1] = cscale;
+  scal[2] = vis;
+  scal[3] = dem;
+  loss_out[0] = train ? (rank + vis_lam * vis) * 10.0f : rank * 10.0f;  // model.py:606
+  loss_out[1] = rank;
+  loss_out[2] = vis;
+  loss_out[3] = dem;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+constexpr int MAXCH = 8;  // D <= 2048 : float4 chunks per lane
+
+// one wave per region row r
+__global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
+                                                         const float *__restrict__ Wm, int R, int Nb, int Q, int D,
+                                                         int train, int n_centries, const float *__restrict__ ws,
+                                                         LossWs L, const float *__restrict__ pre_scale,
+                                                         float *__restrict__ dV) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int f = r / Nb, b = r - f * Nb;
+  f32x4 acc[MAXCH];
+#pragma unroll
+  for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int qb = 0; qb < Q; qb += 64) {
+    const int q = qb + lane;
+    bool hit = false;
+    float ds = 0.f;
+    if (q < Q) {
+      ds = dS[(size_t)f * Q + q];
+      hit = ((int)D_ind[(size_t)f * Q + q] == b) && ds != 0.f;
+    }
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int i = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const float w = __shfl(ds, i);
+      const float *wr = Wm + (size_t)(qb + i) * D;
+#pragma unroll
+      for (int c = 0; c < MAXCH; c++) {
+        const int d = lane * 4 + c * 256;
+        if (d < D) {
+          const f32x4 x = *reinterpret_cast<const f32x4 *>(wr + d);
+          acc[c] += w * x;
+        }
+      }
+    }
+  }
+  if (train && r < Nb) {  // clustering gradient lands on rows [0, Nb) only (reference quirk)
+    const int *cidx = reinterpret_cast<const int *>(ws + L.cidx);
+    const float cscale = ws[L.scal + 1];
+    for (int tb = 0; tb < n_centries; tb += 64) {
+      const int t = tb + lane;
+      const bool hit = t < n_centries && cidx[t] == r;
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float *gr = ws + L.dgc + (size_t)(tb + i) * D;
+#pragma unroll
+        for (int c = 0; c < MAXCH; c++) {
+          const int d = lane * 4 + c * 256;
+          if (d < D) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(gr + d);
+            acc[c] += cscale * x;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MAXCH; c++) {
+    const int d = lane * 4 + c * 256;
+    if (d < D) {
+      f32x4 v = acc[c];
+      if (pre_scale) v *= *reinterpret_cast<const f32x4 *>(pre_scale + (size_t)r * D + d);
+      *reinterpret_cast<f32x4 *>(dV + (size_t)r * D + d) = v;
+    }
+  }
+}
+
+// one wave per query column q
+__global__ __launch_bounds__(256) void sim_bwd_dw_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
+                                                         const float *__restrict__ V, int F, int Nb, int Q, int D,
+                                                         float *__restrict__ dW) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  f32x4 acc[MAXCH];
+#pragma unroll
+  for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < F; f++) {
+    const float ds = dS[(size_t)f * Q + q];
+    if (ds == 0.f) continue;
+    const float *vr = V + ((size_t)f * Nb + (int)D_ind[(size_t)f * Q + q]) * D;
+#pragma unroll
+    for (int c = 0; c < MAXCH; c++) {
+      const int d = lane * 4 + c * 256;
+      if (d < D) acc[c] += ds * *reinterpret_cast<const f32x4 *>(vr + d);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MAXCH; c++) {
+    const int d = lane * 4 + c * 256;
+    if (d < D) *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = acc[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding tails
+__global__ __launch_bounds__(256) void dropout_tanh_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                           float scale, float *__restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+    if (mask) {
+      const uchar4 m = reinterpret_cast<const uchar4 *>(mask)[i];
+      v[0] = v[0] * (float)m.x * scale;
+      v[1] = v[1] * (float)m.y * scale;
+      v[2] = v[2] * (float)m.z * scale;
+      v[3] = v[3] * (float)m.w * scale;
+    }
+    f32x4 o = {tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
+    reinterpret_cast<f32x4 *>(y)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_tanh_bwd_kernel(const float *__restrict__ go, const float *__restrict__ y,
+                                                               const uint8_t *__restrict__ mask, float scale,
+                                                               float *__restrict__ gi, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 g = reinterpret_cast<const f32x4 *>(go)[i];
+    const f32x4 t = reinterpret_cast<const f32x4 *>(y)[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = g[k] * (1.0f - t[k] * t[k]);
+    if (mask) {
+      const uchar4 m = reinterpret_cast<const uchar4 *>(mask)[i];
+      o[0] = o[0] * (float)m.x * scale;
+      o[1] = o[1] * (float)m.y * scale;
+      o[2] = o[2] * (float)m.z * scale;
+      o[3] = o[3] * (float)m.w * scale;
+    }
+    reinterpret_cast<f32x4 *>(gi)[i] = o;
+  }
+}
+
+// BatchNorm1d, one thread per feature column (Q is a few hundred rows at most)
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                     const float *__restrict__ b, float *__restrict__ rmean,
+                                                     float *__restrict__ rvar, float *__restrict__ y,
+                                                     float *__restrict__ smean, float *__restrict__ sinv, int Q, int D,
+                                                     int training, float momentum, float eps) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float mean, inv;
+  if (training) {
+    float s = 0.f;
+    for (int q = 0; q < Q; q++) s += x[(size_t)q * D + d];
+    mean = s / (float)Q;
+    float v = 0.f;
+    for (int q = 0; q < Q; q++) {
+      const float t = x[(size_t)q * D + d] - mean;
+      v += t * t;
+    }
+    const float var_b = v / (float)Q;
+    inv = 1.0f / sqrtf(var_b + eps);
+    if (rmean) {
+      const float var_u = Q > 1 ? v / (float)(Q - 1) : var_b;
+      rmean[d] = (1.0f - momentum) * rmean[d] + momentum * mean;
+      rvar[d] = (1.0f - momentum) * rvar[d] + momentum * var_u;
+    }
+    if (smean) {
+      smean[d] = mean;
+      sinv[d] = inv;
+    }
+  } else {
+    mean = rmean[d];
+    inv = 1.0f / sqrtf(rvar[d] + eps);
+  }
+  const float g = w[d], bb = b[d];
+  for (int q = 0; q < Q; q++) y[(size_t)q * D + d] = (x[(size_t)q * D + d] - mean) * inv * g + bb;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
+                                                     const float *__restrict__ w, const float *__restrict__ smean,
+                                                     const float *__restrict__ sinv, float *__restrict__ gx,
+                                                     float *__restrict__ gw, float *__restrict__ gb, int Q, int D) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const float mean = smean[d], inv = sinv[d], g = w[d];
+  float sg = 0.f, sgx = 0.f;
+  for (int q = 0; q < Q; q++) {
+    const float dy = gy[(size_t)q * D + d];
+    const float xh = (x[(size_t)q * D + d] - mean) * inv;
+    sg += dy;
+    sgx += dy * xh;
+  }
+  gw[d] = sgx;
+  gb[d] = sg;
+  const float invQ = 1.0f / (float)Q;
+  for (int q = 0; q < Q; q++) {
+    const float dy = gy[(size_t)q * D + d];
+    const float xh = (x[(size_t)q * D + d] - mean) * inv;
+    gx[(size_t)q * D + d] = g * inv * (dy - sg * invQ - xh * sgx * invQ);
+  }
+}
+
+// out[j] = sum_i x[i][j]: block = 64 columns x 4 row-groups, fixed-order combine
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, int rows,
+                                                     int cols) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = g; r < rows; r += 4) acc += x[(size_t)r * cols + c];
+  part[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && c < cols) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, int Na, int Ns, int Nb, int Ne, int D,
+                      float *S_max, int64_t *D_ind, void *stream) {
+  if (!V || !W || !ent_len || !S_max || !D_ind) return NAFAE_EINVAL;
+  if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  using E = Engine<128, 32, 4, 1>;
+  const int Q = Na * Ne, F = Na * Ns;
+  if (F > 65535) return NAFAE_ELIMIT;
+  const size_t lds = (2 * E::STAGE + 128 * 33 + 2 * 8 * 32) * sizeof(float);
+  hipLaunchKernelGGL(sim_max_kernel, dim3((Q + 31) / 32, F), dim3(NTHREADS), lds, S(stream), V, W, ent_len, Nb, Ne, Q, D,
+                     S_max, D_ind);
+  return NAFAE_OK;
+}
+
+int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D) {
+  if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0) return NAFAE_EINVAL;
+  return (int64_t)(loss_ws(Na, Ns, Nb, Ne, D).total * sizeof(float));
+}
+
+int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V, const int32_t *ent_len, int Na,
+                       int Ns, int Nb, int Ne, int D, float Delta, float vis_lam, int train, float *loss_out,
+                       float *dS, void *workspace, void *stream) {
+  if (!S_max || !D_ind || !ent_len || !loss_out || !workspace) return NAFAE_EINVAL;
+  if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  if (train && !V) return NAFAE_EINVAL;
+  const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
+  float *ws = reinterpret_cast<float *>(workspace);
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
+  if (train) {
+    if (Ns > 64) return NAFAE_ELIMIT;
+    const size_t lds = (size_t)2 * Ns * D * sizeof(float);
+    if (lds > 64 * 1024) {
+      if (lds > 144 * 1024) return NAFAE_ELIMIT;
+      static bool once = false;
+      if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cluster_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        once = true;
+      }
+    }
+    hipLaunchKernelGGL(cluster_kernel, dim3(Na * Ne), dim3(256), lds, S(stream), S_max, D_ind, V, ent_len, Na, Ns, Ne, D,
+                       ws, L);
+  }
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, S(stream), ws, L, Na, Ne, vis_lam, train, loss_out);
+  return NAFAE_OK;
+}
+
+int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const float *W, const int32_t *ent_len,
+                  int Na, int Ns, int Nb, int Ne, int D, int train, const void *workspace, const float *pre_scale,
+                  float *dV, float *dW, void *stream) {
+  if (!dS || !D_ind || !V || !W || !ent_len || !dV || !dW) return NAFAE_EINVAL;
+  if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  if (D > 256 * MAXCH) return NAFAE_ELIMIT;
+  if (train && !workspace) return NAFAE_EINVAL;
+  const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
+  const int F = Na * Ns, Q = Na * Ne, R = F * Nb;
+  hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, train,
+                     Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, dV);
+  hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3((Q + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, V, F, Nb, Q, D, dW);
+  return NAFAE_OK;
+}
+
+int nafae_dropout_tanh(const float *x, const uint8_t *mask, float scale, float *y, int64_t n, void *stream) {
+  if (!x || !y || n <= 0 || (n & 3)) return NAFAE_EINVAL;
+  const long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(dropout_tanh_kernel, dim3(blocks), dim3(256), 0, S(stream), x, mask, scale, y, n4);
+  return NAFAE_OK;
+}
+
+int nafae_dropout_tanh_bwd(const float *g_out, const float *y, const uint8_t *mask, float scale, float *g_in, int64_t n,
+                           void *stream) {
+  if (!g_out || !y || !g_in || n <= 0 || (n & 3)) return NAFAE_EINVAL;
+  const long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(dropout_tanh_bwd_kernel, dim3(blocks), dim3(256), 0, S(stream), g_out, y, mask, scale, g_in, n4);
+  return NAFAE_OK;
+}
+
+int nafae_batchnorm_fwd(const float *x, const float *weight, const float *bias, float *running_mean,
+                        float *running_var, float *y, float *save_mean, float *save_invstd, int Q, int D, int training,
+                        float momentum, float eps, void *stream) {
+  if (!x || !weight || !bias || !y || Q <= 0 || D <= 0) return NAFAE_EINVAL;
+  if (!training && (!running_mean || !running_var)) return NAFAE_EINVAL;
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), x, weight, bias, running_mean,
+                     running_var, y, save_mean, save_invstd, Q, D, training, momentum, eps);
+  return NAFAE_OK;
+}
+
+int nafae_batchnorm_bwd(const float *g_y, const float *x, const float *weight, const float *save_mean,
+                        const float *save_invstd, float *g_x, float *g_weight, float *g_bias, int Q, int D,
+                        void *stream) {
+  if (!g_y || !x || !weight || !save_mean || !save_invstd || !g_x || !g_weight || !g_bias || Q <= 0 || D <= 0)
+    return NAFAE_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), g_y, x, weight, save_mean,
+                     save_invstd, g_x, g_weight, g_bias, Q, D);
+  return NAFAE_OK;
+}
+
+int nafae_colsum(const float *x, float *out, int rows, int cols, void *stream) {
+  if (!x || !out || rows <= 0 || cols <= 0) return NAFAE_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, S(stream), x, out, rows, cols);
+  return NAFAE_OK;
+}
+
+}  // extern "C"

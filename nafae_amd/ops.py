@@ -1,0 +1,276 @@
+"""Tensor-level wrappers over the C ABI (include/nafae_hip.h).
+
+PyTorch supplies device memory and the current HIP stream only; every computation below happens in
+libnafae_hip.so.  All wrappers require CUDA(ROCm) tensors and raise on anything else -- no eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+class NafaeOpError(RuntimeError):
+    pass
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise NafaeOpError("%s must live on the GPU (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise NafaeOpError("%s: expected %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise NafaeOpError("%s must be contiguous" % name)
+
+
+def _rc(rc, what):
+    if rc != 0:
+        raise NafaeOpError("%s failed with code %d" % (what, rc))
+
+
+# ------------------------------------------------------------------------------------------------ contractions
+def gemm_nt(A, B, bias=None, alpha=1.0, act=ACT_NONE, out=None):
+    """act(alpha * A @ B.T + bias); A [M,K], B [N,K]."""
+    _chk(A, name="A"); _chk(B, name="B"); _chk(bias, name="bias")
+    M, K = A.shape
+    N = B.shape[0]
+    if B.shape[1] != K:
+        raise NafaeOpError("gemm_nt: K mismatch")
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    _chk(out, name="out")
+    _rc(_lib.lib().nafae_gemm_nt(_p(A), K, _p(B), K, _p(out), N, _p(bias), M, N, K, float(alpha), int(act), _stream()),
+        "nafae_gemm_nt")
+    return out
+
+
+def gemm_tn(A, B, alpha=1.0, out=None, accumulate=False):
+    """alpha * A.T @ B; A [K,M], B [K,N]."""
+    _chk(A, name="A"); _chk(B, name="B")
+    K, M = A.shape
+    N = B.shape[1]
+    if B.shape[0] != K:
+        raise NafaeOpError("gemm_tn: K mismatch")
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    _chk(out, name="out")
+    _rc(_lib.lib().nafae_gemm_tn(_p(A), M, _p(B), N, _p(out), N, M, N, K, float(alpha), int(bool(accumulate)), _stream()),
+        "nafae_gemm_tn")
+    return out
+
+
+def conv1_3x3_relu(x_nchw, w27, bias):
+    _chk(x_nchw); _chk(w27); _chk(bias)
+    F, C, H, W = x_nchw.shape
+    if C != 3 or w27.numel() != 64 * 27:
+        raise NafaeOpError("conv1: expects Cin=3, Cout=64")
+    out = torch.empty(F, H, W, 64, device=x_nchw.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_conv1_3x3_relu(_p(x_nchw), _p(w27), _p(bias), _p(out), F, H, W, _stream()), "nafae_conv1_3x3_relu")
+    return out
+
+
+def conv3x3_relu(x_nhwc, w_ohwi, bias, relu=True):
+    """x [F,H,W,Cin], w [Cout,3,3,Cin] -> [F,H,W,Cout]."""
+    _chk(x_nhwc); _chk(w_ohwi); _chk(bias)
+    F, H, W, Cin = x_nhwc.shape
+    Cout = w_ohwi.shape[0]
+    if w_ohwi.numel() != Cout * 9 * Cin:
+        raise NafaeOpError("conv3x3: weight shape mismatch")
+    out = torch.empty(F, H, W, Cout, device=x_nhwc.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_conv3x3_relu(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)),
+                                      _stream()), "nafae_conv3x3_relu")
+    return out
+
+
+def maxpool2x2(x_nhwc):
+    _chk(x_nhwc)
+    F, H, W, C = x_nhwc.shape
+    out = torch.empty(F, H // 2, W // 2, C, device=x_nhwc.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_maxpool2x2(_p(x_nhwc), _p(out), F, H, W, C, _stream()), "nafae_maxpool2x2")
+    return out
+
+
+def nchw_to_nhwc(x):
+    _chk(x)
+    N, C, H, W = x.shape
+    out = torch.empty(N, H, W, C, device=x.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_nchw_to_nhwc(_p(x), _p(out), N, C, H, W, _stream()), "nafae_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    _chk(x)
+    N, H, W, C = x.shape
+    out = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_nhwc_to_nchw(_p(x), _p(out), N, C, H, W, _stream()), "nafae_nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ proposals
+def rpn_decode(head, anchors, im_info, F, H, W, A, feat_stride):
+    _chk(head); _chk(anchors); _chk(im_info)
+    n = H * W * A
+    scores = torch.empty(F, n, device=head.device, dtype=torch.float32)
+    boxes = torch.empty(F, n, 4, device=head.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_rpn_decode(_p(head), _p(anchors), _p(im_info), _p(scores), _p(boxes), F, H, W, A, int(feat_stride),
+                                    _stream()), "nafae_rpn_decode")
+    return scores, boxes
+
+
+def sort_desc(scores):
+    _chk(scores)
+    F, n = scores.shape
+    order = torch.empty(F, n, device=scores.device, dtype=torch.int32)
+    _rc(_lib.lib().nafae_sort_desc(_p(scores), _p(order), F, n, _stream()), "nafae_sort_desc")
+    return order
+
+
+def proposals(boxes, scores, order, n_sorted, nms_thresh, post_nms_topN):
+    _chk(boxes); _chk(scores); _chk(order, torch.int32)
+    F, n = scores.shape
+    rois = torch.empty(F, post_nms_topN, 5, device=boxes.device, dtype=torch.float32)
+    roi_scores = torch.empty(F, post_nms_topN, device=boxes.device, dtype=torch.float32)
+    n_keep = torch.empty(F, device=boxes.device, dtype=torch.int32)
+    _rc(_lib.lib().nafae_proposals(_p(boxes), _p(scores), _p(order), F, n, int(n_sorted), float(nms_thresh),
+                                   int(post_nms_topN), _p(rois), _p(roi_scores), _p(n_keep), _stream()), "nafae_proposals")
+    return rois, roi_scores, n_keep
+
+
+def nms(dets, thresh):
+    """Drop-in for the reference's nms_gpu (lib/model/nms/nms_gpu.py:7-12): dets [n,5] sorted by descending score
+    -> int32 [n_keep, 1] kept positions.  (The slice by num_out synchronises, exactly like the reference's.)"""
+    _chk(dets)
+    n, dim = dets.shape
+    keep = torch.empty(n, 1, device=dets.device, dtype=torch.int32)
+    num = torch.empty(1, device=dets.device, dtype=torch.int32)
+    _rc(_lib.lib().nafae_nms(_p(keep), _p(num), _p(dets), n, dim, float(thresh), _stream()), "nafae_nms")
+    return keep[:int(num[0])]
+
+
+def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_scale):
+    """Drop-in for roi_align_forward_cuda (lib/model/roi_align/src/roi_align_cuda.c:7-40), NCHW."""
+    _chk(features); _chk(rois)
+    B, C, H, W = features.shape
+    N = rois.shape[0]
+    if rois.shape[1] != 5:
+        raise NafaeOpError("rois must be [N,5]")
+    out = torch.empty(N, C, aligned_height, aligned_width, device=features.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_roi_align_forward(int(aligned_height), int(aligned_width), float(spatial_scale), _p(features), B, C,
+                                           H, W, _p(rois), N, _p(out), _stream()), "nafae_roi_align_forward")
+    return out
+
+
+def roi_align_avg_nhwc(feat_nhwc, rois, spatial_scale):
+    """feat [F,H,W,C], rois [N,5] -> [N,7,7,C]."""
+    _chk(feat_nhwc); _chk(rois)
+    F, H, W, C = feat_nhwc.shape
+    N = rois.shape[0]
+    out = torch.empty(N, 7, 7, C, device=feat_nhwc.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_roi_align_avg_nhwc(_p(feat_nhwc), F, H, W, C, _p(rois), N, float(spatial_scale), _p(out), _stream()),
+        "nafae_roi_align_avg_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ sim + loss
+def sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne):
+    _chk(V); _chk(W); _chk(ent_len, torch.int32)
+    D = V.shape[1]
+    F, Q = Na * Ns, Na * Ne
+    if V.shape[0] != F * Nb or W.shape[0] != Q or W.shape[1] != D:
+        raise NafaeOpError("sim_max_fwd: shape mismatch V %s W %s (Na,Ns,Nb,Ne)=(%d,%d,%d,%d)"
+                           % (tuple(V.shape), tuple(W.shape), Na, Ns, Nb, Ne))
+    S_max = torch.empty(F, Q, device=V.device, dtype=torch.float32)
+    D_ind = torch.empty(F, Q, device=V.device, dtype=torch.int64)
+    _rc(_lib.lib().nafae_sim_max_fwd(_p(V), _p(W), _p(ent_len), Na, Ns, Nb, Ne, D, _p(S_max), _p(D_ind), _stream()),
+        "nafae_sim_max_fwd")
+    return S_max, D_ind
+
+
+def loss_workspace(Na, Ns, Nb, Ne, D, device):
+    nbytes = _lib.lib().nafae_loss_workspace_bytes(Na, Ns, Nb, Ne, D)
+    if nbytes < 0:
+        raise NafaeOpError("nafae_loss_workspace_bytes failed")
+    return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+
+
+def loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=True, workspace=None):
+    """-> (loss_out f32[4] = margin_loss, mean frame_score, vis_loss, dem; dS [F,Q] or None; workspace)."""
+    _chk(S_max); _chk(D_ind, torch.int64); _chk(V); _chk(ent_len, torch.int32)
+    D = V.shape[1]
+    if workspace is None:
+        workspace = loss_workspace(Na, Ns, Nb, Ne, D, S_max.device)
+    loss_out = torch.empty(4, device=S_max.device, dtype=torch.float32)
+    dS = torch.empty_like(S_max) if need_grad else None
+    _rc(_lib.lib().nafae_loss_fwd_bwd(_p(S_max), _p(D_ind), _p(V), _p(ent_len), Na, Ns, Nb, Ne, D, float(Delta),
+                                      float(vis_lam), int(bool(train)), _p(loss_out), _p(dS), _p(workspace), _stream()),
+        "nafae_loss_fwd_bwd")
+    return loss_out, dS, workspace
+
+
+def sim_bwd(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, train, workspace, pre_scale=None):
+    _chk(dS); _chk(D_ind, torch.int64); _chk(V); _chk(W); _chk(ent_len, torch.int32); _chk(pre_scale)
+    D = V.shape[1]
+    dV = torch.empty_like(V)
+    dW = torch.empty_like(W)
+    _rc(_lib.lib().nafae_sim_bwd(_p(dS), _p(D_ind), _p(V), _p(W), _p(ent_len), Na, Ns, Nb, Ne, D, int(bool(train)),
+                                 _p(workspace), _p(pre_scale), _p(dV), _p(dW), _stream()), "nafae_sim_bwd")
+    return dV, dW
+
+
+# ------------------------------------------------------------------------------------------------ embedding tails
+def dropout_tanh(x, mask=None, scale=1.0):
+    _chk(x); _chk(mask, torch.uint8)
+    y = torch.empty_like(x)
+    _rc(_lib.lib().nafae_dropout_tanh(_p(x), _p(mask), float(scale), _p(y), x.numel(), _stream()), "nafae_dropout_tanh")
+    return y
+
+
+def dropout_tanh_bwd(g_out, y, mask=None, scale=1.0):
+    _chk(g_out); _chk(y); _chk(mask, torch.uint8)
+    g_in = torch.empty_like(g_out)
+    _rc(_lib.lib().nafae_dropout_tanh_bwd(_p(g_out), _p(y), _p(mask), float(scale), _p(g_in), g_out.numel(), _stream()),
+        "nafae_dropout_tanh_bwd")
+    return g_in
+
+
+def batchnorm_fwd(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    _chk(x); _chk(weight); _chk(bias); _chk(running_mean); _chk(running_var)
+    Q, D = x.shape
+    y = torch.empty_like(x)
+    save_mean = torch.empty(D, device=x.device, dtype=torch.float32)
+    save_invstd = torch.empty(D, device=x.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_batchnorm_fwd(_p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var), _p(y), _p(save_mean),
+                                       _p(save_invstd), Q, D, int(bool(training)), float(momentum), float(eps), _stream()),
+        "nafae_batchnorm_fwd")
+    return y, save_mean, save_invstd
+
+
+def batchnorm_bwd(g_y, x, weight, save_mean, save_invstd):
+    _chk(g_y); _chk(x); _chk(weight); _chk(save_mean); _chk(save_invstd)
+    Q, D = x.shape
+    g_x = torch.empty_like(x)
+    g_w = torch.empty(D, device=x.device, dtype=torch.float32)
+    g_b = torch.empty(D, device=x.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_batchnorm_bwd(_p(g_y), _p(x), _p(weight), _p(save_mean), _p(save_invstd), _p(g_x), _p(g_w), _p(g_b),
+                                       Q, D, _stream()), "nafae_batchnorm_bwd")
+    return g_x, g_w, g_b
+
+
+def colsum(x):
+    _chk(x)
+    rows, cols = x.shape
+    out = torch.empty(cols, device=x.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_colsum(_p(x), _p(out), rows, cols, _stream()), "nafae_colsum")
+    return out

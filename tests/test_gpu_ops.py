@@ -1,0 +1,338 @@
+"""GPU parity tests, op level: every entry point of libnafae_hip.so (called through the C ABI via ctypes) against
+the CPU oracle on identical seeded inputs.  Bit-exact for index outputs (sort order, NMS keep lists, arg-max);
+fp32 tolerance 1e-4 (relative to the tensor's scale) for floating point, as BASELINE.json states."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from nafae_amd import ops as _ops
+    return _ops
+
+
+def dev(x):
+    return torch.as_tensor(x).contiguous().cuda()
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def rnd(seed, *shape, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * std
+
+
+# ------------------------------------------------------------------------------------------------ contractions
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 200), (257, 72, 512), (16, 512, 200), (1, 4, 4),
+                                   (513, 130, 36), (1000, 64, 576)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_nt(ops, M, N, K, act):
+    A, B, bias = rnd(1, M, K), rnd(2, N, K), rnd(3, N)
+    ref = 0.37 * (A.double() @ B.double().T) + bias.double()
+    ref = [ref, torch.relu(ref), torch.tanh(ref)][act]
+    out = ops.gemm_nt(dev(A), dev(B), dev(bias), alpha=0.37, act=act).cpu()
+    assert relerr(out, ref) < TOL
+    out2 = ops.gemm_nt(dev(A), dev(B), None, alpha=1.0, act=0).cpu()
+    assert relerr(out2, A.double() @ B.double().T) < TOL
+
+
+def test_gemm_nt_identity_asymmetric(ops):
+    # A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md section 3)
+    n = 160
+    A = torch.eye(n)
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    out = ops.gemm_nt(dev(A), dev(B)).cpu()
+    assert torch.equal(out, B.T.contiguous())
+
+
+@pytest.mark.parametrize("K,M,N", [(64, 128, 128), (1000, 512, 200), (8192, 512, 256), (37, 4, 8), (300, 132, 260)])
+def test_gemm_tn(ops, K, M, N):
+    A, B = rnd(4, K, M), rnd(5, K, N)
+    ref = 0.01 * (A.double().T @ B.double())
+    out = ops.gemm_tn(dev(A), dev(B), alpha=0.01).cpu()
+    assert relerr(out, ref) < TOL
+
+
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout,relu", [(2, 14, 14, 64, 64, True), (1, 6, 5, 32, 132, False),
+                                                  (3, 9, 11, 96, 512, True), (1, 28, 28, 128, 128, True)])
+def test_conv3x3(ops, Fr, H, W, Cin, Cout, relu):
+    x = rnd(6, Fr, Cin, H, W)
+    w = rnd(7, Cout, Cin, 3, 3, std=0.05)
+    b = rnd(8, Cout, std=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous()
+    out = ops.conv3x3_relu(dev(x_nhwc), dev(w_ohwi), dev(b), relu=relu).cpu().permute(0, 3, 1, 2)
+    assert relerr(out, ref) < TOL
+
+
+def test_conv1(ops):
+    x = torch.randint(0, 255, (3, 3, 20, 18), generator=torch.Generator().manual_seed(9)).float() - 127.5
+    w = rnd(10, 64, 3, 3, 3, std=0.01)
+    b = rnd(11, 64, std=0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    out = ops.conv1_3x3_relu(dev(x), dev(w.reshape(64, 27)), dev(b)).cpu().permute(0, 3, 1, 2)
+    assert relerr(out, ref) < TOL
+
+
+def test_maxpool_and_layout(ops):
+    x = rnd(12, 2, 8, 10, 12)
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    out = ops.maxpool2x2(dev(xh)).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(out, F.max_pool2d(x, 2, 2))
+    assert torch.equal(ops.nchw_to_nhwc(dev(x)).cpu(), xh)
+    assert torch.equal(ops.nhwc_to_nchw(dev(xh)).cpu(), x)
+    y = rnd(13, 3, 37, 5, 7)
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(dev(y))).cpu(), y)
+
+
+# ------------------------------------------------------------------------------------------------ proposal path
+def test_rpn_decode_matches_oracle(ops):
+    from oracle import detector as OD
+    g = np.load(os.path.join(G, "proposal.npz"))
+    cls, deltas, im_info = [torch.from_numpy(g[k]) for k in ("cls", "deltas", "im_info")]
+    Fr, C2, H, W = cls.shape
+    A = C2 // 2
+    prob = torch.from_numpy(g["prob"])
+    s_ref, p_ref = OD.decode_proposals(prob, deltas, im_info, 16, g["scales"].tolist(), g["ratios"].tolist())
+    head = torch.cat([cls, deltas], 1).permute(0, 2, 3, 1).contiguous().view(Fr * H * W, 6 * A)
+    anchors = torch.from_numpy(OD.generate_anchors(scales=g["scales"], ratios=g["ratios"])).float()
+    s, p = ops.rpn_decode(dev(head), dev(anchors), dev(im_info), Fr, H, W, A, 16)
+    np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 2352, 4096, 5000])
+def test_sort_desc_bit_exact(ops, n):
+    from oracle import detector as OD
+    s = torch.rand(5, n, generator=torch.Generator().manual_seed(n))
+    s[:, ::7] = s[:, :1]            # plenty of exact ties
+    s[1] = 0.5                      # a whole row of ties
+    if n > 3:
+        s[2, 3] = -1.0              # negative / zero scores order correctly too
+        s[2, 1] = 0.0
+    ref = OD.sort_desc(s)
+    out = ops.sort_desc(dev(s)).cpu()
+    assert torch.equal(out.long(), ref)
+
+
+def _rand_dets(seed, n, span=224.0):
+    rs = np.random.RandomState(seed)
+    xy = rs.rand(n, 2) * span * 0.7
+    wh = rs.rand(n, 2) * span * 0.5 + 2
+    sc = np.sort(rs.rand(n))[::-1]
+    d = np.concatenate([xy, np.minimum(xy + wh, span - 1), sc[:, None]], 1).astype(np.float32)
+    return d
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 130, 2352])
+def test_nms_bit_exact(ops, n):
+    from oracle import native as N
+    for seed in range(3):
+        d = _rand_dets(seed * 100 + n, n)
+        if seed == 1:
+            d[:, :4] = np.round(d[:, :4] / 8) * 8      # quantised boxes: many exact duplicates / IoU ties
+        if seed == 2 and n > 1:
+            d[:, :4] = d[0, :4]                         # all identical: only the first survives
+        ref = N.nms(d, 0.7)
+        out = ops.nms(dev(d), 0.7).cpu().numpy().reshape(-1)
+        assert np.array_equal(out, ref), (n, seed)
+    # threshold edge: IoU exactly 0.5 is kept by the strict '>'
+    d = np.array([[0, 0, 9, 9, .9], [0, 0, 9, 4, .8]], np.float32)
+    assert ops.nms(dev(d), 0.5).cpu().numpy().reshape(-1).tolist() == [0, 1]
+    assert ops.nms(dev(d), 0.49).cpu().numpy().reshape(-1).tolist() == [0]
+
+
+@pytest.mark.parametrize("topN", [8, 32, 128, 300])
+def test_proposals_match_oracle(ops, topN):
+    from oracle import detector as OD
+    Fr, n = 4, 2352
+    rs = np.random.RandomState(topN)
+    boxes = np.stack([_rand_dets(topN * 10 + f, n)[:, :4] for f in range(Fr)])
+    boxes = boxes[:, rs.permutation(n)]
+    if topN == 300:
+        boxes[3] = boxes[3, :1]                                    # frame with a single survivor -> zero padding
+    scores = rs.rand(Fr, n).astype(np.float32)
+    bt, st = torch.from_numpy(boxes), torch.from_numpy(scores)
+    order_ref = OD.sort_desc(st)
+    rois_ref, rs_ref, nk_ref = OD.select_proposals(st, bt, order_ref, 6000, topN, 0.7)
+    order = ops.sort_desc(dev(st))
+    assert torch.equal(order.cpu().long(), order_ref)
+    rois, roi_scores, n_keep = ops.proposals(dev(bt), dev(st), order, n, 0.7, topN)
+    assert n_keep.cpu().tolist() == nk_ref
+    assert torch.equal(rois.cpu(), rois_ref)
+    assert torch.equal(roi_scores.cpu(), rs_ref)
+
+
+def _rois(rs, n, Fr, size=224.0):
+    xy = rs.rand(n, 2) * size * 0.8
+    wh = rs.rand(n, 2) * size * 0.6
+    r = np.concatenate([rs.randint(0, Fr, (n, 1)), xy, np.minimum(xy + wh, size - 1)], 1).astype(np.float32)
+    r[0] = [0, 0, 0, size - 1, size - 1]      # whole image: last sample row/col out of range -> 0
+    r[1] = [Fr - 1, 0, 0, 0, 0]               # zero-padded proposal row
+    r[2] = [0, 160, 20, 16, 200]              # x2 < x1
+    r[3] = [0, 13.5 * 16, 13.5 * 16, 13.9 * 16, 13.9 * 16]   # h in [H-1, H): extrapolation branch
+    return r
+
+
+def test_roi_align_forward_dropin(ops):
+    from oracle import native as N
+    rs = np.random.RandomState(5)
+    Fr, C, H, W = 3, 10, 14, 14
+    f = rs.randn(Fr, C, H, W).astype(np.float32)
+    rois = _rois(rs, 40, Fr)
+    for (AH, AW) in ((8, 8), (7, 7), (3, 5)):
+        ref = N.roi_align_forward(f, rois, AH, AW, 1 / 16.)
+        out = ops.roi_align_forward(dev(f), dev(rois), AH, AW, 1 / 16.).cpu().numpy()
+        np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_roi_align_avg_nhwc(ops):
+    from oracle import native as N
+    rs = np.random.RandomState(6)
+    Fr, C, H, W = 3, 512, 14, 14
+    f = rs.randn(Fr, C, H, W).astype(np.float32)
+    rois = _rois(rs, 50, Fr)
+    ref = N.roi_align_avg(f, rois, 7, 1 / 16.)                                   # [N,C,7,7]
+    fh = torch.from_numpy(f).permute(0, 2, 3, 1).contiguous()
+    out = ops.roi_align_avg_nhwc(dev(fh), dev(rois), 1 / 16.).cpu().permute(0, 3, 1, 2).numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-6)
+    # non-square map and a small channel count
+    f2 = rs.randn(2, 6, 9, 5).astype(np.float32)
+    rois2 = _rois(rs, 12, 2, size=80.0)
+    rois2[3] = [1, 8.5 * 16, 4.5 * 16, 8.9 * 16, 4.9 * 16]
+    ref2 = N.roi_align_avg(f2, rois2, 7, 1 / 16.)
+    out2 = ops.roi_align_avg_nhwc(dev(torch.from_numpy(f2).permute(0, 2, 3, 1).contiguous()), dev(rois2), 1 / 16.)
+    np.testing.assert_allclose(out2.cpu().permute(0, 3, 1, 2).numpy(), ref2, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ sim + loss
+DVSA_CASES = ["c1", "c1b", "ragged", "na1", "full", "big"]
+
+
+def _run_dvsa(ops, V, W, lens, Na, Ns, Nb, Ne, Delta, lam, train):
+    Vd, Wd = dev(V), dev(W)
+    el = torch.tensor(lens, dtype=torch.int32).cuda()
+    S_max, D_ind = ops.sim_max_fwd(Vd, Wd, el, Na, Ns, Nb, Ne)
+    loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, Vd, el, Na, Ns, Nb, Ne, Delta, lam, train)
+    dV, dW = ops.sim_bwd(dS, D_ind, Vd, Wd, el, Na, Ns, Nb, Ne, train, ws)
+    return S_max.cpu(), D_ind.cpu(), loss_out.cpu(), dV.cpu(), dW.cpu()
+
+
+@pytest.mark.parametrize("name", DVSA_CASES)
+@pytest.mark.parametrize("phase", ["train", "eval"])
+def test_dvsa_against_reference_goldens(ops, name, phase):
+    g = np.load(os.path.join(G, "dvsa_%s.npz" % name))
+    Na, Ns, Nb, Ne, D = [int(x) for x in g["shape"]]
+    S_max, D_ind, loss, dV, dW = _run_dvsa(ops, g["V"], g["W"], g["lens"].tolist(), Na, Ns, Nb, Ne, float(g["Delta"]),
+                                           float(g["vis_lam"]), phase == "train")
+    assert np.array_equal(D_ind.numpy(), g["D_ind_" + phase])                    # grounding indices: bit-exact
+    assert relerr(S_max, g["D_sim_" + phase]) < TOL
+    assert abs(float(loss[0]) - float(g["loss_" + phase])) < TOL * abs(float(g["loss_" + phase]))
+    assert relerr(dV, g["dV_" + phase]) < 5 * TOL
+    assert relerr(dW, g["dW_" + phase]) < 5 * TOL
+
+
+@pytest.mark.parametrize("Na,Ns,Nb,Ne", [(8, 8, 128, 16), (2, 5, 300, 64), (3, 4, 20, 13)])
+def test_dvsa_against_oracle_larger(ops, Na, Ns, Nb, Ne):
+    from nafae_amd import synthetic as syn
+    from oracle import dvsa as O
+    D = 512
+    V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, D, seed=Na * 100 + Nb)
+    lens = syn.entity_lengths(Na, Ne, seed=Nb)
+    for train in (True, False):
+        v, w = V.clone().requires_grad_(), W.clone().requires_grad_()
+        Di, Ds, L = O.dvsa_forward(v, w, lens, Na, Nb, Ne, 10.0, 4.13, "train" if train else "eval")
+        L.backward()
+        S_max, D_ind, loss, dV, dW = _run_dvsa(ops, V, W, lens, Na, Ns, Nb, Ne, 10.0, 4.13, train)
+        # arg-max must agree wherever the oracle's own top-2 gap exceeds fp32 summation noise
+        assert relerr(S_max, Ds.detach()) < TOL
+        mism = (D_ind != Di)
+        if mism.any():
+            S_ = (V @ W.T).view(Na * Ns, Nb, Na * Ne)
+            top2 = S_.topk(2, dim=1).values
+            gap = (top2[:, 0] - top2[:, 1]).abs()
+            assert float(gap[mism].max()) < 1e-4, "arg-max differs on a non-tie"
+        else:
+            assert abs(float(loss[0]) - L.item()) < TOL * abs(L.item())
+            assert relerr(dV, v.grad) < 5 * TOL
+            assert relerr(dW, w.grad) < 5 * TOL
+
+
+def test_sim_max_full_size_properties(ops):
+    """BASELINE config C5 per-GPU shape (19200 x 512): size-independent checks -- max >= every sampled entry,
+    arg-max points at the max, masked slots are (0, 0), linearity in W."""
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, D = 8, 8, 300, 64, 512
+    V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, D, seed=5)
+    lens = syn.entity_lengths(Na, Ne, seed=5)
+    el = torch.tensor(lens, dtype=torch.int32).cuda()
+    Vd, Wd = dev(V), dev(W)
+    S_max, D_ind = ops.sim_max_fwd(Vd, Wd, el, Na, Ns, Nb, Ne)
+    S2, _ = ops.sim_max_fwd(Vd, dev(2 * W), el, Na, Ns, Nb, Ne)
+    assert torch.equal(S2, 2 * S_max)                                   # exact: scaling by 2 is exact in fp32
+    S_max, D_ind = S_max.cpu(), D_ind.cpu()
+    masked = (torch.arange(Ne)[None, :] >= torch.tensor(lens)[:, None]).view(-1)
+    assert (S_max[:, masked] == 0).all() and (D_ind[:, masked] == 0).all()
+    f = torch.arange(Na * Ns)[:, None]
+    rows = (f * Nb + D_ind)                                             # winning region row per (frame, query)
+    sel = (V[rows.view(-1)].double() * W.repeat(Na * Ns, 1).double()).sum(1).view(Na * Ns, -1)
+    assert relerr(sel[:, ~masked], S_max[:, ~masked]) < TOL
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        ff, q, b = rs.randint(Na * Ns), rs.randint(Na * Ne), rs.randint(Nb)
+        if masked[q]:
+            continue
+        v = float(V[ff * Nb + b].double() @ W[q].double())
+        assert v <= float(S_max[ff, q]) + 1e-3
+
+
+def test_embedding_tail_ops(ops):
+    x = rnd(20, 24, 32)
+    w, b = 1 + rnd(21, 32, std=0.2), rnd(22, 32, std=0.2)
+    rm, rv = torch.zeros(32), torch.ones(32)
+    xr = x.clone().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.batch_norm(xr, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5)
+    gy = rnd(23, 24, 32)
+    y_ref.backward(gy)
+    rmd, rvd = dev(rm), dev(rv)
+    y, sm, si = ops.batchnorm_fwd(dev(x), dev(w), dev(b), rmd, rvd, True)
+    assert relerr(y.cpu(), y_ref.detach()) < TOL
+    assert relerr(rmd.cpu(), rm_ref) < TOL and relerr(rvd.cpu(), rv_ref) < TOL
+    gx, gw, gb = ops.batchnorm_bwd(dev(gy), dev(x), dev(w), sm, si)
+    assert relerr(gx.cpu(), xr.grad) < TOL and relerr(gw.cpu(), wr.grad) < TOL and relerr(gb.cpu(), br.grad) < TOL
+    y_eval, _, _ = ops.batchnorm_fwd(dev(x), dev(w), dev(b), rmd, rvd, False)
+    assert relerr(y_eval.cpu(), F.batch_norm(x, rm_ref, rv_ref, w, b, False, 0.1, 1e-5)) < TOL
+    # dropout + tanh
+    mask = (torch.rand(24, 32, generator=torch.Generator().manual_seed(3)) > 0.1).to(torch.uint8)
+    t = ops.dropout_tanh(dev(x), dev(mask), 1 / 0.9).cpu()
+    assert relerr(t, torch.tanh(x * mask * (1 / 0.9))) < 1e-5
+    gi = ops.dropout_tanh_bwd(dev(gy), dev(t), dev(mask), 1 / 0.9).cpu()
+    assert relerr(gi, gy * (1 - t * t) * mask * (1 / 0.9)) < 1e-5
+    assert relerr(ops.dropout_tanh(dev(x)).cpu(), torch.tanh(x)) < 1e-5
+    big = rnd(24, 1000, 132)
+    assert relerr(ops.colsum(dev(big)).cpu(), big.double().sum(0)) < 1e-5
+
+
+def test_ops_refuse_cpu_tensors(ops):
+    with pytest.raises(Exception):
+        ops.gemm_nt(torch.zeros(4, 4), torch.zeros(4, 4))
