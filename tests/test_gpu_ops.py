@@ -123,7 +123,7 @@ def test_rpn_decode_matches_oracle(ops):
 def test_sort_desc_bit_exact(ops, n):
     from oracle import detector as OD
     s = torch.rand(5, n, generator=torch.Generator().manual_seed(n))
-    s[:, ::7] = s[:, :1]            # plenty of exact ties
+    s[:, ::7] = s[:, :1].clone()    # plenty of exact ties
     s[1] = 0.5                      # a whole row of ties
     if n > 3:
         s[2, 3] = -1.0              # negative / zero scores order correctly too
