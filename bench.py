@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training steps of the NAFAE grounding hot path on synthetic data (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path over one segment batch, exactly the body of the reference's train loop
+(model.py:684-775): frozen detector forward (VGG16 conv -> RPN/NMS -> ROI-Align -> fc6/fc7), VisEbd / WordEbd,
+similarity + contextual-similarity + clustering loss, backward, gradient all-reduce (N > 1), clip, Adam.
+Inputs (frames, GloVe rows) are resident in HBM before the timed region.  At N = 1 the workload is BASELINE
+config C2 (64 frames 224x224, 128 proposals/frame, 16 query slots, fp32); each additional GPU processes its own
+64 frames (weak scaling, no data-path collective; one RCCL all-reduce of 8.8 MB of gradients per step).
+
+Prints ONE JSON line on rank 0.  `value` = frames/s over all GPUs; pairs/s through sim+loss is reported next to
+it.  `roofline` prices the dominant kernel (the fc6 fp32-MFMA GEMM) from HIP-event timings taken inside the timed
+region on the launch stream; `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (Na, Ns, Nb, Ne)            BASELINE.json configs
+    "c2": (8, 8, 128, 16),
+    "c4": (8, 8, 256, 32),
+    "c5": (8, 8, 300, 64),
+    "c1": (2, 2, 32, 8),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_frame(Nb):
+    """Algorithmic FLOPs of the detector forward per frame."""
+    return 30.693e9 + 0.939e9 + Nb * (205.5e6 + 33.55e6 + 4.19e6)
+
+
+def cpu_baseline(Na, Ns, Nb, Ne, seconds_budget=25.0):
+    """CPU oracle (oracle/: plain PyTorch fp32 + C NMS/ROI-Align) on a bounded sample of the same workload:
+    `nf` frames through the detector + embeddings, then sim+loss at the full (R, Q) shape, all host cores."""
+    import torch
+    from nafae_amd import synthetic as syn
+    from oracle import detector as OD
+    from oracle import dvsa as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nf = 4
+    sd = syn.detector_state(seed=1234, heads=False)
+    im, im_info = syn.frames(nf, 224, 224, seed=1234)
+    ocfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
+                RPN_POST_NMS_TOP_N=Nb, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
+    t0 = time.time()
+    rois, rs, pooled, fc7 = OD.detector_forward(im, im_info, sd, ocfg)
+    t_det = time.time() - t0
+    # sim + loss (+ backward) at the full shape
+    V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, 512, seed=1)
+    lens = syn.entity_lengths(Na, Ne, seed=1234)
+    V.requires_grad_(); W.requires_grad_()
+    t0 = time.time()
+    Di, Ds, L = O.dvsa_forward(V, W, lens, Na, Nb, Ne, 10.0, 4.13, 'train')
+    L.backward()
+    t_sim = time.time() - t0
+    frames = Na * Ns
+    per_frame = t_det / nf + t_sim / frames
+    return {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle detector forward on %d of %d frames (%.1f s) + sim+loss fwd+bwd at R=%d,Q=%d (%.2f s), "
+                      "torch CPU fp32, %d threads" % (nf, frames, t_det, Na * Ns * Nb, Na * Ne, t_sim, cores),
+            "pairs_per_s": round(Na * Ns * Nb * Na * Ne / t_sim, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from nafae_amd import ops
+    from nafae_amd.config import cfg, cfg_from_file, reset_cfg
+    from nafae_amd.model import default_args
+    from nafae_amd.train import make_batch, setup_training, train_step
+
+    Na, Ns, Nb, Ne = WORKLOADS[a.workload]
+    reset_cfg()
+    cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
+    cfg.TEST.RPN_POST_NMS_TOP_N = Nb
+    args = default_args(batch_size=Na, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
+    model, opt, crit, reducer = setup_training(args, device=dev, seed=1234, distributed=distributed)
+    batch = make_batch(Na, Ns, Ne, seed=1234 + rank, device=dev)
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        train_step(model, opt, crit, batch, args, reducer)
+    sync()
+    ops.profile_reset(enable=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _, _, _ = train_step(model, opt, crit, batch, args, reducer)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_summary()
+    ops.profile_reset(enable=False)
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        F = Na * Ns
+        R, Q = F * Nb, Na * Ne
+        frames_per_s = world * F * a.steps / dt
+        out = {
+            "metric": "frames/sec + region-query-pairs/sec through sim+loss",
+            "value": round(frames_per_s, 2), "unit": "frames/s",
+            "pairs_per_s": round(world * R * Q * a.steps / dt, 1),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d frames 224x224 per GPU (Na=%d,Ns=%d), %d proposals/frame, %d query slots/segment, "
+                                   "VGG16 random-init, full train step" % (a.workload.upper(), F, Na, Ns, Nb, Ne),
+                       "frames_per_gpu": F, "proposals_per_frame": Nb, "queries_per_segment": Ne,
+                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": reducer.nbytes if reducer else 0},
+            "loss": round(float(loss), 5),
+        }
+        # dominant kernel: fc6 = [R,25088] x [4096,25088]^T on fp32 MFMA
+        fc6 = prof.get("fc6")
+        if fc6:
+            fl = 2.0 * R * 25088 * 4096
+            ach = fl / (fc6["avg_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "gemm_nt_kernel<128,128,2,2> (fc6)", "bound": "mfma", "achieved": round(ach, 2),
+                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "traffic": None, "avg_ms": round(fc6["avg_ms"], 4), "launches": fc6["n"]}
+        sim = prof.get("sim_max")
+        if sim:
+            by = 4.0 * 512 * (R + Q) + 12.0 * F * Q
+            ach = by / (sim["avg_ms"] * 1e-3) / 1e9
+            out["roofline_sim"] = {"kernel": "sim_max_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                   "avg_ms": round(sim["avg_ms"], 4),
+                                   "mfma_frac": round(2.0 * R * Q * 512 / (sim["avg_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        out["stage_ms"] = {k: round(v["avg_ms"], 4) for k, v in sorted(prof.items())}
+        det_ms = sum(v["avg_ms"] for k, v in prof.items() if k in ("base", "rpn", "roi_align", "fc6", "fc7"))
+        if det_ms > 0:
+            out["detector_mfma_frac"] = round(F * flops_per_frame(Nb) / (det_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(Na, Ns, Nb, Ne)
+            except Exception as e:      # the baseline is reporting, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,10 +154,13 @@ int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V,
 
 /* Backward of the similarity: dV [R,D] (dense, arg-max rows + clustering rows), dW [Q,D].
  * If pre_scale != NULL the VisEbd tail is fused: dV is multiplied elementwise by pre_scale [R,D]
- * (= (1 - V^2) * dropout_mask * dropout_scale, the tanh/dropout backward of model.py:627-628).  */
+ * (= (1 - V^2) * dropout_mask * dropout_scale, the tanh/dropout backward of model.py:627-628).
+ * grad_scale (device f32[1], may be NULL) is the upstream d(objective)/d(margin_loss), e.g. the +-1 of the
+ * reference's L1Loss(margin_loss, 0) (model.py:771); both outputs are multiplied by it.  */
 int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const float *W,
                   const int32_t *ent_len, int Na, int Ns, int Nb, int Ne, int D, int train,
-                  const void *workspace, const float *pre_scale, float *dV, float *dW, void *stream);
+                  const void *workspace, const float *pre_scale, const float *grad_scale, float *dV, float *dW,
+                  void *stream);
 
 /* ---- small embedding-tail ops (model.py:624-642) ------------------------------------------------ */
 

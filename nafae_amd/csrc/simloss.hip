@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
                                                          const float *__restrict__ Wm, int R, int Nb, int Q, int D,
                                                          int train, int n_centries, const float *__restrict__ ws,
                                                          LossWs L, const float *__restrict__ pre_scale,
+                                                         const float *__restrict__ grad_scale,
                                                          float *__restrict__ dV) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
     const int d = lane * 4 + c * 256;
     if (d < D) {
       f32x4 v = acc[c];
+      if (grad_scale) v *= grad_scale[0];
       if (pre_scale) v *= *reinterpret_cast<const f32x4 *>(pre_scale + (size_t)r * D + d);
       *reinterpret_cast<f32x4 *>(dV + (size_t)r * D + d) = v;
     }
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
 // one wave per query column q
 __global__ __launch_bounds__(256) void sim_bwd_dw_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
                                                          const float *__restrict__ V, int F, int Nb, int Q, int D,
+                                                         const float *__restrict__ grad_scale,
                                                          float *__restrict__ dW) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(256) void sim_bwd_dw_kernel(const float *__restrict
 #pragma unroll
   for (int c = 0; c < MAXCH; c++) {
     const int d = lane * 4 + c * 256;
-    if (d < D) *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = acc[c];
+    if (d < D) *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = grad_scale ? acc[c] * grad_scale[0] : acc[c];
   }
 }
 
@@ -687,7 +690,7 @@ int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V,
 
 int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const float *W, const int32_t *ent_len,
                   int Na, int Ns, int Nb, int Ne, int D, int train, const void *workspace, const float *pre_scale,
-                  float *dV, float *dW, void *stream) {
+                  const float *grad_scale, float *dV, float *dW, void *stream) {
   if (!dS || !D_ind || !V || !W || !ent_len || !dV || !dW) return NAFAE_EINVAL;
   if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
   if (D > 256 * MAXCH) return NAFAE_ELIMIT;
@@ -695,8 +698,8 @@ int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const f
   const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
   const int F = Na * Ns, Q = Na * Ne, R = F * Nb;
   hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, train,
-                     Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, dV);
-  hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3((Q + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, V, F, Nb, Q, D, dW);
+                     Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
+  hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3((Q + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, V, F, Nb, Q, D, grad_scale, dW);
   return NAFAE_OK;
 }
 

@@ -1,0 +1,223 @@
+"""Frozen Faster-RCNN (VGG16 + RPN + ROI-Align + fc6/fc7) detector, MI355X-native.
+
+Host-side mirror of the reference's ``vgg16`` / ``_fasterRCNN`` / ``_RPN`` / ``_ProposalLayer`` classes
+(lib/model/faster_rcnn/vgg16_rpn.py:19-61, lib/model/faster_rcnn/rpn.py:19-109, lib/model/rpn/rpn.py:17-113,
+lib/model/rpn/proposal_layer.py:26-171): same constructor arguments, same ``forward(im_data, im_info, gt_boxes,
+num_boxes) -> (rois, roi_scores, pooled_feat, fc7)``, same state-dict keys and tensor shapes, same ``cfg`` keys
+read at call time.  All arithmetic runs in libnafae_hip.so:
+
+    NCHW frames --conv1--> NHWC --12x conv3x3(+pool)--> base_feat NHWC [F,h,w,512]
+      --RPN conv3x3 + one fused 1x1 head GEMM--> decode/clip --> per-frame sort --> batched device NMS/top-N
+      --fused RoIAlignAvg--> [R,7,7,512] --fc6/fc7 GEMMs--> fc7 [R,4096]
+
+Activations are NHWC so every contraction's K dimension is contiguous; weights keep the reference's layout in the
+state dict (checkpoint compatible) and are re-laid-out once into kernel layout (``_pack``), re-done automatically
+whenever the parameters change (load_state_dict / .to()).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import cfg
+
+VGG_CFG_D = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]
+
+
+def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=(8, 16, 32)):
+    """Base anchor windows, fp64 (lib/model/rpn/generate_anchors.py:45-105): enumerate aspect ratios of the
+    (0,0,15,15) window with rounded sides, then scales, keeping the centre."""
+    ratios = np.asarray(ratios, dtype=np.float64)
+    scales = np.asarray(scales, dtype=np.float64)
+
+    def whc(a):
+        w, h = a[2] - a[0] + 1, a[3] - a[1] + 1
+        return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)
+
+    def mk(ws, hs, xc, yc):
+        ws, hs = np.asarray(ws, np.float64)[:, None], np.asarray(hs, np.float64)[:, None]
+        return np.hstack((xc - 0.5 * (ws - 1), yc - 0.5 * (hs - 1), xc + 0.5 * (ws - 1), yc + 0.5 * (hs - 1)))
+
+    w, h, xc, yc = whc(np.array([0, 0, base_size - 1, base_size - 1], dtype=np.float64))
+    ws = np.round(np.sqrt(w * h / ratios))
+    hs = np.round(ws * ratios)
+    out = []
+    for ra in mk(ws, hs, xc, yc):
+        w, h, xc, yc = whc(ra)
+        out.append(mk(w * scales, h * scales, xc, yc))
+    return np.vstack(out)
+
+
+class _RPN(nn.Module):
+    """Parameter container + eval-branch forward of lib/model/rpn/rpn.py:17-79."""
+
+    def __init__(self, din):
+        super().__init__()
+        self.din = din
+        self.anchor_scales = cfg.ANCHOR_SCALES
+        self.anchor_ratios = cfg.ANCHOR_RATIOS
+        self.feat_stride = cfg.FEAT_STRIDE[0]
+        A = len(self.anchor_scales) * len(self.anchor_ratios)
+        self.nc_score_out = A * 2
+        self.nc_bbox_out = A * 4
+        self.RPN_Conv = nn.Conv2d(din, 512, 3, 1, 1, bias=True)
+        self.RPN_cls_score = nn.Conv2d(512, self.nc_score_out, 1, 1, 0)
+        self.RPN_bbox_pred = nn.Conv2d(512, self.nc_bbox_out, 1, 1, 0)
+        self.rpn_loss_cls = 0
+        self.rpn_loss_box = 0
+
+
+class _fasterRCNN(nn.Module):
+    def __init__(self, classes, class_agnostic):
+        super().__init__()
+        self.classes = classes
+        self.n_classes = len(classes)
+        self.class_agnostic = class_agnostic
+        self.RCNN_loss_cls = 0
+        self.RCNN_loss_bbox = 0
+        self.RCNN_rpn = _RPN(self.dout_base_model)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ weights -> kernel layout
+    def _pack_key(self):
+        ps = list(self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in ps)
+
+    def _pack(self):
+        key = self._pack_key()
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        P = {}
+        convs = [m for m in self.RCNN_base if isinstance(m, nn.Conv2d)]
+        with torch.no_grad():
+            c0 = convs[0]
+            P['conv1_w'] = c0.weight.detach().reshape(64, 27).contiguous()
+            P['conv1_b'] = c0.bias.detach().contiguous()
+            P['convs'] = [(c.weight.detach().permute(0, 2, 3, 1).contiguous(), c.bias.detach().contiguous())
+                          for c in convs[1:]]
+            r = self.RCNN_rpn
+            P['rpn_w'] = r.RPN_Conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+            P['rpn_b'] = r.RPN_Conv.bias.detach().contiguous()
+            # both 1x1 heads as ONE GEMM: rows [bg A | fg A | deltas 4A]
+            P['head_w'] = torch.cat([r.RPN_cls_score.weight.detach().reshape(r.nc_score_out, 512),
+                                     r.RPN_bbox_pred.weight.detach().reshape(r.nc_bbox_out, 512)], 0).contiguous()
+            P['head_b'] = torch.cat([r.RPN_cls_score.bias.detach(), r.RPN_bbox_pred.bias.detach()], 0).contiguous()
+            fc6, fc7 = self.RCNN_top[0], self.RCNN_top[3]
+            ps = cfg.POOLING_SIZE
+            # flatten order (c, ph, pw) -> (ph, pw, c): ROI-Align writes bins channel-contiguous
+            P['fc6_w'] = fc6.weight.detach().view(4096, 512, ps * ps).permute(0, 2, 1).reshape(4096, 512 * ps * ps).contiguous()
+            P['fc6_b'] = fc6.bias.detach().contiguous()
+            P['fc7_w'] = fc7.weight.detach().contiguous()
+            P['fc7_b'] = fc7.bias.detach().contiguous()
+            anc = generate_anchors(scales=np.array(r.anchor_scales), ratios=np.array(r.anchor_ratios))
+            P['anchors'] = torch.from_numpy(anc).float().to(c0.weight.device)
+        self._packed, self._packed_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ forward
+    def base_features(self, im_data):
+        """RCNN_base (vgg16_rpn.py:38) -> NHWC [F, H/16, W/16, 512]."""
+        P = self._pack()
+        x = ops.conv1_3x3_relu(im_data.contiguous(), P['conv1_w'], P['conv1_b'])
+        li = 0
+        for v in VGG_CFG_D[1:]:
+            if v == 'M':
+                x = ops.maxpool2x2(x)
+            else:
+                w, b = P['convs'][li]
+                x = ops.conv3x3_relu(x, w, b, relu=True)
+                li += 1
+        return x
+
+    def proposals(self, base_feat, im_info):
+        """RCNN_rpn in eval mode (rpn/rpn.py:58-79 + proposal_layer.py:49-171)."""
+        P = self._pack()
+        F, h, w, _ = base_feat.shape
+        r = self.RCNN_rpn
+        A = r.nc_score_out // 2
+        x = ops.conv3x3_relu(base_feat, P['rpn_w'], P['rpn_b'], relu=True)
+        head = ops.gemm_nt(x.view(F * h * w, 512), P['head_w'], P['head_b'])
+        scores, boxes = ops.rpn_decode(head, P['anchors'], im_info.contiguous().float(), F, h, w, A, r.feat_stride)
+        order = ops.sort_desc(scores)
+        n = scores.shape[1]
+        pre = cfg.TEST.RPN_PRE_NMS_TOP_N
+        # proposal_layer.py:140 compares against the numel of the whole batch
+        n_sorted = min(n, pre) if (pre > 0 and pre < F * n) else n
+        rois, roi_scores, self.n_keep = ops.proposals(boxes, scores, order, n_sorted, cfg.TEST.RPN_NMS_THRESH,
+                                                      cfg.TEST.RPN_POST_NMS_TOP_N)
+        return rois, roi_scores
+
+    def forward(self, im_data, im_info, gt_boxes=None, num_boxes=None):
+        if self.training:
+            raise NotImplementedError("the detector is frozen and always runs in eval mode (model.py:651,673)")
+        if cfg.POOLING_MODE != 'align':
+            raise NotImplementedError("only POOLING_MODE 'align' (cfgs/vgg16.yml) is on the hot path")
+        with torch.no_grad():
+            P = self._pack()
+            with ops.timed("base"):
+                base_feat = self.base_features(im_data)
+            with ops.timed("rpn"):
+                rois, roi_scores = self.proposals(base_feat, im_info)
+            R = rois.shape[0] * rois.shape[1]
+            with ops.timed("roi_align"):
+                pooled = ops.roi_align_avg_nhwc(base_feat, rois.view(R, 5), 1.0 / 16.0)      # [R,7,7,512]
+            with ops.timed("fc6"):
+                fc6 = ops.gemm_nt(pooled.view(R, -1), P['fc6_w'], P['fc6_b'], act=ops.ACT_RELU)
+            with ops.timed("fc7"):
+                fc7 = ops.gemm_nt(fc6, P['fc7_w'], P['fc7_b'], act=ops.ACT_RELU)
+            pooled_feat = pooled.permute(0, 3, 1, 2)     # logical [R,512,7,7] (channels-last memory)
+        return rois, roi_scores, pooled_feat, fc7
+
+    def _init_weights(self):
+        """faster_rcnn/rpn.py:89-105."""
+        def normal_init(m, mean, stddev):
+            m.weight.data.normal_(mean, stddev)
+            m.bias.data.zero_()
+        normal_init(self.RCNN_rpn.RPN_Conv, 0, 0.01)
+        normal_init(self.RCNN_rpn.RPN_cls_score, 0, 0.01)
+        normal_init(self.RCNN_rpn.RPN_bbox_pred, 0, 0.01)
+        normal_init(self.RCNN_cls_score, 0, 0.01)
+        normal_init(self.RCNN_bbox_pred, 0, 0.001)
+
+    def create_architecture(self):
+        self._init_modules()
+        self._init_weights()
+
+
+class vgg16(_fasterRCNN):
+    def __init__(self, classes, pretrained=False, class_agnostic=False):
+        self.model_path = 'data/pretrained_model/vgg16_caffe.pth'
+        self.dout_base_model = 512
+        self.pretrained = pretrained
+        _fasterRCNN.__init__(self, classes, class_agnostic)
+
+    def _init_modules(self):
+        layers, cin = [], 3
+        for v in VGG_CFG_D:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                conv = nn.Conv2d(cin, v, kernel_size=3, padding=1)
+                nn.init.kaiming_normal_(conv.weight, mode='fan_out', nonlinearity='relu')
+                nn.init.constant_(conv.bias, 0)
+                layers += [conv, nn.ReLU(inplace=True)]
+                cin = v
+        self.RCNN_base = nn.Sequential(*layers)                         # 30 modules: torchvision features[:-1]
+        for layer in range(10):                                          # vgg16_rpn.py:41-42
+            for p in self.RCNN_base[layer].parameters():
+                p.requires_grad = False
+        fc6, fc7 = nn.Linear(512 * 7 * 7, 4096), nn.Linear(4096, 4096)
+        for m in (fc6, fc7):
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+        self.RCNN_top = nn.Sequential(fc6, nn.ReLU(True), nn.Dropout(), fc7, nn.ReLU(True), nn.Dropout())
+        self.RCNN_cls_score = nn.Linear(4096, self.n_classes)
+        self.RCNN_bbox_pred = nn.Linear(4096, 4 if self.class_agnostic else 4 * self.n_classes)
+
+    def _head_to_tail(self, pool5):
+        P = self._pack()
+        R = pool5.shape[0]
+        x = pool5.permute(0, 2, 3, 1).contiguous().view(R, -1)          # (ph,pw,c) order of the packed fc6
+        fc6 = ops.gemm_nt(x, P['fc6_w'], P['fc6_b'], act=ops.ACT_RELU)
+        return ops.gemm_nt(fc6, P['fc7_w'], P['fc7_b'], act=ops.ACT_RELU)

@@ -1,0 +1,299 @@
+"""Grounding model: host-side mirror of the reference's ``model.py`` classes, computing in libnafae_hip.so.
+
+Kept from the reference (so that this module drops into ``train_model.sh`` / the train + validate loops):
+  * ``parse_args``                      model.py:35-264   (same flags, dests and defaults)
+  * ``GroundModel(args, cfg)``          model.py:644-657  sub-modules ``fasterRCNN``, ``vis_ebd``, ``word_ebd``, ``DVSA``
+  * ``VisEbd.forward(feats)``           model.py:624-629
+  * ``WordEbd.forward(feats)``          model.py:640-642
+  * ``DVSA.init_train/init_eval/forward(vis_feats, word_feats, entities_length) -> (D_ind, D_sim, margin_loss)``
+                                        model.py:509-614
+  * ``stepRCNN`` / ``postprocess``      model.py:429-474
+  * the 59 state-dict keys (incl. the never-executed attention / position / ffn parameters of DVSA), so
+    ``faster_rcnn_gnome.pth`` and ``vis_ground_*.pth`` load unchanged (model.py:1039-1064).
+
+Autograd is plumbing only: each module's forward/backward is a ``torch.autograd.Function`` whose two halves call
+the HIP kernels; no PyTorch compute op sits on the path, and there is no CPU fallback.
+"""
+import argparse
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import cfg
+from .detector import vgg16
+
+EPS = 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------- CLI
+_FLAGS = [
+    # (flag, dest, default, type | 'store_true' | 'store_false')
+    ('--cfg', 'cfg_file', 'cfgs/vgg16.yml', str), ('--net', 'net', 'vgg16', str), ('--model', 'model', 'DVSA', str),
+    ('--load_dir', 'load_dir', 'models/vgg16/pretrain', str), ('--save_dir', 'save_dir', 'output/models', str),
+    ('--vid_list_file', 'vid_list_file', './data/YouCookII/split/dummy_list.txt', str),
+    ('--val_list_file', 'val_list_file', 'val_list.txt', str), ('--test_list_file', 'test_list_file', 'test_list.txt', str),
+    ('--word_file', 'word_file', './data/YouCookII/sampled_entities/train_entities.pkl', str),
+    ('--box_val_anno_file', 'box_val_anno_file', 'yc2_bb_val_annotations.json', str),
+    ('--box_test_anno_file', 'box_test_anno_file', 'yc2_bb_test_annotations.json', str),
+    ('--seg_anno_file', 'seg_anno_file', 'youcookii_annotations.json', str), ('--root', 'root', 'data', str),
+    ('--dataset', 'dataset', 'YouCookII', str), ('--class_file', 'class_file', 'youcook_cls.txt', str),
+    ('--cuda', 'cuda', None, 'store_true'), ('--mGPUs', 'mGPUs', None, 'store_true'),
+    ('--cag', 'class_agnostic', None, 'store_true'), ('--parallel_type', 'parallel_type', 0, int),
+    ('--checksession', 'checksession', 1, int), ('--checkepoch', 'checkepoch', 1, int),
+    ('--checkbatch', 'checkbatch', 10021, int), ('--bs', 'batch_size', 8, int), ('--bs_val', 'batch_size_val', 1, int),
+    ('--workers', 'workers', 8, int), ('--vis', 'vis', None, 'store_true'), ('--act_trunc', 'act_trunc', 20, int),
+    ('--debug', 'debug', None, 'store_true'), ('--pdb', 'pdb', None, 'store_true'), ('--img_h', 'img_h', 224, int),
+    ('--img_w', 'img_w', 224, int), ('--o', 'optimizer', 'sgd', str), ('--lr', 'lr', 0.001, float),
+    ('--lr_decay_step', 'lr_decay_step', 20, int), ('--lr_decay_gamma', 'lr_decay_gamma', 0.1, float),
+    ('--dropout_rate', 'dropout_rate', 0.1, float), ('--clip', 'clip', 100, float),
+    ('--weight_decay', 'weight_decay', 0.00001, float), ('--shuffle_train', 'shuffle_train', None, 'store_true'),
+    ('--no_shuffle_train', 'shuffle_train', None, 'store_false'), ('--shuffle_val', 'shuffle_val', False, bool),
+    ('--vis_fc_dim', 'vis_fc_dim', 4096, int), ('--glove_dim', 'glove_dim', 200, int),
+    ('--word_ebd_dim', 'word_ebd_dim', 512, int), ('--max_ent_len', 'max_ent_len', 13, int), ('--n_head', 'n_head', 8, int),
+    ('--d_k', 'd_k', 64, int), ('--d_v', 'd_v', 64, int), ('--n_position', 'n_position', 100, int),
+    ('--epoch', 'epoch', 10, int), ('--Delta', 'Delta', 1, float), ('--vis_lam', 'vis_lam', 1, float),
+    ('--sample_num', 'sample_num', 5, int), ('--sample_num_val', 'sample_num_val', 0, int),
+    ('--sample_rate', 'sample_rate', 1, int), ('--sample_rate_val', 'sample_rate_val', 16, int),
+    ('--fix_seg_len', 'fix_seg_len', None, 'store_true'), ('--fix_seg_len_val', 'fix_seg_len_val', None, 'store_true'),
+    ('--eval_freq', 'eval_freq', 1, int), ('--validate', 'validate', None, 'store_true'),
+    ('--resume', 'resume', None, 'store_true'), ('--iou_thr', 'iou_thr', 0.5, float), ('--ovthr', 'ovthr', 0.7, float),
+    ('--val_vis_freq', 'val_vis_freq', 100, int), ('--train_vis_freq', 'train_vis_freq', 100, int),
+    ('--statement', 'statement', '', str),
+]
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='NAFAE grounding (MI355X-native)')
+    for flag, dest, default, typ in _FLAGS:
+        if typ in ('store_true', 'store_false'):
+            p.add_argument(flag, dest=dest, action=typ)
+        else:
+            p.add_argument(flag, dest=dest, default=default, type=typ)
+    p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
+    p.add_argument('--entity_type', dest='entity_type', default=['category'], type=list)
+    p.add_argument('--phase', dest='phase', choices=['train', 'val', 'test', 'detvis'], type=str)
+    return p
+
+
+def parse_args(argv=None):
+    return build_parser().parse_args(argv)
+
+
+def default_args(**over):
+    a = build_parser().parse_args([])
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+# ---------------------------------------------------------------------------------------------------- autograd glue
+def _drop_mask(shape, p, device):
+    """Bernoulli keep mask for nn.Dropout(p) in train mode (random numbers are plumbing, like the allocator)."""
+    return (torch.rand(shape, device=device) >= p).to(torch.uint8)
+
+
+class _VisEbdFn(torch.autograd.Function):
+    """tanh(drop(fc1(x / 100)))  -- model.py:624-629."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, mask, scale):
+        with ops.timed("vis_ebd"):
+            pre = ops.gemm_nt(feats, weight, bias, alpha=0.01)      # (x/100) W^T + b  ==  0.01 (x W^T) + b
+            y = ops.dropout_tanh(pre, mask, scale)
+        ctx.save_for_backward(feats, y, mask)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        feats, y, mask = ctx.saved_tensors
+        with ops.timed("vis_ebd_bwd"):
+            gpre = ops.dropout_tanh_bwd(gy.contiguous(), y, mask, ctx.scale)
+            gw = ops.gemm_tn(gpre, feats, alpha=0.01)               # [D, 4096]
+            gb = ops.colsum(gpre)
+        return None, gw, gb, None, None
+
+
+class _WordEbdFn(torch.autograd.Function):
+    """tanh(drop(bn(fc1(x))))  -- model.py:640-642."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, bn_w, bn_b, run_mean, run_var, training, momentum, eps, mask, scale):
+        with ops.timed("word_ebd"):
+            lin = ops.gemm_nt(feats, weight, bias)
+            bn, save_mean, save_invstd = ops.batchnorm_fwd(lin, bn_w, bn_b, run_mean, run_var, training, momentum, eps)
+            y = ops.dropout_tanh(bn, mask, scale)
+        ctx.save_for_backward(feats, lin, bn_w, save_mean, save_invstd, y, mask, run_var)
+        ctx.scale, ctx.training, ctx.eps = scale, training, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        feats, lin, bn_w, save_mean, save_invstd, y, mask, run_var = ctx.saved_tensors
+        gbn = ops.dropout_tanh_bwd(gy.contiguous(), y, mask, ctx.scale)
+        if not ctx.training:
+            raise NotImplementedError("WordEbd backward in eval mode is never taken by the reference")
+        glin, g_bn_w, g_bn_b = ops.batchnorm_bwd(gbn, lin, bn_w, save_mean, save_invstd)
+        gw = ops.gemm_tn(glin, feats)                                # [D, glove_dim]
+        gb = ops.colsum(glin)
+        return None, gw, gb, g_bn_w, g_bn_b, None, None, None, None, None, None, None
+
+
+class _DVSAFn(torch.autograd.Function):
+    """Similarity + ranking/clustering loss -- model.py:532-614.  The gradient wrt S_max is produced in the same
+    pass as the loss; backward only scatters it to dV / dW."""
+
+    @staticmethod
+    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train):
+        with ops.timed("sim_max"):
+            S_max, D_ind = ops.sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne)
+        need = V.requires_grad or W.requires_grad
+        with ops.timed("loss_tail"):
+            loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train,
+                                                need_grad=need)
+        if need:
+            ctx.save_for_backward(V, W, ent_len, D_ind, dS, ws)
+        ctx.dims = (Na, Ns, Nb, Ne, train)
+        ctx.mark_non_differentiable(D_ind, S_max)
+        ctx.loss_parts = loss_out
+        return D_ind, S_max, loss_out[0]
+
+    @staticmethod
+    def backward(ctx, g_ind, g_sim, g_loss):
+        V, W, ent_len, D_ind, dS, ws = ctx.saved_tensors
+        Na, Ns, Nb, Ne, train = ctx.dims
+        gs = g_loss.detach().reshape(1).float().contiguous()
+        with ops.timed("sim_bwd"):
+            dV, dW = ops.sim_bwd(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, train, ws, grad_scale=gs)
+        return dV, dW, None, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------- modules
+class _DeadAttention(nn.Module):
+    """Parameter shapes of the reference's MultiHeadAttention (lib/model/transformer/SubLayers.py:13-39), which
+    DVSA.__init__ instantiates (model.py:495) and DVSA.forward never calls.  Kept for checkpoint compatibility."""
+
+    def __init__(self, n_head, d_model, d_k, d_v):
+        super().__init__()
+        self.w_qs = nn.Parameter(torch.empty(n_head, d_model, d_k))
+        self.w_ks = nn.Parameter(torch.empty(n_head, d_model, d_k))
+        self.w_vs = nn.Parameter(torch.empty(n_head, d_model, d_v))
+        for w in (self.w_qs, self.w_ks, self.w_vs):
+            nn.init.xavier_normal_(w)
+        self.layer_norm = nn.Module()
+        self.layer_norm.a_2 = nn.Parameter(torch.ones(d_model))
+        self.layer_norm.b_2 = nn.Parameter(torch.zeros(d_model))
+        self.proj = nn.Module()
+        self.proj.linear = nn.Linear(n_head * d_v, d_model)
+
+
+def _position_encoding(n_position, d):
+    """lib/model/transformer/Models.py:23-36 (sinusoid table; dead weight, checkpoint compatibility only)."""
+    pos = np.arange(n_position)[:, None] / np.power(10000, 2 * (np.arange(d)[None, :] // 2) / d)
+    pos[:, 0::2] = np.sin(pos[:, 0::2])
+    pos[:, 1::2] = np.cos(pos[:, 1::2])
+    return torch.tensor(pos, dtype=torch.float)
+
+
+class DVSA(nn.Module):
+    def __init__(self, args, cfg_):
+        super().__init__()
+        self.args = args
+        self.cfg = cfg_
+        self.slf_attn = _DeadAttention(args.n_head, args.word_ebd_dim, args.d_k, args.d_v)
+        self.position_enc = nn.Embedding(args.n_position, args.word_ebd_dim)
+        self.position_enc.weight.data = _position_encoding(args.n_position, args.word_ebd_dim)
+        self.ffn = nn.Linear(2 * args.word_ebd_dim, args.sample_num)
+        self.phase = ''
+        self.last_loss_parts = None
+
+    def init_train(self):
+        self.Na = self.args.batch_size
+        self.phase = 'train'
+
+    def init_eval(self):
+        self.Na = self.args.batch_size_val
+        self.phase = 'eval'
+
+    def forward(self, vis_feats, word_feats, entities_length):
+        Na = self.Na
+        Nb = cfg.TEST.RPN_POST_NMS_TOP_N                      # read at call time, like model.py:525
+        Ne = self.args.max_ent_len
+        Ns = int(vis_feats.size()[0] / Na / Nb)
+        if len(entities_length) != Na:
+            raise ValueError("entities_length has %d entries, Na = %d" % (len(entities_length), Na))
+        ent_len = torch.tensor([int(x) for x in entities_length], dtype=torch.int32, device=vis_feats.device)
+        D_ind, D_sim, margin_loss = _DVSAFn.apply(vis_feats.contiguous(), word_feats.contiguous(), ent_len, Na, Ns, Nb,
+                                                  Ne, float(self.args.Delta), float(self.args.vis_lam),
+                                                  self.phase == 'train')
+        return D_ind, D_sim, margin_loss
+
+
+class VisEbd(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.fc1 = nn.Linear(args.vis_fc_dim, args.word_ebd_dim)
+        self.drop = nn.Dropout(p=args.dropout_rate)
+
+    def forward(self, feats):
+        p = self.drop.p
+        mask, scale = (None, 1.0)
+        if self.training and p > 0:
+            mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device), 1.0 / (1.0 - p)
+        return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, mask, scale)
+
+
+class WordEbd(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.fc1 = nn.Linear(args.glove_dim, args.word_ebd_dim)
+        self.drop = nn.Dropout(p=args.dropout_rate)
+        self.bn = nn.BatchNorm1d(args.word_ebd_dim)
+
+    def forward(self, feats):
+        p = self.drop.p
+        mask, scale = (None, 1.0)
+        if self.training and p > 0:
+            mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device), 1.0 / (1.0 - p)
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return _WordEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, self.bn.weight, self.bn.bias,
+                                self.bn.running_mean, self.bn.running_var, self.training, self.bn.momentum,
+                                self.bn.eps, mask, scale)
+
+
+class GroundModel(nn.Module):
+    def __init__(self, args, cfg_):
+        super().__init__()
+        gnome_classes = np.array(['' for _ in range(2501)])
+        self.fasterRCNN = vgg16(gnome_classes, pretrained=False, class_agnostic=args.class_agnostic)
+        self.fasterRCNN.create_architecture()
+        self.fasterRCNN.eval()
+        self.vis_ebd = VisEbd(args)
+        self.word_ebd = WordEbd(args)
+        self.DVSA = DVSA(args, cfg_)
+
+
+# ---------------------------------------------------------------------------------------------------- helpers
+def stepRCNN(im_data, im_info, gt_boxes, num_boxes, ground_model, step_size=64):
+    """model.py:429-454: run the detector over a long segment in chunks of 64 frames."""
+    Ns = im_data.shape[0]
+    rois_lst, roi_feats_lst, fc_feats_lst = [], [], []
+    for s in range(0, Ns, step_size):
+        e = min(s + step_size, Ns)
+        rois, roi_scores, roi_feats, fc_feats = ground_model.fasterRCNN(im_data[s:e], im_info[s:e], gt_boxes, num_boxes)
+        rois_lst.append(rois)
+        roi_feats_lst.append(roi_feats)
+        fc_feats_lst.append(fc_feats)
+    return torch.cat(rois_lst, 0), torch.cat(roi_feats_lst, 0), torch.cat(fc_feats_lst, 0)
+
+
+def postprocess(D, D_sim, Na, Ns, Nb, Ne):
+    """model.py:457-474: own-segment block of the grounding result + global box offsets (numpy, host)."""
+    D_t = np.asarray(D).reshape(Na, Ns, Na, Ne)
+    S_t = np.asarray(D_sim).reshape(Na, Ns, Na, Ne)
+    a = np.arange(Na)
+    off = a[:, None, None] * Ns * Nb + np.arange(Ns)[None, :, None] * Nb
+    return D_t[a, :, a, :].astype(int) + off, S_t[a, :, a, :].astype(np.float64)

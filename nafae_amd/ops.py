@@ -35,6 +35,44 @@ def _chk(t, dtype=torch.float32, name="tensor"):
         raise NafaeOpError("%s must be contiguous" % name)
 
 
+# ---- optional HIP-event stage timing (bench.py): events are recorded on the stream the kernels launch on ----
+_PROF = {"on": False, "ev": {}}
+
+
+class timed:
+    """with ops.timed("fc6"): ...   -- brackets the enclosed launches with HIP events when profiling is on."""
+
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        if _PROF["on"]:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROF["on"]:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            _PROF["ev"].setdefault(self.label, []).append((self.s, e))
+        return False
+
+
+def profile_reset(enable):
+    _PROF["on"] = bool(enable)
+    _PROF["ev"] = {}
+
+
+def profile_summary():
+    torch.cuda.synchronize()
+    out = {}
+    for k, evs in _PROF["ev"].items():
+        ms = [s.elapsed_time(e) for s, e in evs]
+        out[k] = {"avg_ms": sum(ms) / len(ms), "n": len(ms), "min_ms": min(ms)}
+    return out
+
+
 def _rc(rc, what):
     if rc != 0:
         raise NafaeOpError("%s failed with code %d" % (what, rc))
@@ -219,13 +257,13 @@ def loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train
     return loss_out, dS, workspace
 
 
-def sim_bwd(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, train, workspace, pre_scale=None):
-    _chk(dS); _chk(D_ind, torch.int64); _chk(V); _chk(W); _chk(ent_len, torch.int32); _chk(pre_scale)
+def sim_bwd(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, train, workspace, pre_scale=None, grad_scale=None):
+    _chk(dS); _chk(D_ind, torch.int64); _chk(V); _chk(W); _chk(ent_len, torch.int32); _chk(pre_scale); _chk(grad_scale)
     D = V.shape[1]
     dV = torch.empty_like(V)
     dW = torch.empty_like(W)
     _rc(_lib.lib().nafae_sim_bwd(_p(dS), _p(D_ind), _p(V), _p(W), _p(ent_len), Na, Ns, Nb, Ne, D, int(bool(train)),
-                                 _p(workspace), _p(pre_scale), _p(dV), _p(dW), _stream()), "nafae_sim_bwd")
+                                 _p(workspace), _p(pre_scale), _p(grad_scale), _p(dV), _p(dW), _stream()), "nafae_sim_bwd")
     return dV, dW
 
 

@@ -1,0 +1,88 @@
+"""Training / evaluation steps on synthetic batches: the body of the reference's train() and validate() loops
+(model.py:684-775, :869-947) with the data loader replaced by seeded synthetic tensors of the same shapes
+(no frames, GloVe table or checkpoints exist offline -- SURVEY.md section 8d)."""
+import torch
+
+from . import synthetic as syn
+from .config import cfg
+from .model import GroundModel, default_args
+from .parallel import GradAllReducer, trainable_parameters
+
+
+class Batch:
+    """What train() unpacks from the loader (model.py:684) after the host-side preparation of :689-747."""
+
+    def __init__(self, im_data, im_info, glove_feats, entities_length):
+        self.im_data, self.im_info, self.glove_feats, self.entities_length = im_data, im_info, glove_feats, entities_length
+        self.gt_boxes = torch.zeros(1, 1, 5, device=im_data.device)
+        self.num_boxes = torch.zeros(1, device=im_data.device)
+
+
+def make_batch(Na, Ns, Ne, H=224, W=224, glove_dim=200, seed=1234, device='cuda', lens=None):
+    im, im_info = syn.frames(Na * Ns, H, W, seed=seed)
+    lens = lens if lens is not None else syn.entity_lengths(Na, Ne, seed=seed)
+    g = syn.glove(Na, Ne, lens, dim=glove_dim, seed=seed)
+    return Batch(im.to(device), im_info.to(device), g.to(device), lens)
+
+
+def build_model(args=None, device='cuda', seed=1234, heads=False):
+    """GroundModel with the seeded synthetic detector (random-init weights of the reference's architecture)."""
+    args = args or default_args()
+    model = GroundModel(args, cfg)
+    sd = syn.detector_state(seed=seed, heads=heads)
+    model.fasterRCNN.load_state_dict(sd, strict=heads)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():       # deterministic trainable weights (same on every rank)
+        for p in trainable_parameters(model):
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / p.shape[1]) ** 0.5)
+    return model.to(device)
+
+
+def make_optimizer(model, args):
+    """model.py:1075-1082: Adam over DVSA + word_ebd + vis_ebd."""
+    params = (list(model.DVSA.parameters()) + list(model.word_ebd.parameters()) + list(model.vis_ebd.parameters()))
+    return torch.optim.Adam(params, lr=args.lr, weight_decay=args.weight_decay)
+
+
+def train_step(model, optimizer, criterion, batch, args, reducer=None):
+    """One iteration of model.py:684-775.  Returns the (device) loss; no host synchronisation inside."""
+    with torch.no_grad():
+        rois, roi_scores, roi_feats, fc_feats = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes,
+                                                                 batch.num_boxes)
+    vis_feats = model.vis_ebd(fc_feats)
+    word_feats = model.word_ebd(batch.glove_feats)
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad()
+    D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
+    loss = criterion(margin_loss, torch.zeros_like(margin_loss))
+    loss.backward()
+    if reducer is not None:
+        reducer.allreduce()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
+    optimizer.step()
+    return loss.detach(), D, D_sim, rois
+
+
+def eval_step(model, batch):
+    """Forward of validate() (model.py:875-947) for one segment batch."""
+    with torch.no_grad():
+        rois, roi_scores, roi_feats, fc_feats = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes,
+                                                                 batch.num_boxes)
+        vis_feats = model.vis_ebd(fc_feats)
+        word_feats = model.word_ebd(batch.glove_feats)
+        D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
+    return margin_loss, D, D_sim, rois
+
+
+def setup_training(args, device='cuda', seed=1234, distributed=False):
+    model = build_model(args, device=device, seed=seed)
+    model.train()
+    model.DVSA.init_train()
+    model.fasterRCNN.eval()                      # model.py:671-673
+    reducer = GradAllReducer(trainable_parameters(model)) if distributed else None
+    optimizer = make_optimizer(model, args)
+    criterion = torch.nn.L1Loss()
+    return model, optimizer, criterion, reducer

@@ -1,0 +1,167 @@
+"""GPU parity tests, model level: the host-side mirror of the reference's model.py classes (nafae_amd/model.py,
+detector.py) against golden vectors generated from the imported reference and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from nafae_amd.config import cfg, cfg_from_file, reset_cfg
+    reset_cfg()
+    cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
+    return cfg
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def test_embed_and_dvsa_modules_match_reference(gpu):
+    """VisEbd / WordEbd / DVSA modules chained exactly like model.py:711,749,768-772, against the reference's
+    outputs and parameter gradients (tests/golden/embed.npz)."""
+    from nafae_amd.model import DVSA, VisEbd, WordEbd, default_args
+    g = np.load(os.path.join(G, "embed.npz"))
+    Na, Ns, Nb, Ne, D, FC, Gd = [int(x) for x in g["shape"]]
+    gpu.TEST.RPN_POST_NMS_TOP_N = Nb
+    args = default_args(batch_size=Na, batch_size_val=Na, sample_num=Ns, max_ent_len=Ne, dropout_rate=0.0, Delta=10.0,
+                        vis_lam=4.13, word_ebd_dim=D, vis_fc_dim=FC, glove_dim=Gd)
+    ve, we, dv = VisEbd(args).cuda(), WordEbd(args).cuda(), DVSA(args, gpu).cuda()
+    with torch.no_grad():
+        for p, k in ((ve.fc1.weight, "ve_w"), (ve.fc1.bias, "ve_b"), (we.fc1.weight, "we_w"), (we.fc1.bias, "we_b"),
+                     (we.bn.weight, "bn_w"), (we.bn.bias, "bn_b")):
+            p.copy_(torch.from_numpy(g[k]))
+    fc7, glove = torch.from_numpy(g["fc7"]).cuda(), torch.from_numpy(g["glove"]).cuda()
+    lens = g["lens"].tolist()
+    ve.train(); we.train(); dv.init_train()
+    V, W = ve(fc7), we(glove)
+    assert relerr(V.detach().cpu(), g["V_train"]) < TOL and relerr(W.detach().cpu(), g["W_train"]) < TOL
+    Di, Ds, L = dv(V, W, lens)
+    loss = torch.nn.L1Loss()(L, torch.zeros_like(L))
+    loss.backward()
+    assert np.array_equal(Di.cpu().numpy(), g["D_ind_train"])
+    assert abs(float(L) - float(g["loss_train"])) < TOL * abs(float(g["loss_train"]))
+    for p, k in ((ve.fc1.weight, "g_ve_w"), (ve.fc1.bias, "g_ve_b"), (we.fc1.weight, "g_we_w"), (we.fc1.bias, "g_we_b"),
+                 (we.bn.weight, "g_bn_w"), (we.bn.bias, "g_bn_b")):
+        assert relerr(p.grad.cpu(), g[k]) < 1e-3, k
+    assert relerr(we.bn.running_mean.cpu(), g["run_mean"]) < TOL and relerr(we.bn.running_var.cpu(), g["run_var"]) < TOL
+    assert all(p.grad is None for p in dv.parameters())          # DVSA's own parameters never get a gradient
+    ve.eval(); we.eval(); dv.init_eval()
+    with torch.no_grad():
+        V, W = ve(fc7), we(glove)
+        Di, Ds, L = dv(V, W, lens)
+    assert relerr(W.cpu(), g["W_eval"]) < TOL
+    assert np.array_equal(Di.cpu().numpy(), g["D_ind_eval"])
+    assert relerr(Ds.cpu(), g["D_sim_eval"]) < TOL
+    assert abs(float(L) - float(g["loss_eval"])) < TOL * abs(float(g["loss_eval"]))
+
+
+def _detector(seed, device="cuda"):
+    from nafae_amd import synthetic as syn
+    from nafae_amd.detector import vgg16
+    fr = vgg16(np.array([''] * 2501), pretrained=False, class_agnostic=False)
+    fr.create_architecture()
+    fr.load_state_dict(syn.detector_state(seed=seed, heads=False), strict=False)
+    return fr.eval().to(device)
+
+
+def test_detector_matches_reference_golden(gpu):
+    """fasterRCNN.forward against the reference's own forward on 2 small frames (tests/golden/detector.npz)."""
+    from nafae_amd import synthetic as syn
+    from oracle import detector as OD
+    g = np.load(os.path.join(G, "detector.npz"))
+    gpu.TEST.RPN_POST_NMS_TOP_N = int(g["post_nms_topN"])
+    fr = _detector(int(g["seed"]))
+    h, w = [int(x) for x in g["frames_hw"]]
+    im, im_info = syn.frames(2, h, w, seed=int(g["seed"]))
+    base = fr.base_features(im.cuda())
+    assert relerr(base.permute(0, 3, 1, 2).cpu(), g["base_feat"]) < TOL
+    rois, roi_scores, pooled, fc7 = fr(im.cuda(), im_info.cuda(), None, None)
+    assert tuple(pooled.shape) == (16, 512, 7, 7) and tuple(fc7.shape) == (16, 4096)
+    same = (rois.cpu().numpy() == g["rois"]).all(-1).reshape(-1)
+    assert same.mean() >= 0.9, "rois differ from the reference: %s" % same
+    assert np.allclose(roi_scores.cpu().numpy().reshape(-1)[same], g["roi_scores"].reshape(-1)[same], rtol=1e-5)
+    assert relerr(pooled.cpu().numpy()[same][:, ::37], g["pooled_sub"][same]) < TOL
+    assert relerr(fc7.cpu().numpy()[same], g["fc7"][same]) < TOL
+    # stage-wise with teacher forcing: oracle RPN/proposals fed with the HIP base_feat must give the HIP rois
+    sd = syn.detector_state(seed=int(g["seed"]), heads=False)
+    rp = {k[len('RCNN_rpn.'):]: v for k, v in sd.items() if k.startswith('RCNN_rpn.')}
+    prob, deltas = OD.rpn_head(base.permute(0, 3, 1, 2).cpu().contiguous(), rp)
+    s, props = OD.decode_proposals(prob, deltas, im_info, 16, [4, 8, 16, 32], [0.5, 1, 2])
+    r_o, rs_o, _ = OD.select_proposals(s, props, OD.sort_desc(s), 6000, int(g["post_nms_topN"]), 0.7)
+    assert ((rois.cpu() - r_o).abs().max(-1)[0] < 1e-3).float().mean() >= 0.9
+    # ROI-Align + head fed with the HIP rois
+    pooled_o = OD.roi_align_avg(base.permute(0, 3, 1, 2).cpu().contiguous(), rois.cpu().view(-1, 5))
+    assert relerr(pooled.cpu(), pooled_o) < 1e-5
+    assert relerr(fc7.cpu(), OD.head_to_tail(pooled_o, sd)) < TOL
+    # _head_to_tail on the logical NCHW view gives the same fc7 (vgg16_rpn.py:56-61 signature)
+    assert relerr(fr._head_to_tail(pooled).cpu(), fc7.cpu()) < 1e-6
+
+
+def test_detector_config_c1_against_oracle(gpu):
+    """BASELINE config C1: 4 frames 224x224, 32 proposals/frame; whole detector vs the CPU oracle."""
+    from nafae_amd import synthetic as syn
+    from oracle import detector as OD
+    gpu.TEST.RPN_POST_NMS_TOP_N = 32
+    fr = _detector(1234)
+    im, im_info = syn.frames(4, 224, 224, seed=1234)
+    rois, roi_scores, pooled, fc7 = fr(im.cuda(), im_info.cuda(), None, None)
+    sd = syn.detector_state(seed=1234, heads=False)
+    ocfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
+                RPN_POST_NMS_TOP_N=32, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
+    r_o, s_o, pooled_o, fc7_o = OD.detector_forward(im, im_info, sd, ocfg)
+    same = (rois.cpu() == r_o).all(-1).view(-1).numpy()
+    assert same.mean() >= 0.9
+    assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < TOL
+    assert (fr.n_keep.cpu() <= 32).all()
+
+
+def test_full_train_step_and_eval_step(gpu):
+    """One iteration of the reference's train loop body (model.py:706-774) and of validate (model.py:875-947)."""
+    from nafae_amd.model import default_args, postprocess, stepRCNN
+    from nafae_amd.train import eval_step, make_batch, setup_training, train_step
+    Na, Ns, Ne, Nb = 2, 3, 8, 16
+    gpu.TEST.RPN_POST_NMS_TOP_N = Nb
+    args = default_args(batch_size=Na, batch_size_val=Na, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
+    model, opt, crit, _ = setup_training(args, seed=3)
+    batch = make_batch(Na, Ns, Ne, H=96, W=80, seed=3, lens=[3, 5])
+    w0 = model.vis_ebd.fc1.weight.detach().clone()
+    base0 = model.fasterRCNN.RCNN_top[0].weight.detach().clone()
+    losses = [float(train_step(model, opt, crit, batch, args)[0]) for _ in range(3)]
+    assert all(np.isfinite(losses))
+    assert not torch.equal(w0, model.vis_ebd.fc1.weight)                     # trainable params moved
+    assert torch.equal(base0, model.fasterRCNN.RCNN_top[0].weight)           # detector stayed frozen
+    assert int(model.word_ebd.bn.num_batches_tracked) == 3
+    model.eval(); model.DVSA.init_eval()
+    L, D, D_sim, rois = eval_step(model, batch)
+    assert D.dtype == torch.int64 and tuple(D.shape) == (Na * Ns, Na * Ne) and int(D.max()) < Nb
+    Dp, Sp = postprocess(D.cpu().numpy(), D_sim.cpu().numpy(), Na, Ns, Nb, Ne)
+    assert Dp.shape == (Na, Ns, Ne) and Dp.max() < Na * Ns * Nb
+    # long-segment chunking (model.py:429-454)
+    r1, f1, c1 = stepRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes, model, step_size=4)
+    r2, _, f2, c2 = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+    assert torch.equal(r1[:, :, 1:], r2[:, :, 1:]) and torch.equal(c1, c2)
+
+
+def test_dropout_is_active_in_train_mode_only(gpu):
+    from nafae_amd.model import VisEbd, default_args
+    args = default_args(vis_fc_dim=64, word_ebd_dim=32, dropout_rate=0.5)
+    ve = VisEbd(args).cuda()
+    x = torch.randn(256, 64, device="cuda") * 100
+    ve.train()
+    y = ve(x)
+    frac0 = float((y == 0).float().mean())
+    assert 0.4 < frac0 < 0.6
+    ve.eval()
+    assert float((ve(x) == 0).float().mean()) < 0.01
