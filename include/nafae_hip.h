@@ -7,7 +7,8 @@
  *     buffer (outputs need not be pre-zeroed) and keeps ownership; nothing is allocated, freed or
  *     synchronised inside, so every call is hipGraph-capturable;
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
- *   - return value: 0 = launched, negative = NAFAE_E* argument error (nothing launched);
+ *   - return value: 0 = launched, negative = NAFAE_E* (argument error: nothing launched; NAFAE_ELAUNCH: the
+ *     runtime refused the launch);
  *     kernel-side failures surface through hipGetLastError()/stream sync of the caller, like any
  *     HIP launch.  (The reference prints-and-continues in NMS, nms_cuda_kernel.cu:14-26, and
  *     exit(-1)s in ROI-Align, roi_align_kernel.cu:84-88; a library must do neither.)
@@ -29,6 +30,7 @@ extern "C" {
 #define NAFAE_OK 0
 #define NAFAE_EINVAL (-1)   /* bad size / null pointer / unsupported shape */
 #define NAFAE_ELIMIT (-2)   /* shape exceeds a compiled limit (stated per function) */
+#define NAFAE_ELAUNCH (-3)  /* the HIP runtime rejected the kernel launch (hipGetLastError() != hipSuccess) */
 
 #define NAFAE_ACT_NONE 0
 #define NAFAE_ACT_RELU 1
@@ -49,7 +51,7 @@ int nafae_version(char *buf_host, int cap);
  * boxes: [n, dim] (dim >= 4; x1,y1,x2,y2[,score]) already sorted by descending score.
  * keep_out: int32[n] -- first *num_out entries are the kept positions, ascending; the rest is 0.
  * Device-resident: no host copies, no allocation (the reference does 2 cudaMalloc, a 696 KB D2H,
- * a host sweep and 2 H2D per frame).  Limit: n <= 16384.  */
+ * a host sweep and 2 H2D per frame).  Limit: n <= 8192 (kept boxes live in LDS).  */
 int nafae_nms(int32_t *keep_out, int32_t *num_out, const float *boxes, int n, int dim, float thresh,
               void *stream);
 

@@ -3,6 +3,11 @@ does not load, every op raises -- the product path never routes through PyTorch 
 import ctypes
 import os
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It MUST be the one already resident when
+# libnafae_hip.so is dlopen'ed, otherwise the process ends up with two runtimes and kernels launched through this
+# library never touch torch's device memory.  Importing torch first makes the dynamic linker reuse its runtime.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnafae_hip.so")
 _lib = None

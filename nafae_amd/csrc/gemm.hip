@@ -377,6 +377,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 }
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// launch failures (bad configuration, missing code object, wrong runtime) must be loud, never silent
+inline int launched() { return hipGetLastError() == hipSuccess ? NAFAE_OK : NAFAE_ELAUNCH; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int BM, int BN, int WM, int WN>
@@ -413,7 +415,7 @@ int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, in
     launch_gemm_nt<128, 64, 4, 1>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
   else
     launch_gemm_nt<128, 128, 2, 2>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
@@ -438,7 +440,7 @@ int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, in
   }
   hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tiles * splits), dim3(NTHREADS), lds, S(stream), A, lda, B, ldb, C,
                      ldc, M, N, K, alpha, accumulate, tiles_m, tiles_n, k_chunk);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias, float *out_nhwc, int F, int H,
@@ -448,7 +450,7 @@ int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias
   if ((total + 63) / 64 > 0x7fffffffL) return NAFAE_ELIMIT;
   int blocks = (int)((total + 63) / 64);
   hipLaunchKernelGGL(conv1_kernel, dim3(blocks), dim3(256), 0, S(stream), in_nchw, w, bias, out_nhwc, F, H, W);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float *out, int F, int H, int W, int Cin,
@@ -460,7 +462,7 @@ int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   else
     launch_conv<128, 128, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_maxpool2x2(const float *in, float *out, int F, int H, int W, int C, void *stream) {
@@ -468,7 +470,7 @@ int nafae_maxpool2x2(const float *in, float *out, int F, int H, int W, int C, vo
   long total = (long)F * (H / 2) * (W / 2) * (C / 4);
   int blocks = (int)((total + 255) / 256 < 256 * 8 ? (total + 255) / 256 : 256 * 8);
   hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, S(stream), in, out, F, H, W, C);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream) {
@@ -476,7 +478,7 @@ int nafae_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, 
   int rows = C, cols = H * W;
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, S(stream), in, out,
                      rows, cols);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_nhwc_to_nchw(const float *in, float *out, int N, int C, int H, int W, void *stream) {
@@ -484,7 +486,7 @@ int nafae_nhwc_to_nchw(const float *in, float *out, int N, int C, int H, int W, 
   int rows = H * W, cols = C;
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, S(stream), in, out,
                      rows, cols);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_version(char *buf, int cap) {

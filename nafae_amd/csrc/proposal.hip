@@ -18,6 +18,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// launch failures (bad configuration, missing code object, wrong runtime) must be loud, never silent
+inline int launched() { return hipGetLastError() == hipSuccess ? NAFAE_OK : NAFAE_ELAUNCH; }
 
 // ------------------------------------------------------------------------------------------------ decode
 __global__ __launch_bounds__(256) void rpn_decode_kernel(const float *__restrict__ head,
@@ -317,7 +319,7 @@ int nafae_rpn_decode(const float *head, const float *anchors, const float *im_in
   const long total = (long)F * H * W * A;
   hipLaunchKernelGGL(rpn_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), head, anchors,
                      im_info, scores, boxes, F, H, W, A, feat_stride);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_sort_desc(const float *scores, int32_t *order, int F, int n, void *stream) {
@@ -335,7 +337,7 @@ int nafae_sort_desc(const float *scores, int32_t *order, int F, int n, void *str
     }
   }
   hipLaunchKernelGGL(sort_kernel, dim3(F), dim3(P < 1024 ? P : 1024), lds, S(stream), scores, order, n, P);
-  return NAFAE_OK;
+  return launched();
 }
 
 static int launch_nms(const float *boxes, int box_stride, const float *scores, const int32_t *order, int F, int n,
@@ -353,7 +355,7 @@ static int launch_nms(const float *boxes, int box_stride, const float *scores, c
   }
   hipLaunchKernelGGL(nms_kernel, dim3(F), dim3(64), lds, st, boxes, box_stride, scores, order, n, n_sorted, thresh, topN,
                      keep_out, num_out, rois, roi_scores);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_nms(int32_t *keep_out, int32_t *num_out, const float *boxes, int n, int dim, float thresh, void *stream) {
@@ -377,7 +379,7 @@ int nafae_roi_align_forward(int AH, int AW, float scale, const float *features, 
   const long total = (long)N * C * AH * AW;
   hipLaunchKernelGGL(roi_align_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), total,
                      features, scale, H, W, C, AH, AW, rois, output);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, const float *rois, int N, float scale,
@@ -385,7 +387,7 @@ int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, cons
   if (!feat || !rois || !out || F <= 0 || H < 2 || W < 2 || C <= 0 || N <= 0) return NAFAE_EINVAL;
   if (C & 1) return NAFAE_EINVAL;
   hipLaunchKernelGGL(roi_align_avg_nhwc_kernel, dim3(N), dim3(256), 0, S(stream), feat, H, W, C, rois, scale, out);
-  return NAFAE_OK;
+  return launched();
 }
 
 }  // extern "C"

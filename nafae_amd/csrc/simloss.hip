@@ -21,6 +21,8 @@ namespace {
 constexpr float EPS = 1e-5f;  // model.py:33
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// launch failures (bad configuration, missing code object, wrong runtime) must be loud, never silent
+inline int launched() { return hipGetLastError() == hipSuccess ? NAFAE_OK : NAFAE_ELAUNCH; }
 
 __device__ __forceinline__ f32x4 ldg4(const float *p, bool ok) {
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -652,7 +654,7 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
   const size_t lds = (2 * E::STAGE + 128 * 33 + 2 * 8 * 32) * sizeof(float);
   hipLaunchKernelGGL(sim_max_kernel, dim3((Q + 31) / 32, F), dim3(NTHREADS), lds, S(stream), V, W, ent_len, Nb, Ne, Q, D,
                      S_max, D_ind);
-  return NAFAE_OK;
+  return launched();
 }
 
 int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D) {
@@ -685,7 +687,7 @@ int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V,
                        ws, L);
   }
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, S(stream), ws, L, Na, Ne, vis_lam, train, loss_out);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const float *W, const int32_t *ent_len,
@@ -700,7 +702,7 @@ int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const f
   hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, train,
                      Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
   hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3((Q + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, V, F, Nb, Q, D, grad_scale, dW);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_dropout_tanh(const float *x, const uint8_t *mask, float scale, float *y, int64_t n, void *stream) {
@@ -708,7 +710,7 @@ int nafae_dropout_tanh(const float *x, const uint8_t *mask, float scale, float *
   const long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(dropout_tanh_kernel, dim3(blocks), dim3(256), 0, S(stream), x, mask, scale, y, n4);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_dropout_tanh_bwd(const float *g_out, const float *y, const uint8_t *mask, float scale, float *g_in, int64_t n,
@@ -717,7 +719,7 @@ int nafae_dropout_tanh_bwd(const float *g_out, const float *y, const uint8_t *ma
   const long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(dropout_tanh_bwd_kernel, dim3(blocks), dim3(256), 0, S(stream), g_out, y, mask, scale, g_in, n4);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_batchnorm_fwd(const float *x, const float *weight, const float *bias, float *running_mean,
@@ -727,7 +729,7 @@ int nafae_batchnorm_fwd(const float *x, const float *weight, const float *bias, 
   if (!training && (!running_mean || !running_var)) return NAFAE_EINVAL;
   hipLaunchKernelGGL(bn_fwd_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), x, weight, bias, running_mean,
                      running_var, y, save_mean, save_invstd, Q, D, training, momentum, eps);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_batchnorm_bwd(const float *g_y, const float *x, const float *weight, const float *save_mean,
@@ -737,13 +739,13 @@ int nafae_batchnorm_bwd(const float *g_y, const float *x, const float *weight, c
     return NAFAE_EINVAL;
   hipLaunchKernelGGL(bn_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), g_y, x, weight, save_mean,
                      save_invstd, g_x, g_weight, g_bias, Q, D);
-  return NAFAE_OK;
+  return launched();
 }
 
 int nafae_colsum(const float *x, float *out, int rows, int cols, void *stream) {
   if (!x || !out || rows <= 0 || cols <= 0) return NAFAE_EINVAL;
   hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, S(stream), x, out, rows, cols);
-  return NAFAE_OK;
+  return launched();
 }
 
 }  // extern "C"

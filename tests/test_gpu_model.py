@@ -54,7 +54,9 @@ def test_embed_and_dvsa_modules_match_reference(gpu):
     assert abs(float(L) - float(g["loss_train"])) < TOL * abs(float(g["loss_train"]))
     for p, k in ((ve.fc1.weight, "g_ve_w"), (ve.fc1.bias, "g_ve_b"), (we.fc1.weight, "g_we_w"), (we.fc1.bias, "g_we_b"),
                  (we.bn.weight, "g_bn_w"), (we.bn.bias, "g_bn_b")):
-        assert relerr(p.grad.cpu(), g[k]) < 1e-3, k
+        # (the bias in front of a train-mode BatchNorm has an exactly-zero true gradient: absolute floor)
+        err = np.abs(p.grad.cpu().numpy().astype(np.float64) - g[k]).max()
+        assert err < TOL * max(np.abs(g[k]).max(), 1e-2), (k, err)
     assert relerr(we.bn.running_mean.cpu(), g["run_mean"]) < TOL and relerr(we.bn.running_var.cpu(), g["run_var"]) < TOL
     assert all(p.grad is None for p in dv.parameters())          # DVSA's own parameters never get a gradient
     ve.eval(); we.eval(); dv.init_eval()
@@ -89,7 +91,8 @@ def test_detector_matches_reference_golden(gpu):
     assert relerr(base.permute(0, 3, 1, 2).cpu(), g["base_feat"]) < TOL
     rois, roi_scores, pooled, fc7 = fr(im.cuda(), im_info.cuda(), None, None)
     assert tuple(pooled.shape) == (16, 512, 7, 7) and tuple(fc7.shape) == (16, 4096)
-    same = (rois.cpu().numpy() == g["rois"]).all(-1).reshape(-1)
+    # box coordinates are fp32 values downstream of 14 conv layers: "same proposal" = within 0.02 px (1e-4 of 224)
+    same = (np.abs(rois.cpu().numpy() - g["rois"]) < 0.02).all(-1).reshape(-1)
     assert same.mean() >= 0.9, "rois differ from the reference: %s" % same
     assert np.allclose(roi_scores.cpu().numpy().reshape(-1)[same], g["roi_scores"].reshape(-1)[same], rtol=1e-5)
     assert relerr(pooled.cpu().numpy()[same][:, ::37], g["pooled_sub"][same]) < TOL
@@ -121,8 +124,8 @@ def test_detector_config_c1_against_oracle(gpu):
     ocfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
                 RPN_POST_NMS_TOP_N=32, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
     r_o, s_o, pooled_o, fc7_o = OD.detector_forward(im, im_info, sd, ocfg)
-    same = (rois.cpu() == r_o).all(-1).view(-1).numpy()
-    assert same.mean() >= 0.9
+    same = ((rois.cpu() - r_o).abs() < 0.02).all(-1).view(-1).numpy()
+    assert same.mean() >= 0.9, same.mean()
     assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < TOL
     assert (fr.n_keep.cpu() <= 32).all()
 
