@@ -39,6 +39,20 @@ def flops_per_frame(Nb):
     return 30.693e9 + 0.939e9 + Nb * (205.5e6 + 33.55e6 + 4.19e6)
 
 
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch from the latest committed PMC pass (profiles/rNN_pmc_counters.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return d[kernel_key]["traffic_bytes_corrected"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(Na, Ns, Nb, Ne, seconds_budget=25.0):
     """CPU oracle (oracle/: plain PyTorch fp32 + C NMS/ROI-Align) on a bounded sample of the same workload:
     `nf` frames through the detector + embeddings, then sim+loss at the full (R, Q) shape, all host cores."""
@@ -152,13 +166,16 @@ def main():
             ach = fl / (fc6["avg_ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "gemm_nt_kernel<128,128,2,2> (fc6)", "bound": "mfma", "achieved": round(ach, 2),
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                               "traffic": None, "avg_ms": round(fc6["avg_ms"], 4), "launches": fc6["n"]}
+                               "traffic": pmc_traffic("gemm_nt_fc6") if a.workload == "c2" else None,
+                               "algorithmic": 4.0 * (R * 25088 + 4096 * 25088 + R * 4096),
+                               "avg_ms": round(fc6["avg_ms"], 4), "launches": fc6["n"]}
         sim = prof.get("sim_max")
         if sim:
             by = 4.0 * 512 * (R + Q) + 12.0 * F * Q
             ach = by / (sim["avg_ms"] * 1e-3) / 1e9
             out["roofline_sim"] = {"kernel": "sim_max_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                   "traffic": pmc_traffic("sim_max") if a.workload == "c2" else None,
                                    "avg_ms": round(sim["avg_ms"], 4),
                                    "mfma_frac": round(2.0 * R * Q * 512 / (sim["avg_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
         out["stage_ms"] = {k: round(v["avg_ms"], 4) for k, v in sorted(prof.items())}
