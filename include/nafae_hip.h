@@ -130,6 +130,35 @@ int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, cons
 int nafae_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream);
 int nafae_nhwc_to_nchw(const float *in, float *out, int N, int C, int H, int W, void *stream);
 
+
+/* ---- bf16 / split-bf16 ("bf16x3") detector kernels ------------------------------------------------------
+ * fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950.  An fp32 tensor x is carried as two bf16 planes
+ * hi = bf16(x), lo = bf16(x - hi) (same bytes as fp32) and products are evaluated as hi*hi + hi*lo + lo*hi with fp32
+ * accumulation (3 bf16 MFMAs, ~1e-5 relative error per product): the "bf16x3" precision of the detector.
+ * Passing NULL for every *_lo pointer selects plain bf16 (BASELINE config C3).  Planes are dense, same shape and
+ * layout as the fp32 tensor they stand for; pointers are to 2-byte bf16 elements, 16-byte aligned.  */
+int nafae_split_bf16(const float *in, void *hi, void *lo, int64_t n, void *stream);   /* n % 4 == 0; lo may be NULL */
+int nafae_merge_bf16(const void *hi, const void *lo, float *out, int64_t n, void *stream);
+
+/* act(alpha * X W^T + bias): X [M,K], W [N,K] as planes; output as fp32 (C_f32) and/or planes (C_hi[, C_lo]).
+ * K % 8 == 0, N % 4 == 0; act in {NONE, RELU}.  fc6 / fc7 (vgg16_rpn.py:56-61).  */
+int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *W_hi, const void *W_lo, int ldw,
+                       float *C_f32, void *C_hi, void *C_lo, int ldc, const float *bias, int M, int N, int K,
+                       float alpha, int act, void *stream);
+
+/* 3x3 conv + bias (+ReLU), NHWC planes in, fp32 and/or planes out; w planes are [Cout,3,3,Cin].  */
+int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
+                       float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
+                       void *stream);
+/* First VGG layer from the reference's fp32 NCHW frames straight to NHWC planes.  */
+int nafae_conv1_3x3_relu_bf16(const float *in_nchw, const float *w, const float *bias, void *out_hi, void *out_lo,
+                              int F, int H, int W, void *stream);
+int nafae_maxpool2x2_bf16(const void *in_hi, const void *in_lo, void *out_hi, void *out_lo, int F, int H, int W,
+                          int C, void *stream);                                          /* C % 8 == 0 */
+int nafae_roi_align_avg_nhwc_bf16(const void *feat_hi, const void *feat_lo, int F, int H, int W, int C,
+                                  const float *rois, int N, float spatial_scale, void *out_hi, void *out_lo,
+                                  void *stream);
+
 /* ---- similarity + loss (DVSA.forward, model.py:517-614) ---------------------------------------- */
 
 /* S_ = V W^T with masked query slots, reduced on the fly to per-frame max / arg-max over the Nb proposals

@@ -1,0 +1,134 @@
+// bf16_tile.h -- bf16 MFMA tile engine with optional split-bf16 ("bf16x3") fp32 emulation, gfx950.
+//
+// Why: fp32 MFMA runs at 1/16 of the bf16 MFMA rate on CDNA4 and there is no xf32/TF32 path.  An fp32 value x is
+// carried as two bf16 planes  hi = bf16(x), lo = bf16(x - hi)  (16-17 significant bits together, the same 4 bytes per
+// element as fp32), and a product is evaluated as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  on the bf16 matrix cores with
+// fp32 accumulation: 3 MFMAs instead of one fp32 MFMA that costs 16, relative error ~1e-5 per product (the dropped
+// lo*lo term and the representation error are each <= 2^-18).  With SPLIT = false only the hi planes exist: plain bf16
+// (BASELINE config C3).
+//
+// Mapping (cdna_hip_programming.md section 3):
+//   * v_mfma_f32_32x32x16_bf16, 32 cycles; lane l = (r = l&31, h = l>>5) supplies A[row r][k = 8h+j], B[k = 8h+j][col r].
+//   * OPERAND SWAP: the MFMA "A" operand is the WEIGHT side (rows = output channel n), the "B" operand is the
+//     ACTIVATION side (cols = pixel / row m).  Accumulator register r of lane l is then
+//     C[m = l&31][n = (r&3) + 8*(r>>2) + 4*(l>>5)]: 4 consecutive output channels of one row sit in 4 consecutive
+//     registers of one lane, so the epilogue writes 8-byte (bf16x4) / 16-byte (f32x4) pieces instead of 2-byte scalars.
+//   * both sides are K-contiguous in HBM; a k-tile is 32 bf16 = one 64-B row piece per plane; LDS image [rows][32]
+//     per plane with the four 16-B slots XOR-swizzled by (row>>2)&3 -> conflict-free ds_read_b128 fragment reads
+//     (16-lane groups cover rows that are distinct mod 16).
+//   * 512 threads = 8 waves (2 per SIMD), tile 256(m) x 128(n): 21-31 B/clk/CU of L2->LDS staging per k-tile, the most
+//     the L2 fabric sustains chip-wide at the bf16x3 MFMA rate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace nafae {
+
+constexpr int BKH = 32;    // bf16 elements per k-tile
+constexpr int NT16 = 512;  // threads per workgroup
+
+__device__ __forceinline__ int lds_off16(int row, int slot) { return row * BKH + ((slot ^ ((row >> 2) & 3)) << 3); }
+
+__device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
+  hi = (__bf16)v;
+  lo = (__bf16)(v - (float)hi);
+}
+
+// BX: rows of the activation side (m), BW: rows of the weight side (n); WX x WW waves.
+template <int BX, int BW, int WX, int WW, bool SPLIT>
+struct EngineH {
+  static_assert(WX * WW == 8, "8 waves per workgroup");
+  static constexpr int TX = BX / WX / 32;
+  static constexpr int TW = BW / WW / 32;
+  static_assert(TX >= 1 && TW >= 1, "tile too small");
+  static constexpr int PL = SPLIT ? 2 : 1;
+  static constexpr int CHUNKS = (BX + BW) * 4 * PL;  // 16-byte chunks per stage
+  static constexpr int NCH = (CHUNKS + NT16 - 1) / NT16;  // per thread (the last one may be partial)
+  static constexpr int STAGE = (BX + BW) * BKH * PL;  // bf16 elements per LDS stage
+  static constexpr int XCH = BX * 4 * PL;             // chunks of the activation side
+
+  f32x16 acc[TW][TX];
+  int lane, wx, ww;
+
+  __device__ __forceinline__ void init() {
+    lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    wx = wave / WW;
+    ww = wave % WW;
+    zero_acc();
+  }
+  __device__ __forceinline__ void zero_acc() {
+#pragma unroll
+    for (int i = 0; i < TW; i++)
+#pragma unroll
+      for (int j = 0; j < TX; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  }
+
+  // chunk i of this thread -> (is weight side, plane, row, slot) and its LDS element offset inside a stage
+  struct Chunk {
+    bool w, valid;
+    int plane, row, slot, lds;
+  };
+  __device__ __forceinline__ Chunk chunk(int i) const {
+    Chunk c;
+    int id = threadIdx.x + NT16 * i;
+    c.valid = id < CHUNKS;
+    if (!c.valid) id = 0;
+    c.slot = id & 3;
+    int rowg = id >> 2;
+    c.w = id >= XCH;
+    if (!c.w) {
+      c.plane = rowg / BX;
+      c.row = rowg - c.plane * BX;
+      c.lds = c.plane * BX * BKH + lds_off16(c.row, c.slot);
+    } else {
+      rowg -= BX * PL;
+      c.plane = rowg / BW;
+      c.row = rowg - c.plane * BW;
+      c.lds = BX * BKH * PL + c.plane * BW * BKH + lds_off16(c.row, c.slot);
+    }
+    return c;
+  }
+
+  __device__ __forceinline__ void compute(const __bf16 *stage) {
+    const __bf16 *sX = stage;
+    const __bf16 *sW = stage + BX * BKH * PL;
+    const int r31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf16x8 xa[PL][TX], wa[PL][TW];
+#pragma unroll
+      for (int p = 0; p < PL; p++) {
+#pragma unroll
+        for (int j = 0; j < TX; j++)
+          xa[p][j] = *reinterpret_cast<const bf16x8 *>(&sX[p * BX * BKH + lds_off16(wx * (TX * 32) + j * 32 + r31, 2 * s + h)]);
+#pragma unroll
+        for (int i = 0; i < TW; i++)
+          wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[p * BW * BKH + lds_off16(ww * (TW * 32) + i * 32 + r31, 2 * s + h)]);
+      }
+#pragma unroll
+      for (int i = 0; i < TW; i++)
+#pragma unroll
+        for (int j = 0; j < TX; j++) {
+          if (SPLIT) {  // small cross terms first, the dominant hi*hi last
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xa[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[1][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue coordinates: register group g (0..3) of tile (i, j) holds C[m][n .. n+3]
+  __device__ __forceinline__ int out_m(int j) const { return wx * (TX * 32) + j * 32 + (lane & 31); }
+  __device__ __forceinline__ int out_n(int i, int g) const { return ww * (TW * 32) + i * 32 + 8 * g + 4 * (lane >> 5); }
+};
+
+}  // namespace nafae

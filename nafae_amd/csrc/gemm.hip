@@ -313,9 +313,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ in
   float acc[16];
 #pragma unroll
   for (int c = 0; c < 16; c++) acc[c] = sb[cg + c];
-#pragma unroll
-  for (int ci = 0; ci < 3; ci++)
-#pragma unroll
+#pragma unroll 1
+  for (int ci = 0; ci < 3; ci++)  // not unrolled: a fully unrolled body keeps all 27x16 weights live (256 VGPRs, 1 wave/SIMD)
+#pragma unroll 1
     for (int ky = 0; ky < 3; ky++)
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {

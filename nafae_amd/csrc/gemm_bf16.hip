@@ -1,0 +1,450 @@
+// gemm_bf16.hip -- bf16 / split-bf16 ("bf16x3") MFMA contractions of the frozen detector (gfx950).
+//
+//   gemm_nt_bf16_kernel   C = act(alpha * X W^T + bias)   fc6 / fc7        (vgg16_rpn.py:56-61)
+//   conv3x3_bf16_kernel   implicit GEMM, NHWC planes                        (vgg16_rpn.py:38, rpn/rpn.py:63)
+//   split / conv1 / maxpool plane kernels
+//
+// Activations and weights are carried as bf16 planes (hi [, lo]); see bf16_tile.h for the numerics.  The exact-fp32
+// kernels in gemm.hip stay the reference implementation of the same entry points; which family runs is the
+// detector's `precision` switch (nafae_amd/detector.py).
+#include "bf16_tile.h"
+#include "mfma_tile.h"  // tile_coords
+#include "../../include/nafae_hip.h"
+
+using namespace nafae;
+
+namespace {
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launched() { return hipGetLastError() == hipSuccess ? NAFAE_OK : NAFAE_ELAUNCH; }
+
+__device__ __forceinline__ bf16x8 ldg8(const __bf16 *p, bool ok) {
+  bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? *reinterpret_cast<const bf16x8 *>(p) : z;
+}
+
+// shared epilogue: acc -> act(alpha*acc + bias) -> fp32 matrix and/or bf16 planes, row stride ldc
+template <class E, bool SPLIT>
+__device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, float alpha, const float *__restrict__ bias,
+                                         int act, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                                         __bf16 *__restrict__ Clo, int ldc) {
+#pragma unroll
+  for (int j = 0; j < E::TX; j++) {
+    const int m = m0 + e.out_m(j);
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < E::TW; i++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int n = n0 + e.out_n(i, g);
+        if (n >= N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float t = alpha * e.acc[i][j][4 * g + q] + (bias ? bias[n + q] : 0.f);
+          if (act == NAFAE_ACT_RELU) t = t > 0.f ? t : 0.f;
+          v[q] = t;
+        }
+        const size_t o = (size_t)m * ldc + n;
+        if (Cf) *reinterpret_cast<f32x4 *>(Cf + o) = v;
+        if (Chi) {
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            __bf16 a, b;
+            split_bf16(v[q], a, b);
+            hi[q] = a;
+            lo[q] = b;
+          }
+          *reinterpret_cast<bf16x4 *>(Chi + o) = hi;
+          if (SPLIT && Clo) *reinterpret_cast<bf16x4 *>(Clo + o) = lo;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+template <int BX, int BW, int WX, int WW, bool SPLIT>
+__global__ __launch_bounds__(NT16) void gemm_nt_bf16_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
+                                                            int ldx, const __bf16 *__restrict__ Whi,
+                                                            const __bf16 *__restrict__ Wlo, int ldw,
+                                                            float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                                                            __bf16 *__restrict__ Clo, int ldc,
+                                                            const float *__restrict__ bias, int M, int N, int K,
+                                                            float alpha, int act, int tiles_m, int tiles_n) {
+  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BX, n0 = tn * BW;
+  const int nk = (K + BKH - 1) / BKH;
+
+  const __bf16 *gp[E::NCH];
+  bool ok[E::NCH], live[E::NCH];
+  int ldsoff[E::NCH], kslot[E::NCH];
+#pragma unroll
+  for (int i = 0; i < E::NCH; i++) {
+    const typename E::Chunk c = e.chunk(i);
+    ldsoff[i] = c.lds;
+    live[i] = c.valid;
+    kslot[i] = c.slot * 8;
+    if (!c.w) {
+      const int m = m0 + c.row;
+      ok[i] = m < M;
+      gp[i] = (c.plane ? Xlo : Xhi) + (size_t)(ok[i] ? m : 0) * ldx + c.slot * 8;
+    } else {
+      const int n = n0 + c.row;
+      ok[i] = n < N;
+      gp[i] = (c.plane ? Wlo : Whi) + (size_t)(ok[i] ? n : 0) * ldw + c.slot * 8;
+    }
+  }
+  bf16x8 rg[E::NCH];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < E::NCH; i++) rg[i] = ldg8(gp[i] + kt * BKH, ok[i] && (kt * BKH + kslot[i] < K));
+  };
+  auto store = [&](__bf16 *stage) {
+#pragma unroll
+    for (int i = 0; i < E::NCH; i++)
+      if (live[i]) *reinterpret_cast<bf16x8 *>(&stage[ldsoff[i]]) = rg[i];
+  };
+  fetch(0);
+  store(smem16);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    __bf16 *cur = smem16 + (kt & 1) * E::STAGE;
+    __bf16 *nxt = smem16 + ((kt + 1) & 1) * E::STAGE;
+    if (kt + 1 < nk) fetch(kt + 1);
+    e.compute(cur);
+    if (kt + 1 < nk) store(nxt);
+    __syncthreads();
+  }
+  epilogue<E, SPLIT>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
+}
+
+// ------------------------------------------------------------------------------------------------ conv
+template <int BX, int BW, int WX, int WW, bool SPLIT>
+__global__ __launch_bounds__(NT16) void conv3x3_bf16_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
+                                                            const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+                                                            const float *__restrict__ bias, float *__restrict__ Cf,
+                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F,
+                                                            int H, int W, int Cin, int Cout, int relu, int tiles_m,
+                                                            int tiles_n) {
+  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int M = F * H * W;
+  const int m0 = tm * BX, n0 = tn * BW;
+  const int cpt = Cin / BKH;
+  const int nk = 9 * cpt;
+  const int K = 9 * Cin;
+
+  const __bf16 *gp[E::NCH];
+  bool ok[E::NCH], isw[E::NCH], live[E::NCH];
+  int ldsoff[E::NCH], py[E::NCH], px[E::NCH];
+#pragma unroll
+  for (int i = 0; i < E::NCH; i++) {
+    const typename E::Chunk c = e.chunk(i);
+    ldsoff[i] = c.lds;
+    live[i] = c.valid;
+    isw[i] = c.w;
+    if (!c.w) {
+      const int m = m0 + c.row;
+      ok[i] = m < M;
+      const int mm = ok[i] ? m : 0;
+      px[i] = mm % W;
+      py[i] = (mm / W) % H;
+      gp[i] = (c.plane ? Xlo : Xhi) + (size_t)mm * Cin + c.slot * 8;
+    } else {
+      const int n = n0 + c.row;
+      ok[i] = n < Cout;
+      px[i] = py[i] = 0;
+      gp[i] = (c.plane ? Wlo : Whi) + (size_t)(ok[i] ? n : 0) * K + c.slot * 8;
+    }
+  }
+  bf16x8 rg[E::NCH];
+  auto fetch = [&](int kt) {
+    const int tap = kt / cpt;
+    const int cc = kt - tap * cpt;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int aoff = (dy * W + dx) * Cin + cc * BKH;
+#pragma unroll
+    for (int i = 0; i < E::NCH; i++) {
+      if (isw[i]) {
+        rg[i] = ldg8(gp[i] + kt * BKH, ok[i]);
+      } else {
+        const int yy = py[i] + dy, xx = px[i] + dx;
+        rg[i] = ldg8(gp[i] + aoff, ok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W);
+      }
+    }
+  };
+  auto store = [&](__bf16 *stage) {
+#pragma unroll
+    for (int i = 0; i < E::NCH; i++)
+      if (live[i]) *reinterpret_cast<bf16x8 *>(&stage[ldsoff[i]]) = rg[i];
+  };
+  fetch(0);
+  store(smem16);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    __bf16 *cur = smem16 + (kt & 1) * E::STAGE;
+    __bf16 *nxt = smem16 + ((kt + 1) & 1) * E::STAGE;
+    if (kt + 1 < nk) fetch(kt + 1);
+    e.compute(cur);
+    if (kt + 1 < nk) store(nxt);
+    __syncthreads();
+  }
+  epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+}
+
+// ------------------------------------------------------------------------------------------------ plane helpers
+__global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ in, __bf16 *__restrict__ hi,
+                                                    __bf16 *__restrict__ lo, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4 *>(in)[i];
+    bf16x4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      __bf16 a, b;
+      split_bf16(v[q], a, b);
+      h[q] = a;
+      l[q] = b;
+    }
+    reinterpret_cast<bf16x4 *>(hi)[i] = h;
+    if (lo) reinterpret_cast<bf16x4 *>(lo)[i] = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void merge_kernel(const __bf16 *__restrict__ hi, const __bf16 *__restrict__ lo,
+                                                    float *__restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const bf16x4 h = reinterpret_cast<const bf16x4 *>(hi)[i];
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = (float)h[q];
+    if (lo) {
+      const bf16x4 l = reinterpret_cast<const bf16x4 *>(lo)[i];
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] += (float)l[q];
+    }
+    reinterpret_cast<f32x4 *>(out)[i] = v;
+  }
+}
+
+// First VGG layer (Cin = 3), fp32 NCHW frames in, bf16 planes out (NHWC, 64 channels).
+__global__ __launch_bounds__(256) void conv1_bf16_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, __bf16 *__restrict__ ohi,
+                                                         __bf16 *__restrict__ olo, int F, int H, int W) {
+  __shared__ float sw[27 * 64];
+  __shared__ float sb[64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    int co = i & 63, k = i >> 6;
+    sw[i] = w[co * 27 + k];
+  }
+  if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const long total = (long)F * H * W;
+  const long p = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (p >= total) return;
+  const int cg = (threadIdx.x & 3) * 16;
+  const int x = p % W;
+  const int y = (p / W) % H;
+  const long n = p / ((long)W * H);
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) acc[c] = sb[cg + c];
+#pragma unroll 1
+  for (int ci = 0; ci < 3; ci++)  // not unrolled: a fully unrolled body keeps all 27x16 weights live (256 VGPRs, 1 wave/SIMD)
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((n * 3 + ci) * H + yy) * W + xx];
+        const float *wk = &sw[(ci * 9 + ky * 3 + kx) * 64 + cg];
+#pragma unroll
+        for (int c = 0; c < 16; c++) acc[c] = fmaf(v, wk[c], acc[c]);
+      }
+  bf16x8 h[2], l[2];
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    __bf16 a, b;
+    split_bf16(fmaxf(acc[c], 0.f), a, b);
+    h[c >> 3][c & 7] = a;
+    l[c >> 3][c & 7] = b;
+  }
+  bf16x8 *oh = reinterpret_cast<bf16x8 *>(ohi + p * 64 + cg);
+  oh[0] = h[0];
+  oh[1] = h[1];
+  if (olo) {
+    bf16x8 *ol = reinterpret_cast<bf16x8 *>(olo + p * 64 + cg);
+    ol[0] = l[0];
+    ol[1] = l[1];
+  }
+}
+
+// 2x2/2 max-pool on NHWC planes: the (hi, lo) pair of the largest element is copied unchanged.
+__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const __bf16 *__restrict__ ihi, const __bf16 *__restrict__ ilo,
+                                                           __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo, int F, int H,
+                                                           int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+  const long total = (long)F * Ho * Wo * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C8;
+    long t = i / C8;
+    const int x = t % Wo;
+    t /= Wo;
+    const int y = t % Ho;
+    const long n = t / Ho;
+    const long base = ((n * H + 2 * y) * W + 2 * x) * (long)C8 + c;
+    const long offs[4] = {0, C8, (long)W * C8, (long)W * C8 + C8};
+    bf16x8 bh = reinterpret_cast<const bf16x8 *>(ihi)[base];
+    bf16x8 bl = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ilo) bl = reinterpret_cast<const bf16x8 *>(ilo)[base];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const bf16x8 h = reinterpret_cast<const bf16x8 *>(ihi)[base + offs[k]];
+      bf16x8 l = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ilo) l = reinterpret_cast<const bf16x8 *>(ilo)[base + offs[k]];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const float v = (float)h[q] + (float)l[q], b = (float)bh[q] + (float)bl[q];
+        if (v > b) {
+          bh[q] = h[q];
+          bl[q] = l[q];
+        }
+      }
+    }
+    reinterpret_cast<bf16x8 *>(ohi)[i] = bh;
+    if (olo) reinterpret_cast<bf16x8 *>(olo)[i] = bl;
+  }
+}
+
+template <int BX, int BW, int WX, int WW, bool SPLIT>
+int launch_gemm(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const void *Wlo, int ldw, float *Cf, void *Chi,
+                void *Clo, int ldc, const float *bias, int M, int N, int K, float alpha, int act, hipStream_t st) {
+  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
+  const size_t lds = 2 * E::STAGE * sizeof(__bf16);
+  auto kern = gemm_nt_bf16_kernel<BX, BW, WX, WW, SPLIT>;
+  if (lds > 64 * 1024) {
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      once = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, ldx,
+                     (const __bf16 *)Whi, (const __bf16 *)Wlo, ldw, Cf, (__bf16 *)Chi, (__bf16 *)Clo, ldc, bias, M, N, K, alpha,
+                     act, tiles_m, tiles_n);
+  return launched();
+}
+
+template <int BX, int BW, int WX, int WW, bool SPLIT>
+int launch_conv(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
+                void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  const int M = F * H * W;
+  const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
+  const size_t lds = 2 * E::STAGE * sizeof(__bf16);
+  auto kern = conv3x3_bf16_kernel<BX, BW, WX, WW, SPLIT>;
+  if (lds > 64 * 1024) {
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      once = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo,
+                     (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu,
+                     tiles_m, tiles_n);
+  return launched();
+}
+
+inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int nafae_split_bf16(const float *in, void *hi, void *lo, int64_t n, void *stream) {
+  if (!in || !hi || n <= 0 || (n & 3)) return NAFAE_EINVAL;
+  const long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, S(stream), in, (__bf16 *)hi, (__bf16 *)lo, n4);
+  return launched();
+}
+
+int nafae_merge_bf16(const void *hi, const void *lo, float *out, int64_t n, void *stream) {
+  if (!hi || !out || n <= 0 || (n & 3)) return NAFAE_EINVAL;
+  const long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(merge_kernel, dim3(blocks), dim3(256), 0, S(stream), (const __bf16 *)hi, (const __bf16 *)lo, out, n4);
+  return launched();
+}
+
+int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *W_hi, const void *W_lo, int ldw, float *C_f32,
+                       void *C_hi, void *C_lo, int ldc, const float *bias, int M, int N, int K, float alpha, int act,
+                       void *stream) {
+  if (!X_hi || !W_hi || (!C_f32 && !C_hi) || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
+  if ((K & 7) || (ldx & 7) || (ldw & 7) || (N & 3) || (ldc & 3) || !al16(X_hi) || !al16(W_hi)) return NAFAE_EINVAL;
+  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU) return NAFAE_EINVAL;
+  const bool split = X_lo && W_lo;
+  if (!split && (X_lo || W_lo)) return NAFAE_EINVAL;
+  if (split)
+    return launch_gemm<256, 128, 4, 2, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha, act,
+                                             S(stream));
+  return launch_gemm<256, 128, 4, 2, false>(X_hi, nullptr, ldx, W_hi, nullptr, ldw, C_f32, C_hi, nullptr, ldc, bias, M, N, K,
+                                            alpha, act, S(stream));
+}
+
+int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
+                       float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
+                       void *stream) {
+  if (!in_hi || !w_hi || !bias || (!out_f32 && !out_hi) || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
+  if (Cin % 32 || Cout % 4 || !al16(in_hi) || !al16(w_hi)) return NAFAE_EINVAL;
+  if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
+  const bool split = in_lo && w_lo;
+  if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
+  if (Cout <= 64) {
+    if (split)
+      return launch_conv<256, 64, 8, 1, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                              S(stream));
+    return launch_conv<256, 64, 8, 1, false>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H, W, Cin, Cout,
+                                             relu, S(stream));
+  }
+  if (split)
+    return launch_conv<256, 128, 4, 2, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                             S(stream));
+  return launch_conv<256, 128, 4, 2, false>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H, W, Cin, Cout,
+                                            relu, S(stream));
+}
+
+int nafae_conv1_3x3_relu_bf16(const float *in_nchw, const float *w, const float *bias, void *out_hi, void *out_lo, int F,
+                              int H, int W, void *stream) {
+  if (!in_nchw || !w || !bias || !out_hi || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
+  long total = (long)F * H * W;
+  if ((total + 63) / 64 > 0x7fffffffL) return NAFAE_ELIMIT;
+  hipLaunchKernelGGL(conv1_bf16_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, S(stream), in_nchw, w, bias,
+                     (__bf16 *)out_hi, (__bf16 *)out_lo, F, H, W);
+  return launched();
+}
+
+int nafae_maxpool2x2_bf16(const void *in_hi, const void *in_lo, void *out_hi, void *out_lo, int F, int H, int W, int C,
+                          void *stream) {
+  if (!in_hi || !out_hi || F <= 0 || (H & 1) || (W & 1) || (C & 7)) return NAFAE_EINVAL;
+  if ((in_lo == nullptr) != (out_lo == nullptr)) return NAFAE_EINVAL;
+  long total = (long)F * (H / 2) * (W / 2) * (C / 8);
+  int blocks = (int)((total + 255) / 256 < 256 * 8 ? (total + 255) / 256 : 256 * 8);
+  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(blocks), dim3(256), 0, S(stream), (const __bf16 *)in_hi, (const __bf16 *)in_lo,
+                     (__bf16 *)out_hi, (__bf16 *)out_lo, F, H, W, C);
+  return launched();
+}
+
+}  // extern "C"

@@ -308,6 +308,74 @@ __global__ __launch_bounds__(256) void roi_align_avg_nhwc_kernel(const float *__
   }
 }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// Same fused RoIAlignAvg on bf16 planes (hi [, lo]): feature value = hi + lo (split-bf16), output re-split.
+__global__ __launch_bounds__(256) void roi_align_avg_nhwc_bf16_kernel(const __bf16 *__restrict__ fhi,
+                                                                      const __bf16 *__restrict__ flo, int H, int W, int C,
+                                                                      const float *__restrict__ rois, float scale,
+                                                                      __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo) {
+  const int n = blockIdx.x;
+  const RoiGeom g = roi_geom(rois + (long)n * 5, scale, AS, AS);
+  __shared__ int s_hs[AS], s_ws[AS], s_hv[AS], s_wv[AS];
+  __shared__ float s_hr[AS], s_wr[AS];
+  if (threadIdx.x < AS) {
+    const int p = threadIdx.x;
+    const float h = (float)p * g.bin_h + g.start_h;
+    const float w = (float)p * g.bin_w + g.start_w;
+    const int hsp = (int)fminf(floorf(h), (float)(H - 2));
+    const int wsp = (int)fminf(floorf(w), (float)(W - 2));
+    s_hs[p] = hsp;
+    s_ws[p] = wsp;
+    s_hv[p] = !(h < 0 || h >= H);
+    s_wv[p] = !(w < 0 || w >= W);
+    s_hr[p] = h - (float)hsp;
+    s_wr[p] = w - (float)wsp;
+  }
+  __syncthreads();
+  const long img = (long)g.img * H * W * C;
+  const long ob = (long)n * PS * PS * C;
+  auto ld = [&](long off, int q) -> float {
+    float v = (float)fhi[off + q];
+    if (flo) v += (float)flo[off + q];
+    return v;
+  };
+  for (int c = threadIdx.x * 2; c < C; c += 512) {
+    f32x2 prev[AS], cur[AS];
+#pragma unroll
+    for (int ph = 0; ph < AS; ph++) {
+#pragma unroll
+      for (int pw = 0; pw < AS; pw++) {
+        f32x2 v = {0.f, 0.f};
+        if (s_hv[ph] && s_wv[pw]) {
+          const long p = img + ((long)s_hs[ph] * W + s_ws[pw]) * C + c;
+          const long r = (long)C, d = (long)W * C;
+          v[0] = bilerp(ld(p, 0), ld(p + r, 0), ld(p + d, 0), ld(p + d + r, 0), s_hr[ph], s_wr[pw]);
+          v[1] = bilerp(ld(p, 1), ld(p + r, 1), ld(p + d, 1), ld(p + d + r, 1), s_hr[ph], s_wr[pw]);
+        }
+        cur[pw] = v;
+      }
+      if (ph > 0) {
+#pragma unroll
+        for (int pw = 0; pw < PS; pw++) {
+          const float s0 = (((prev[pw][0] + prev[pw + 1][0]) + cur[pw][0]) + cur[pw + 1][0]) / 4.0f;
+          const float s1 = (((prev[pw][1] + prev[pw + 1][1]) + cur[pw][1]) + cur[pw + 1][1]) / 4.0f;
+          const long o = ob + ((ph - 1) * PS + pw) * (long)C + c;
+          const __bf16 h0 = (__bf16)s0, h1 = (__bf16)s1;
+          bf16x2_t hv = {h0, h1};
+          *reinterpret_cast<bf16x2_t *>(ohi + o) = hv;
+          if (olo) {
+            bf16x2_t lv = {(__bf16)(s0 - (float)h0), (__bf16)(s1 - (float)h1)};
+            *reinterpret_cast<bf16x2_t *>(olo + o) = lv;
+          }
+        }
+      }
+#pragma unroll
+      for (int pw = 0; pw < AS; pw++) prev[pw] = cur[pw];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -387,6 +455,16 @@ int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, cons
   if (!feat || !rois || !out || F <= 0 || H < 2 || W < 2 || C <= 0 || N <= 0) return NAFAE_EINVAL;
   if (C & 1) return NAFAE_EINVAL;
   hipLaunchKernelGGL(roi_align_avg_nhwc_kernel, dim3(N), dim3(256), 0, S(stream), feat, H, W, C, rois, scale, out);
+  return launched();
+}
+
+int nafae_roi_align_avg_nhwc_bf16(const void *feat_hi, const void *feat_lo, int F, int H, int W, int C, const float *rois,
+                                  int N, float spatial_scale, void *out_hi, void *out_lo, void *stream) {
+  if (!feat_hi || !rois || !out_hi || F <= 0 || H < 2 || W < 2 || C <= 0 || N <= 0) return NAFAE_EINVAL;
+  if (C & 1) return NAFAE_EINVAL;
+  if ((feat_lo == nullptr) != (out_lo == nullptr)) return NAFAE_EINVAL;
+  hipLaunchKernelGGL(roi_align_avg_nhwc_bf16_kernel, dim3(N), dim3(256), 0, S(stream), (const __bf16 *)feat_hi,
+                     (const __bf16 *)feat_lo, H, W, C, rois, spatial_scale, (__bf16 *)out_hi, (__bf16 *)out_lo);
   return launched();
 }
 

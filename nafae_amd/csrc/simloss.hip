@@ -626,18 +626,23 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ g
   }
 }
 
-// out[j] = sum_i x[i][j]: block = 64 columns x 4 row-groups, fixed-order combine
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, int rows,
-                                                     int cols) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
+// out[j] = sum_i x[i][j]: block = 16 columns x 64 row-groups (1024 threads), fixed-order LDS combine -> deterministic
+__global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, int rows,
+                                                      int cols) {
+  __shared__ float part[64][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float acc = 0.f;
   if (c < cols)
-    for (int r = g; r < rows; r += 4) acc += x[(size_t)r * cols + c];
-  part[g][threadIdx.x & 63] = acc;
+    for (int r = g; r < rows; r += 64) acc += x[(size_t)r * cols + c];
+  part[g][cl] = acc;
   __syncthreads();
-  if (g == 0 && c < cols) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (g == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; k++) t += part[k][cl];
+    out[c] = t;
+  }
 }
 
 }  // namespace
@@ -744,7 +749,7 @@ int nafae_batchnorm_bwd(const float *g_y, const float *x, const float *weight, c
 
 int nafae_colsum(const float *x, float *out, int rows, int cols, void *stream) {
   if (!x || !out || rows <= 0 || cols <= 0) return NAFAE_EINVAL;
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, S(stream), x, out, rows, cols);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 15) / 16), dim3(1024), 0, S(stream), x, out, rows, cols);
   return launched();
 }
 

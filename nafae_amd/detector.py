@@ -14,6 +14,8 @@ Activations are NHWC so every contraction's K dimension is contiguous; weights k
 state dict (checkpoint compatible) and are re-laid-out once into kernel layout (``_pack``), re-done automatically
 whenever the parameters change (load_state_dict / .to()).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -78,11 +80,15 @@ class _fasterRCNN(nn.Module):
         self.RCNN_rpn = _RPN(self.dout_base_model)
         self._packed = None
         self._packed_key = None
+        # arithmetic of the conv stack / fc6 / fc7: 'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 on the bf16 matrix
+        # cores, fp32-accurate to ~1e-5) or 'bf16' (plain bf16, BASELINE config C3)
+        self.precision = os.environ.get("NAFAE_PRECISION", "f32")
+        self.materialize_pooled = True     # bf16 modes: also hand out pooled_feat as fp32 (API parity)
 
     # ------------------------------------------------------------------ weights -> kernel layout
     def _pack_key(self):
         ps = list(self.parameters())
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def _pack(self):
         key = self._pack_key()
@@ -112,13 +118,37 @@ class _fasterRCNN(nn.Module):
             P['fc7_b'] = fc7.bias.detach().contiguous()
             anc = generate_anchors(scales=np.array(r.anchor_scales), ratios=np.array(r.anchor_ratios))
             P['anchors'] = torch.from_numpy(anc).float().to(c0.weight.device)
+            if self.precision != 'f32':
+                if self.precision not in ('bf16x3', 'bf16'):
+                    raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16', got %r" % (self.precision,))
+                sp = self.precision == 'bf16x3'
+                P['convs_h'] = [(ops.split_bf16(w, sp), b) for (w, b) in P['convs']]
+                P['rpn_w_h'] = ops.split_bf16(P['rpn_w'], sp)
+                P['fc6_w_h'] = ops.split_bf16(P['fc6_w'], sp)
+                P['fc7_w_h'] = ops.split_bf16(P['fc7_w'], sp)
+                # the fp32 copies of the big matrices are not needed on this path
+                P['convs'] = None
+                P['fc6_w'] = None
+                P['fc7_w'] = None
+                P['rpn_w'] = None
         self._packed, self._packed_key = P, key
         return P
 
     # ------------------------------------------------------------------ forward
     def base_features(self, im_data):
-        """RCNN_base (vgg16_rpn.py:38) -> NHWC [F, H/16, W/16, 512]."""
+        """RCNN_base (vgg16_rpn.py:38) -> NHWC [F, H/16, W/16, 512] (fp32 tensor, or ops.Planes in the bf16 modes)."""
         P = self._pack()
+        if self.precision != 'f32':
+            x = ops.conv1_3x3_relu_bf16(im_data.contiguous(), P['conv1_w'], P['conv1_b'], split=self.precision == 'bf16x3')
+            li = 0
+            for v in VGG_CFG_D[1:]:
+                if v == 'M':
+                    x = ops.maxpool2x2_bf16(x)
+                else:
+                    w, b = P['convs_h'][li]
+                    _, x = ops.conv3x3_bf16(x, w, b, relu=True)
+                    li += 1
+            return x
         x = ops.conv1_3x3_relu(im_data.contiguous(), P['conv1_w'], P['conv1_b'])
         li = 0
         for v in VGG_CFG_D[1:]:
@@ -136,7 +166,10 @@ class _fasterRCNN(nn.Module):
         F, h, w, _ = base_feat.shape
         r = self.RCNN_rpn
         A = r.nc_score_out // 2
-        x = ops.conv3x3_relu(base_feat, P['rpn_w'], P['rpn_b'], relu=True)
+        if self.precision != 'f32':
+            x, _ = ops.conv3x3_bf16(base_feat, P['rpn_w_h'], P['rpn_b'], relu=True, want_f32=True, want_planes=False)
+        else:
+            x = ops.conv3x3_relu(base_feat, P['rpn_w'], P['rpn_b'], relu=True)
         head = ops.gemm_nt(x.view(F * h * w, 512), P['head_w'], P['head_b'])
         scores, boxes = ops.rpn_decode(head, P['anchors'], im_info.contiguous().float(), F, h, w, A, r.feat_stride)
         order = ops.sort_desc(scores)
@@ -160,13 +193,25 @@ class _fasterRCNN(nn.Module):
             with ops.timed("rpn"):
                 rois, roi_scores = self.proposals(base_feat, im_info)
             R = rois.shape[0] * rois.shape[1]
-            with ops.timed("roi_align"):
-                pooled = ops.roi_align_avg_nhwc(base_feat, rois.view(R, 5), 1.0 / 16.0)      # [R,7,7,512]
-            with ops.timed("fc6"):
-                fc6 = ops.gemm_nt(pooled.view(R, -1), P['fc6_w'], P['fc6_b'], act=ops.ACT_RELU)
-            with ops.timed("fc7"):
-                fc7 = ops.gemm_nt(fc6, P['fc7_w'], P['fc7_b'], act=ops.ACT_RELU)
-            pooled_feat = pooled.permute(0, 3, 1, 2)     # logical [R,512,7,7] (channels-last memory)
+            if self.precision != 'f32':
+                with ops.timed("roi_align"):
+                    pooled = ops.roi_align_avg_nhwc_bf16(base_feat, rois.view(R, 5), 1.0 / 16.0)
+                with ops.timed("fc6"):
+                    _, fc6 = ops.gemm_nt_bf16(pooled.view(R, -1), P['fc6_w_h'], P['fc6_b'], act=ops.ACT_RELU)
+                with ops.timed("fc7"):
+                    fc7, _ = ops.gemm_nt_bf16(fc6, P['fc7_w_h'], P['fc7_b'], act=ops.ACT_RELU, want_f32=True,
+                                              want_planes=False)
+                with ops.timed("pooled_f32"):
+                    pooled = ops.merge_bf16(pooled) if self.materialize_pooled else None
+            else:
+                with ops.timed("roi_align"):
+                    pooled = ops.roi_align_avg_nhwc(base_feat, rois.view(R, 5), 1.0 / 16.0)  # [R,7,7,512]
+                with ops.timed("fc6"):
+                    fc6 = ops.gemm_nt(pooled.view(R, -1), P['fc6_w'], P['fc6_b'], act=ops.ACT_RELU)
+                with ops.timed("fc7"):
+                    fc7 = ops.gemm_nt(fc6, P['fc7_w'], P['fc7_b'], act=ops.ACT_RELU)
+            # logical [R,512,7,7] (channels-last memory)
+            pooled_feat = pooled.permute(0, 3, 1, 2) if pooled is not None else None
         return rois, roi_scores, pooled_feat, fc7
 
     def _init_weights(self):
@@ -219,5 +264,9 @@ class vgg16(_fasterRCNN):
         P = self._pack()
         R = pool5.shape[0]
         x = pool5.permute(0, 2, 3, 1).contiguous().view(R, -1)          # (ph,pw,c) order of the packed fc6
+        if self.precision != 'f32':
+            _, fc6 = ops.gemm_nt_bf16(ops.split_bf16(x, self.precision == 'bf16x3'), P['fc6_w_h'], P['fc6_b'],
+                                      act=ops.ACT_RELU)
+            return ops.gemm_nt_bf16(fc6, P['fc7_w_h'], P['fc7_b'], act=ops.ACT_RELU, want_f32=True, want_planes=False)[0]
         fc6 = ops.gemm_nt(x, P['fc6_w'], P['fc6_b'], act=ops.ACT_RELU)
         return ops.gemm_nt(fc6, P['fc7_w'], P['fc7_b'], act=ops.ACT_RELU)

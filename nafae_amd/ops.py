@@ -156,6 +156,107 @@ def nhwc_to_nchw(x):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ bf16 / bf16x3 planes
+class Planes:
+    """An fp32 tensor carried as bf16 planes: value = hi (+ lo).  lo is None in plain-bf16 mode."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo=None):
+        self.hi, self.lo = hi, lo
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def view(self, *shape):
+        return Planes(self.hi.view(*shape), None if self.lo is None else self.lo.view(*shape))
+
+
+def split_bf16(x, split=True):
+    _chk(x)
+    hi = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    lo = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if split else None
+    _rc(_lib.lib().nafae_split_bf16(_p(x), _p(hi), _p(lo), x.numel(), _stream()), "nafae_split_bf16")
+    return Planes(hi, lo)
+
+
+def merge_bf16(pl):
+    _chk(pl.hi, torch.bfloat16); _chk(pl.lo, torch.bfloat16)
+    out = torch.empty(pl.hi.shape, device=pl.hi.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_merge_bf16(_p(pl.hi), _p(pl.lo), _p(out), out.numel(), _stream()), "nafae_merge_bf16")
+    return out
+
+
+def _outs(shape, device, want_f32, want_planes, split):
+    cf = torch.empty(shape, device=device, dtype=torch.float32) if want_f32 else None
+    ch = torch.empty(shape, device=device, dtype=torch.bfloat16) if want_planes else None
+    cl = torch.empty(shape, device=device, dtype=torch.bfloat16) if (want_planes and split) else None
+    return cf, ch, cl
+
+
+def gemm_nt_bf16(X, Wt, bias=None, alpha=1.0, act=ACT_NONE, want_f32=False, want_planes=True):
+    """act(alpha * X @ W.T + bias) on the bf16 matrix cores; X, Wt are Planes ([M,K], [N,K]).
+    Returns (f32 tensor or None, Planes or None)."""
+    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16); _chk(Wt.hi, torch.bfloat16); _chk(Wt.lo, torch.bfloat16)
+    _chk(bias)
+    M, K = X.hi.shape
+    N = Wt.hi.shape[0]
+    split = X.lo is not None
+    if (Wt.lo is not None) != split or Wt.hi.shape[1] != K:
+        raise NafaeOpError("gemm_nt_bf16: operand mismatch")
+    cf, ch, cl = _outs((M, N), X.hi.device, want_f32, want_planes, split)
+    _rc(_lib.lib().nafae_gemm_nt_bf16(_p(X.hi), _p(X.lo), K, _p(Wt.hi), _p(Wt.lo), K, _p(cf), _p(ch), _p(cl), N, _p(bias), M, N, K,
+                                      float(alpha), int(act), _stream()), "nafae_gemm_nt_bf16")
+    return cf, (Planes(ch, cl) if want_planes else None)
+
+
+def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True):
+    """X Planes [F,H,W,Cin], Wt Planes [Cout,3,3,Cin] -> (f32 or None, Planes or None) of [F,H,W,Cout]."""
+    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16); _chk(Wt.hi, torch.bfloat16); _chk(Wt.lo, torch.bfloat16)
+    _chk(bias)
+    F, H, W, Cin = X.hi.shape
+    Cout = Wt.hi.shape[0]
+    split = X.lo is not None
+    if (Wt.lo is not None) != split or Wt.hi.numel() != Cout * 9 * Cin:
+        raise NafaeOpError("conv3x3_bf16: operand mismatch")
+    cf, ch, cl = _outs((F, H, W, Cout), X.hi.device, want_f32, want_planes, split)
+    _rc(_lib.lib().nafae_conv3x3_bf16(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), _p(cf), _p(ch), _p(cl), F, H, W, Cin, Cout,
+                                      int(bool(relu)), _stream()), "nafae_conv3x3_bf16")
+    return cf, (Planes(ch, cl) if want_planes else None)
+
+
+def conv1_3x3_relu_bf16(x_nchw, w27, bias, split=True):
+    _chk(x_nchw); _chk(w27); _chk(bias)
+    F, C, H, W = x_nchw.shape
+    if C != 3 or w27.numel() != 64 * 27:
+        raise NafaeOpError("conv1: expects Cin=3, Cout=64")
+    hi = torch.empty(F, H, W, 64, device=x_nchw.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi) if split else None
+    _rc(_lib.lib().nafae_conv1_3x3_relu_bf16(_p(x_nchw), _p(w27), _p(bias), _p(hi), _p(lo), F, H, W, _stream()),
+        "nafae_conv1_3x3_relu_bf16")
+    return Planes(hi, lo)
+
+
+def maxpool2x2_bf16(X):
+    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16)
+    F, H, W, C = X.hi.shape
+    hi = torch.empty(F, H // 2, W // 2, C, device=X.hi.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi) if X.lo is not None else None
+    _rc(_lib.lib().nafae_maxpool2x2_bf16(_p(X.hi), _p(X.lo), _p(hi), _p(lo), F, H, W, C, _stream()), "nafae_maxpool2x2_bf16")
+    return Planes(hi, lo)
+
+
+def roi_align_avg_nhwc_bf16(X, rois, spatial_scale):
+    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16); _chk(rois)
+    F, H, W, C = X.hi.shape
+    N = rois.shape[0]
+    hi = torch.empty(N, 7, 7, C, device=rois.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi) if X.lo is not None else None
+    _rc(_lib.lib().nafae_roi_align_avg_nhwc_bf16(_p(X.hi), _p(X.lo), F, H, W, C, _p(rois), N, float(spatial_scale), _p(hi), _p(lo),
+                                                 _stream()), "nafae_roi_align_avg_nhwc_bf16")
+    return Planes(hi, lo)
+
+
 # ------------------------------------------------------------------------------------------------ proposals
 def rpn_decode(head, anchors, im_info, F, H, W, A, feat_stride):
     _chk(head); _chk(anchors); _chk(im_info)

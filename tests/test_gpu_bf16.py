@@ -1,0 +1,153 @@
+"""GPU parity tests of the bf16 / split-bf16 ("bf16x3") detector kernels (nafae_amd/csrc/gemm_bf16.hip, bf16_tile.h).
+bf16x3 must meet the same 1e-4 fp32 bar as the exact-fp32 path; plain bf16 (BASELINE config C3) gets bf16's own
+tolerance (2e-2 relative to tensor scale, stated here)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = {True: 1e-4, False: 2e-2}      # split (bf16x3) / plain bf16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from nafae_amd import ops as _ops
+    return _ops
+
+
+def dev(x):
+    return torch.as_tensor(x).contiguous().cuda()
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def rnd(seed, *shape, std=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * std
+
+
+def test_split_merge_roundtrip(ops):
+    x = rnd(1, 1000, 64) * torch.logspace(-3, 3, 64)
+    p = ops.split_bf16(dev(x))
+    y = ops.merge_bf16(p).cpu()
+    assert float(((y - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    assert torch.equal(p.hi.cpu(), x.to(torch.bfloat16))
+    p1 = ops.split_bf16(dev(x), split=False)
+    assert p1.lo is None and torch.equal(ops.merge_bf16(p1).cpu(), x.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 200, 200), (257, 72, 512), (16, 512, 200), (1, 4, 8),
+                                   (513, 132, 40), (1000, 4096, 64)])
+def test_gemm_nt_bf16(ops, split, M, N, K):
+    A, B, bias = rnd(1, M, K), rnd(2, N, K), rnd(3, N)
+    ref = 0.37 * (A.double() @ B.double().T) + bias.double()
+    Xp, Wp = ops.split_bf16(dev(A), split), ops.split_bf16(dev(B), split)
+    cf, cp = ops.gemm_nt_bf16(Xp, Wp, dev(bias), alpha=0.37, act=0, want_f32=True, want_planes=True)
+    assert relerr(cf.cpu(), ref) < TOL[split]
+    assert relerr(ops.merge_bf16(cp).cpu(), ref) < (2 * TOL[split] if split else 2e-2)
+    cf2, _ = ops.gemm_nt_bf16(Xp, Wp, dev(bias), alpha=0.37, act=1, want_f32=True, want_planes=False)
+    assert relerr(cf2.cpu(), torch.relu(ref)) < TOL[split]
+
+
+def test_gemm_nt_bf16_orientation_exact(ops):
+    # A = I with an asymmetric, bf16-exact B: any transposed / permuted C write shows up as a mismatch
+    n = 288
+    A = torch.eye(n)
+    B = ((torch.arange(n * n) * 7) % 251).float().reshape(n, n)
+    for split in (True, False):
+        cf, _ = ops.gemm_nt_bf16(ops.split_bf16(dev(A), split), ops.split_bf16(dev(B), split), None, want_f32=True,
+                                 want_planes=False)
+        assert torch.equal(cf.cpu(), B.T.contiguous())
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout,relu", [(2, 14, 14, 64, 64, True), (1, 6, 5, 32, 132, False),
+                                                  (3, 9, 11, 96, 512, True), (1, 28, 28, 128, 128, True)])
+def test_conv3x3_bf16(ops, split, Fr, H, W, Cin, Cout, relu):
+    x = rnd(6, Fr, Cin, H, W)
+    w = rnd(7, Cout, Cin, 3, 3, std=0.05)
+    b = rnd(8, Cout, std=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    xp = ops.split_bf16(dev(x.permute(0, 2, 3, 1).contiguous()), split)
+    wp = ops.split_bf16(dev(w.permute(0, 2, 3, 1).contiguous()), split)
+    cf, cp = ops.conv3x3_bf16(xp, wp, dev(b), relu=relu, want_f32=True, want_planes=True)
+    assert relerr(cf.cpu().permute(0, 3, 1, 2), ref) < TOL[split]
+    assert relerr(ops.merge_bf16(cp).cpu().permute(0, 3, 1, 2), ref) < 2 * TOL[split]
+
+
+def test_conv1_maxpool_roialign_planes(ops):
+    from oracle import native as N
+    x = torch.randint(0, 255, (3, 3, 20, 18), generator=torch.Generator().manual_seed(9)).float() - 127.5
+    w = rnd(10, 64, 3, 3, 3, std=0.01)
+    b = rnd(11, 64, std=0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    p = ops.conv1_3x3_relu_bf16(dev(x), dev(w.reshape(64, 27)), dev(b))
+    assert relerr(ops.merge_bf16(p).cpu().permute(0, 3, 1, 2), ref) < 1e-4
+    # max-pool on planes == max-pool of the merged values
+    m = ops.merge_bf16(p).cpu().permute(0, 3, 1, 2)
+    q = ops.maxpool2x2_bf16(p)
+    assert torch.equal(ops.merge_bf16(q).cpu().permute(0, 3, 1, 2), F.max_pool2d(m, 2, 2))
+    # ROI-Align on planes vs the oracle on the merged feature map
+    rs = np.random.RandomState(6)
+    f = rs.randn(3, 512, 14, 14).astype(np.float32)
+    fp = ops.split_bf16(dev(torch.from_numpy(f).permute(0, 2, 3, 1).contiguous()))
+    fm = ops.merge_bf16(fp).cpu().permute(0, 3, 1, 2).contiguous().numpy()
+    xy = rs.rand(40, 2) * 180
+    rois = np.concatenate([rs.randint(0, 3, (40, 1)), xy, np.minimum(xy + rs.rand(40, 2) * 130, 223)], 1).astype(np.float32)
+    rois[0] = [0, 0, 0, 223, 223]; rois[1] = [2, 0, 0, 0, 0]; rois[2] = [0, 160, 20, 16, 200]
+    ref = N.roi_align_avg(fm, rois, 7, 1 / 16.)
+    out = ops.merge_bf16(ops.roi_align_avg_nhwc_bf16(fp, dev(rois), 1 / 16.)).cpu().permute(0, 3, 1, 2).numpy()
+    assert relerr(out, ref) < 2e-5
+
+
+def _detector(seed, precision):
+    from nafae_amd import synthetic as syn
+    from nafae_amd.detector import vgg16
+    fr = vgg16(np.array([''] * 2501), pretrained=False, class_agnostic=False)
+    fr.create_architecture()
+    fr.load_state_dict(syn.detector_state(seed=seed, heads=False), strict=False)
+    fr.precision = precision
+    return fr.eval().cuda()
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 5e-2)])
+def test_detector_c1_in_bf16_modes(ops, precision, tol):
+    """BASELINE config C1 through the whole detector in the bf16 modes, against the CPU oracle (fp32)."""
+    from nafae_amd import synthetic as syn
+    from nafae_amd.config import cfg, cfg_from_file, reset_cfg
+    from oracle import detector as OD
+    reset_cfg()
+    cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
+    cfg.TEST.RPN_POST_NMS_TOP_N = 32
+    fr = _detector(1234, precision)
+    im, im_info = syn.frames(4, 224, 224, seed=1234)
+    base = ops.merge_bf16(fr.base_features(im.cuda())).cpu().permute(0, 3, 1, 2)
+    sd = syn.detector_state(seed=1234, heads=False)
+    base_o = OD.vgg16_features(im, sd)
+    assert relerr(base, base_o) < tol
+    rois, roi_scores, pooled, fc7 = fr(im.cuda(), im_info.cuda(), None, None)
+    assert tuple(pooled.shape) == (128, 512, 7, 7) and pooled.dtype == torch.float32
+    ocfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
+                RPN_POST_NMS_TOP_N=32, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
+    r_o, s_o, pooled_o, fc7_o = OD.detector_forward(im, im_info, sd, ocfg)
+    if precision == "bf16x3":
+        same = ((rois.cpu() - r_o).abs() < 0.05).all(-1).view(-1).numpy()
+        assert same.mean() >= 0.9, same.mean()
+        assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < tol
+        assert relerr(pooled.cpu().numpy()[same], pooled_o.numpy()[same]) < tol
+    else:
+        # plain bf16 moves box coordinates by O(0.1 px): compare the head on the HIP path's own rois
+        pooled_t = OD.roi_align_avg(base_o, rois.cpu().view(-1, 5))
+        assert relerr(fc7.cpu(), OD.head_to_tail(pooled_t, sd)) < tol
