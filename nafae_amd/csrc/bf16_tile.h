@@ -97,7 +97,11 @@ struct EngineH {
     return c;
   }
 
-  __device__ __forceinline__ void compute(const __bf16 *stage) {
+  // `between(g)` is called after the MFMAs of accumulator tile g (g = 0 .. 2*TW*TX-1 over the two k-steps): the DMA
+  // pipeline issues one staging instruction there, so the ~60-100 cycle issue cost of each global_load_lds overlaps
+  // matrix work already queued on the pipe instead of serialising in front of it.
+  template <class Fn>
+  __device__ __forceinline__ void compute(const __bf16 *stage, Fn between) {
     const __bf16 *sX = stage;
     const __bf16 *sW = stage + BX * BKH * PL;
     const int r31 = lane & 31, h = lane >> 5;
@@ -122,8 +126,12 @@ struct EngineH {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[1][j], acc[i][j], 0, 0, 0);
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], acc[i][j], 0, 0, 0);
+          between(s * TW * TX + i * TX + j);
         }
     }
+  }
+  __device__ __forceinline__ void compute(const __bf16 *stage) {
+    compute(stage, [](int) {});
   }
 
   // epilogue coordinates: register group g (0..3) of tile (i, j) holds C[m][n .. n+3]

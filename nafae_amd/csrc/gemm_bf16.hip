@@ -9,6 +9,7 @@
 // detector's `precision` switch (nafae_amd/detector.py).
 #include "bf16_tile.h"
 #include "mfma_tile.h"  // tile_coords
+#include <stdlib.h>
 #include "../../include/nafae_hip.h"
 
 using namespace nafae;
@@ -202,6 +203,133 @@ __global__ __launch_bounds__(NT16) void conv3x3_bf16_kernel(const __bf16 *__rest
   epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-DMA pipeline
+// Same tile engine, but operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR round trip) through a
+// 3-stage LDS ring with TWO k-tiles in flight.  At the bf16x3 MFMA rate a k-tile is ~1.5k cycles of matrix work per
+// SIMD, less than one L2/HBM round trip under load, so the one-tile-ahead register pipeline above is latency bound;
+// this one waits with a counted s_waitcnt vmcnt(NCH) (tile kt landed, tile kt+1 still in flight) and a raw s_barrier
+// (a __syncthreads() would drain the DMA queue: cdna_hip_programming.md, "Pipelining across barriers").
+// The LDS destination of an LDS-DMA is wave-linear, so the XOR swizzle is applied on the per-lane SOURCE address and
+// undone by the swizzled fragment read.  Zero fill (ragged rows, K tail, conv halo) comes from a zero page.
+__device__ __attribute__((aligned(64))) const unsigned int nafae_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV>
+__global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo, int ldx,
+                                                        const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo, int ldw,
+                                                        float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                                                        __bf16 *__restrict__ Clo, int ldc, const float *__restrict__ bias,
+                                                        int M, int N, int K, float alpha, int act, int tiles_m, int tiles_n,
+                                                        int H, int W, int Cin) {
+  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  static_assert(E::CHUNKS % NT16 == 0, "LDS-DMA path needs every lane active in every staging instruction");
+  constexpr int NST = 3;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BX, n0 = tn * BW;
+  const int cpt = CONV ? Cin / BKH : 1;
+  const int nk = CONV ? 9 * cpt : (K + BKH - 1) / BKH;
+  const __bf16 *zero = reinterpret_cast<const __bf16 *>(nafae_zero_page);
+
+  const __bf16 *gp[E::NCH];
+  bool ok[E::NCH], isw[E::NCH];
+  int kslot[E::NCH], py[E::NCH], px[E::NCH];
+#pragma unroll
+  for (int i = 0; i < E::NCH; i++) {
+    const int id = threadIdx.x + NT16 * i;
+    const int q = id & 3;  // physical 16-byte slot inside the row == where this lane's bytes land
+    int rowg = id >> 2;
+    isw[i] = id >= E::XCH;
+    int plane, row;
+    if (!isw[i]) {
+      plane = rowg / BX;
+      row = rowg - plane * BX;
+    } else {
+      rowg -= BX * E::PL;
+      plane = rowg / BW;
+      row = rowg - plane * BW;
+    }
+    const int slot = q ^ ((row >> 2) & 3);  // logical k-slot this lane must fetch (inverse swizzle on the source)
+    const bool dbg_zero = act == -1;        // timing experiment only (act = -1): every staging load hits the zero page
+    kslot[i] = slot * 8;
+    px[i] = py[i] = 0;
+    if (!isw[i]) {
+      const int m = m0 + row;
+      ok[i] = m < M && !dbg_zero;
+      const int mm = ok[i] ? m : 0;
+      if (CONV) {
+        px[i] = mm % W;
+        py[i] = (mm / W) % H;
+      }
+      gp[i] = (plane ? Xlo : Xhi) + (size_t)mm * ldx + slot * 8;
+    } else {
+      const int n = n0 + row;
+      ok[i] = n < N && !dbg_zero;
+      gp[i] = (plane ? Wlo : Whi) + (size_t)(ok[i] ? n : 0) * ldw + slot * 8;
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+  // one staging instruction (chunk i of k-tile kt -> LDS stage `stage`)
+  const bool dbg_l2 = act == -2;            // timing experiment only: re-read the first 4 k-tiles (everything L2-resident)
+  auto issue_one = [&](int i, int kt, int stage) {
+    if (dbg_l2) kt &= 3;
+    int aoff = kt * BKH, dy = 0, dx = 0;
+    if (CONV) {
+      const int tap = kt / cpt;
+      const int cc = kt - tap * cpt;
+      dy = tap / 3 - 1;
+      dx = tap - (tap / 3) * 3 - 1;
+      aoff = (dy * W + dx) * Cin + cc * BKH;
+    }
+    char *sbase = reinterpret_cast<char *>(smem16) + (size_t)stage * E::STAGE * sizeof(__bf16);
+    bool v = ok[i];
+    const __bf16 *src;
+    if (CONV && !isw[i]) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      v = v && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      src = gp[i] + aoff;
+    } else {
+      if (!CONV) v = v && (kt * BKH + kslot[i] < K);
+      src = gp[i] + kt * BKH;
+    }
+    if (!v) src = zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(sbase + (NT16 * i + wave * 64) * 16), 16, 0, 0);
+  };
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < E::NCH; i++) issue_one(i, kt, stage);
+  };
+  constexpr int NGRP = 2 * E::TW * E::TX;  // accumulator-tile groups per k-tile
+
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk)
+      wait_vmcnt<E::NCH>();  // tile kt has landed; tile kt+1 may still be in flight
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's share of tile kt is in LDS, and everyone is done reading stage (kt-1)%3
+    const bool more = kt + 2 < nk;
+    const int nstage = (kt + 2) % NST;
+    if (E::NCH > NGRP && more) {  // more staging instructions than MFMA groups: the surplus goes first
+#pragma unroll
+      for (int i = NGRP; i < E::NCH; i++) issue_one(i, kt + 2, nstage);
+    }
+    e.compute(smem16 + (size_t)(kt % NST) * E::STAGE, [&](int g) {
+      if (g < E::NCH && g < NGRP && more) issue_one(g, kt + 2, nstage);
+    });
+  }
+  epilogue<E, SPLIT>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
+}
+
 // ------------------------------------------------------------------------------------------------ plane helpers
 __global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ in, __bf16 *__restrict__ hi,
                                                     __bf16 *__restrict__ lo, long n4) {
@@ -367,6 +495,35 @@ int launch_conv(const void *Xhi, const void *Xlo, const void *Whi, const void *W
   return launched();
 }
 
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV>
+int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const void *Wlo, int ldw, float *Cf, void *Chi,
+               void *Clo, int ldc, const float *bias, int M, int N, int K, float alpha, int act, int H, int W, int Cin,
+               hipStream_t st) {
+  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
+  const size_t lds = 3 * E::STAGE * sizeof(__bf16);
+  auto kern = bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV>;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, ldx,
+                     (const __bf16 *)Whi, (const __bf16 *)Wlo, ldw, Cf, (__bf16 *)Chi, (__bf16 *)Clo, ldc, bias, M, N, K, alpha,
+                     act, tiles_m, tiles_n, H, W, Cin);
+  return launched();
+}
+
+// A/B switch for the staging pipeline: NAFAE_BF16_PIPE=reg selects the register-staged kernels
+inline bool use_dma() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("NAFAE_BF16_PIPE");
+    v = (e && e[0] == 'r') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -394,9 +551,16 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                        void *stream) {
   if (!X_hi || !W_hi || (!C_f32 && !C_hi) || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((K & 7) || (ldx & 7) || (ldw & 7) || (N & 3) || (ldc & 3) || !al16(X_hi) || !al16(W_hi)) return NAFAE_EINVAL;
-  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU) return NAFAE_EINVAL;
+  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && act != -1 && act != -2) return NAFAE_EINVAL;   // < 0: timing experiments
   const bool split = X_lo && W_lo;
   if (!split && (X_lo || W_lo)) return NAFAE_EINVAL;
+  if (use_dma()) {
+    if (split)
+      return launch_dma<256, 128, 4, 2, true, false>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha,
+                                                     act, 0, 0, 0, S(stream));
+    return launch_dma<256, 128, 4, 2, false, false>(X_hi, nullptr, ldx, W_hi, nullptr, ldw, C_f32, C_hi, nullptr, ldc, bias, M, N, K,
+                                                    alpha, act, 0, 0, 0, S(stream));
+  }
   if (split)
     return launch_gemm<256, 128, 4, 2, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha, act,
                                              S(stream));
@@ -412,6 +576,20 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
   if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
   const bool split = in_lo && w_lo;
   if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
+  if (use_dma()) {
+    const int M = F * H * W, K9 = 9 * Cin, act = relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE;
+    if (Cout <= 64 && split)
+      return launch_dma<256, 64, 8, 1, true, true>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M, Cout,
+                                                   K9, 1.0f, act, H, W, Cin, S(stream));
+    if (Cout > 64) {
+      if (split)
+        return launch_dma<256, 128, 4, 2, true, true>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M,
+                                                      Cout, K9, 1.0f, act, H, W, Cin, S(stream));
+      return launch_dma<256, 128, 4, 2, false, true>(in_hi, nullptr, Cin, w_hi, nullptr, K9, out_f32, out_hi, nullptr, Cout, bias, M,
+                                                     Cout, K9, 1.0f, act, H, W, Cin, S(stream));
+    }
+    // Cout <= 64 in plain bf16: 1280 chunks do not fill 512 lanes evenly -> register-staged kernel below
+  }
   if (Cout <= 64) {
     if (split)
       return launch_conv<256, 64, 8, 1, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,

@@ -308,10 +308,11 @@ __global__ __launch_bounds__(256) void roi_align_avg_nhwc_kernel(const float *__
   }
 }
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
 // Same fused RoIAlignAvg on bf16 planes (hi [, lo]): feature value = hi + lo (split-bf16), output re-split.
-__global__ __launch_bounds__(256) void roi_align_avg_nhwc_bf16_kernel(const __bf16 *__restrict__ fhi,
+// 128 threads per ROI, 4 adjacent channels per thread (8-byte plane loads / stores).
+__global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf16 *__restrict__ fhi,
                                                                       const __bf16 *__restrict__ flo, int H, int W, int C,
                                                                       const float *__restrict__ rois, float scale,
                                                                       __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo) {
@@ -335,39 +336,47 @@ __global__ __launch_bounds__(256) void roi_align_avg_nhwc_bf16_kernel(const __bf
   __syncthreads();
   const long img = (long)g.img * H * W * C;
   const long ob = (long)n * PS * PS * C;
-  auto ld = [&](long off, int q) -> float {
-    float v = (float)fhi[off + q];
-    if (flo) v += (float)flo[off + q];
+  auto ld4 = [&](long off) -> f32x4 {
+    const bf16x4_t h = *reinterpret_cast<const bf16x4_t *>(fhi + off);
+    f32x4 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    if (flo) {
+      const bf16x4_t l = *reinterpret_cast<const bf16x4_t *>(flo + off);
+      v[0] += (float)l[0];
+      v[1] += (float)l[1];
+      v[2] += (float)l[2];
+      v[3] += (float)l[3];
+    }
     return v;
   };
-  for (int c = threadIdx.x * 2; c < C; c += 512) {
-    f32x2 prev[AS], cur[AS];
+  for (int c = threadIdx.x * 4; c < C; c += 512) {
+    f32x4 prev[AS], cur[AS];
 #pragma unroll
     for (int ph = 0; ph < AS; ph++) {
 #pragma unroll
       for (int pw = 0; pw < AS; pw++) {
-        f32x2 v = {0.f, 0.f};
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (s_hv[ph] && s_wv[pw]) {
           const long p = img + ((long)s_hs[ph] * W + s_ws[pw]) * C + c;
-          const long r = (long)C, d = (long)W * C;
-          v[0] = bilerp(ld(p, 0), ld(p + r, 0), ld(p + d, 0), ld(p + d + r, 0), s_hr[ph], s_wr[pw]);
-          v[1] = bilerp(ld(p, 1), ld(p + r, 1), ld(p + d, 1), ld(p + d + r, 1), s_hr[ph], s_wr[pw]);
+          const f32x4 ul = ld4(p), ur = ld4(p + C), dl = ld4(p + (long)W * C), dr = ld4(p + (long)W * C + C);
+#pragma unroll
+          for (int q = 0; q < 4; q++) v[q] = bilerp(ul[q], ur[q], dl[q], dr[q], s_hr[ph], s_wr[pw]);
         }
         cur[pw] = v;
       }
       if (ph > 0) {
 #pragma unroll
         for (int pw = 0; pw < PS; pw++) {
-          const float s0 = (((prev[pw][0] + prev[pw + 1][0]) + cur[pw][0]) + cur[pw + 1][0]) / 4.0f;
-          const float s1 = (((prev[pw][1] + prev[pw + 1][1]) + cur[pw][1]) + cur[pw + 1][1]) / 4.0f;
-          const long o = ob + ((ph - 1) * PS + pw) * (long)C + c;
-          const __bf16 h0 = (__bf16)s0, h1 = (__bf16)s1;
-          bf16x2_t hv = {h0, h1};
-          *reinterpret_cast<bf16x2_t *>(ohi + o) = hv;
-          if (olo) {
-            bf16x2_t lv = {(__bf16)(s0 - (float)h0), (__bf16)(s1 - (float)h1)};
-            *reinterpret_cast<bf16x2_t *>(olo + o) = lv;
+          bf16x4_t hv, lv;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float sv = (((prev[pw][q] + prev[pw + 1][q]) + cur[pw][q]) + cur[pw + 1][q]) / 4.0f;
+            const __bf16 hq = (__bf16)sv;
+            hv[q] = hq;
+            lv[q] = (__bf16)(sv - (float)hq);
           }
+          const long o = ob + ((ph - 1) * PS + pw) * (long)C + c;
+          *reinterpret_cast<bf16x4_t *>(ohi + o) = hv;
+          if (olo) *reinterpret_cast<bf16x4_t *>(olo + o) = lv;
         }
       }
 #pragma unroll
@@ -461,9 +470,9 @@ int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, cons
 int nafae_roi_align_avg_nhwc_bf16(const void *feat_hi, const void *feat_lo, int F, int H, int W, int C, const float *rois,
                                   int N, float spatial_scale, void *out_hi, void *out_lo, void *stream) {
   if (!feat_hi || !rois || !out_hi || F <= 0 || H < 2 || W < 2 || C <= 0 || N <= 0) return NAFAE_EINVAL;
-  if (C & 1) return NAFAE_EINVAL;
+  if (C & 3) return NAFAE_EINVAL;
   if ((feat_lo == nullptr) != (out_lo == nullptr)) return NAFAE_EINVAL;
-  hipLaunchKernelGGL(roi_align_avg_nhwc_bf16_kernel, dim3(N), dim3(256), 0, S(stream), (const __bf16 *)feat_hi,
+  hipLaunchKernelGGL(roi_align_avg_nhwc_bf16_kernel, dim3(N), dim3(128), 0, S(stream), (const __bf16 *)feat_hi,
                      (const __bf16 *)feat_lo, H, W, C, rois, spatial_scale, (__bf16 *)out_hi, (__bf16 *)out_lo);
   return launched();
 }

@@ -69,25 +69,36 @@ def test_embed_and_dvsa_modules_match_reference(gpu):
     assert abs(float(L) - float(g["loss_eval"])) < TOL * abs(float(g["loss_eval"]))
 
 
-def _detector(seed, device="cuda"):
+PRECISIONS = ["bf16x3", "f32"]      # both must meet the 1e-4 fp32 bar (plain bf16: tests/test_gpu_bf16.py)
+
+
+def _detector(seed, precision, device="cuda"):
     from nafae_amd import synthetic as syn
     from nafae_amd.detector import vgg16
     fr = vgg16(np.array([''] * 2501), pretrained=False, class_agnostic=False)
     fr.create_architecture()
     fr.load_state_dict(syn.detector_state(seed=seed, heads=False), strict=False)
+    fr.precision = precision
     return fr.eval().to(device)
 
 
-def test_detector_matches_reference_golden(gpu):
+def _base_nhwc_f32(fr, im):
+    from nafae_amd import ops
+    b = fr.base_features(im)
+    return ops.merge_bf16(b) if isinstance(b, ops.Planes) else b
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_detector_matches_reference_golden(gpu, precision):
     """fasterRCNN.forward against the reference's own forward on 2 small frames (tests/golden/detector.npz)."""
     from nafae_amd import synthetic as syn
     from oracle import detector as OD
     g = np.load(os.path.join(G, "detector.npz"))
     gpu.TEST.RPN_POST_NMS_TOP_N = int(g["post_nms_topN"])
-    fr = _detector(int(g["seed"]))
+    fr = _detector(int(g["seed"]), precision)
     h, w = [int(x) for x in g["frames_hw"]]
     im, im_info = syn.frames(2, h, w, seed=int(g["seed"]))
-    base = fr.base_features(im.cuda())
+    base = _base_nhwc_f32(fr, im.cuda())
     assert relerr(base.permute(0, 3, 1, 2).cpu(), g["base_feat"]) < TOL
     rois, roi_scores, pooled, fc7 = fr(im.cuda(), im_info.cuda(), None, None)
     assert tuple(pooled.shape) == (16, 512, 7, 7) and tuple(fc7.shape) == (16, 4096)
@@ -106,18 +117,19 @@ def test_detector_matches_reference_golden(gpu):
     assert ((rois.cpu() - r_o).abs().max(-1)[0] < 1e-3).float().mean() >= 0.9
     # ROI-Align + head fed with the HIP rois
     pooled_o = OD.roi_align_avg(base.permute(0, 3, 1, 2).cpu().contiguous(), rois.cpu().view(-1, 5))
-    assert relerr(pooled.cpu(), pooled_o) < 1e-5
+    assert relerr(pooled.cpu(), pooled_o) < 2e-5
     assert relerr(fc7.cpu(), OD.head_to_tail(pooled_o, sd)) < TOL
     # _head_to_tail on the logical NCHW view gives the same fc7 (vgg16_rpn.py:56-61 signature)
-    assert relerr(fr._head_to_tail(pooled).cpu(), fc7.cpu()) < 1e-6
+    assert relerr(fr._head_to_tail(pooled).cpu(), fc7.cpu()) < 1e-5
 
 
-def test_detector_config_c1_against_oracle(gpu):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_detector_config_c1_against_oracle(gpu, precision):
     """BASELINE config C1: 4 frames 224x224, 32 proposals/frame; whole detector vs the CPU oracle."""
     from nafae_amd import synthetic as syn
     from oracle import detector as OD
     gpu.TEST.RPN_POST_NMS_TOP_N = 32
-    fr = _detector(1234)
+    fr = _detector(1234, precision)
     im, im_info = syn.frames(4, 224, 224, seed=1234)
     rois, roi_scores, pooled, fc7 = fr(im.cuda(), im_info.cuda(), None, None)
     sd = syn.detector_state(seed=1234, heads=False)
