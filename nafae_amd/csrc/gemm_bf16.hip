@@ -218,7 +218,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV>
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST>
 __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo, int ldx,
                                                         const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo, int ldw,
                                                         float *__restrict__ Cf, __bf16 *__restrict__ Chi,
@@ -227,7 +227,8 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
                                                         int H, int W, int Cin) {
   using E = EngineH<BX, BW, WX, WW, SPLIT>;
   static_assert(E::CHUNKS % NT16 == 0, "LDS-DMA path needs every lane active in every staging instruction");
-  constexpr int NST = 3;
+  static_assert(NST == 2 || NST == 3, "ring of 2 or 3 LDS stages");
+  constexpr int DIST = NST - 1;  // k-tiles in flight ahead of the one being computed
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   E e;
   e.init();
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
 
   const __bf16 *gp[E::NCH];
   bool ok[E::NCH], isw[E::NCH];
-  int kslot[E::NCH], py[E::NCH], px[E::NCH];
+  int kslot[E::NCH];
+  unsigned tapmask[E::NCH];  // CONV: bit t set <=> tap t of this lane's pixel lies inside the image
 #pragma unroll
   for (int i = 0; i < E::NCH; i++) {
     const int id = threadIdx.x + NT16 * i;
@@ -259,14 +261,20 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
     const int slot = q ^ ((row >> 2) & 3);  // logical k-slot this lane must fetch (inverse swizzle on the source)
     const bool dbg_zero = act == -1;        // timing experiment only (act = -1): every staging load hits the zero page
     kslot[i] = slot * 8;
-    px[i] = py[i] = 0;
+    tapmask[i] = 0x1ffu;
     if (!isw[i]) {
       const int m = m0 + row;
       ok[i] = m < M && !dbg_zero;
       const int mm = ok[i] ? m : 0;
       if (CONV) {
-        px[i] = mm % W;
-        py[i] = (mm / W) % H;
+        const int x = mm % W, y = (mm / W) % H;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+          const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
+        }
+        tapmask[i] = mk;
       }
       gp[i] = (plane ? Xlo : Xhi) + (size_t)mm * ldx + slot * 8;
     } else {
@@ -278,26 +286,25 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
   const int wave = threadIdx.x >> 6;
   // one staging instruction (chunk i of k-tile kt -> LDS stage `stage`)
   const bool dbg_l2 = act == -2;            // timing experiment only: re-read the first 4 k-tiles (everything L2-resident)
+  const int kstep = (act == -3) ? 2 * BKH : BKH;  // timing experiment only (act = -3): hi/lo interleaved per 32-k piece
   auto issue_one = [&](int i, int kt, int stage) {
     if (dbg_l2) kt &= 3;
-    int aoff = kt * BKH, dy = 0, dx = 0;
+    int aoff = kt * BKH, tap = 0;
     if (CONV) {
-      const int tap = kt / cpt;
+      tap = kt / cpt;
       const int cc = kt - tap * cpt;
-      dy = tap / 3 - 1;
-      dx = tap - (tap / 3) * 3 - 1;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
       aoff = (dy * W + dx) * Cin + cc * BKH;
     }
     char *sbase = reinterpret_cast<char *>(smem16) + (size_t)stage * E::STAGE * sizeof(__bf16);
     bool v = ok[i];
     const __bf16 *src;
     if (CONV && !isw[i]) {
-      const int yy = py[i] + dy, xx = px[i] + dx;
-      v = v && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      v = v && ((tapmask[i] >> tap) & 1u);
       src = gp[i] + aoff;
     } else {
       if (!CONV) v = v && (kt * BKH + kslot[i] < K);
-      src = gp[i] + kt * BKH;
+      src = gp[i] + kt * kstep;
     }
     if (!v) src = zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -310,21 +317,21 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
   constexpr int NGRP = 2 * E::TW * E::TX;  // accumulator-tile groups per k-tile
 
   issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  if (DIST > 1 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk)
-      wait_vmcnt<E::NCH>();  // tile kt has landed; tile kt+1 may still be in flight
+    if (DIST > 1 && kt + 1 < nk)
+      wait_vmcnt<(DIST - 1) * E::NCH>();  // tile kt has landed; the younger tile(s) may still be in flight
     else
       wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // everyone's share of tile kt is in LDS, and everyone is done reading stage (kt-1)%3
-    const bool more = kt + 2 < nk;
-    const int nstage = (kt + 2) % NST;
+    __builtin_amdgcn_s_barrier();  // everyone's share of tile kt is in LDS, and everyone is done reading stage (kt-1)%NST
+    const bool more = kt + DIST < nk;
+    const int nstage = (kt + DIST) % NST;
     if (E::NCH > NGRP && more) {  // more staging instructions than MFMA groups: the surplus goes first
 #pragma unroll
-      for (int i = NGRP; i < E::NCH; i++) issue_one(i, kt + 2, nstage);
+      for (int i = NGRP; i < E::NCH; i++) issue_one(i, kt + DIST, nstage);
     }
     e.compute(smem16 + (size_t)(kt % NST) * E::STAGE, [&](int g) {
-      if (g < E::NCH && g < NGRP && more) issue_one(g, kt + 2, nstage);
+      if (g < E::NCH && g < NGRP && more) issue_one(g, kt + DIST, nstage);
     });
   }
   epilogue<E, SPLIT>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
@@ -495,14 +502,14 @@ int launch_conv(const void *Xhi, const void *Xlo, const void *Whi, const void *W
   return launched();
 }
 
-template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV>
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST = 3>
 int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const void *Wlo, int ldw, float *Cf, void *Chi,
                void *Clo, int ldc, const float *bias, int M, int N, int K, float alpha, int act, int H, int W, int Cin,
                hipStream_t st) {
   using E = EngineH<BX, BW, WX, WW, SPLIT>;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
-  const size_t lds = 3 * E::STAGE * sizeof(__bf16);
-  auto kern = bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV>;
+  const size_t lds = NST * E::STAGE * sizeof(__bf16);
+  auto kern = bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -551,10 +558,18 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                        void *stream) {
   if (!X_hi || !W_hi || (!C_f32 && !C_hi) || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((K & 7) || (ldx & 7) || (ldw & 7) || (N & 3) || (ldc & 3) || !al16(X_hi) || !al16(W_hi)) return NAFAE_EINVAL;
-  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && act != -1 && act != -2) return NAFAE_EINVAL;   // < 0: timing experiments
+  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && (act > 0 || act < -3)) return NAFAE_EINVAL;   // < 0: timing experiments
   const bool split = X_lo && W_lo;
   if (!split && (X_lo || W_lo)) return NAFAE_EINVAL;
   if (use_dma()) {
+    static int big = -1;  // NAFAE_BF16_TILE=128 forces the 256x128 tile (A/B experiments)
+    if (big < 0) {
+      const char *e = getenv("NAFAE_BF16_TILE");
+      big = (e && atoi(e) == 128) ? 0 : 1;
+    }
+    if (split && big && M >= 256 && N >= 256)  // 256x256 tile, 2-stage ring: 21 B/clk/CU of staging instead of 31
+      return launch_dma<256, 256, 2, 4, true, false, 2>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K,
+                                                        alpha, act, 0, 0, 0, S(stream));
     if (split)
       return launch_dma<256, 128, 4, 2, true, false>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha,
                                                      act, 0, 0, 0, S(stream));
@@ -581,6 +596,9 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
     if (Cout <= 64 && split)
       return launch_dma<256, 64, 8, 1, true, true>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M, Cout,
                                                    K9, 1.0f, act, H, W, Cin, S(stream));
+    if (Cout >= 256 && split && M >= 256 * 256)  // wide layers with enough pixels to fill the chip: 256x256 tile, 2-stage ring
+      return launch_dma<256, 256, 2, 4, true, true, 2>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M,
+                                                       Cout, K9, 1.0f, act, H, W, Cin, S(stream));
     if (Cout > 64) {
       if (split)
         return launch_dma<256, 128, 4, 2, true, true>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M,
