@@ -596,7 +596,7 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
     if (Cout <= 64 && split)
       return launch_dma<256, 64, 8, 1, true, true>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M, Cout,
                                                    K9, 1.0f, act, H, W, Cin, S(stream));
-    if (Cout >= 256 && split && M >= 256 * 256)  // wide layers with enough pixels to fill the chip: 256x256 tile, 2-stage ring
+    if (Cout >= 256 && split && M >= 256 * 128)  // wide layers with enough pixels to fill the chip: 256x256 tile, 2-stage ring
       return launch_dma<256, 256, 2, 4, true, true, 2>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M,
                                                        Cout, K9, 1.0f, act, H, W, Cin, S(stream));
     if (Cout > 64) {

@@ -1,3 +1,4 @@
+"""Launches the dominant bf16x3 kernels alone at BASELINE C2 shapes (for rocprofv3 --pmc passes)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from nafae_amd import ops
