@@ -337,6 +337,182 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
   epilogue<E, SPLIT>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
 }
 
+// ------------------------------------------------------------------------------------------------ run-reuse conv
+// 3x3 conv whose activation side is staged ONCE PER ROW OFFSET instead of once per tap.  A tile is 256 consecutive
+// pixels p0.. in raster order; for a fixed dy the three taps dx = -1, 0, +1 read the pixel run
+// [p0 + dy*W - 1, p0 + dy*W + 256], so one 320-row LDS image of that run (pixels p0 + dy*W - 32 ...) serves all three
+// taps through fragment reads shifted by one row.  L2 -> LDS traffic of the activation side drops 3x (it was the
+// dominant term: the per-CU L2 -> LDS path, not the matrix pipe, bounds these kernels -- DESIGN.md section 4).
+// Raster runs wrap around image rows and images, so the conv padding is applied to the B-operand FRAGMENTS: a 9-bit
+// per-lane mask says which taps of that lane's output pixel fall inside the image; the others are zeroed in registers.
+// Weights stream per tap through their own LDS ring exactly as in bf16_dma_kernel.  Step order: channel chunk (32) ->
+// dy -> dx; one raw barrier and one counted vmcnt wait per step.
+template <int BW, int WX, int WW, int NSTW>
+__global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
+                                                           const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+                                                           const float *__restrict__ bias, float *__restrict__ Cf,
+                                                           __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
+                                                           int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
+  constexpr int BX = 256, RR = 320, ROFF = 32, PL = 2;
+  using E = EngineH<BX, BW, WX, WW, true>;
+  constexpr int TX = E::TX, TW = E::TW;
+  constexpr int XRUN = RR * BKH * PL;   // bf16 elements per activation-run buffer
+  constexpr int WST = BW * BKH * PL;    // bf16 elements per weight stage
+  constexpr int NXC = RR * 4 * PL / NT16;
+  constexpr int NWC = BW * 4 * PL / NT16;
+  static_assert(RR * 4 * PL % NT16 == 0 && BW * 4 * PL % NT16 == 0, "every lane active in every staging instruction");
+  constexpr int DIST = NSTW - 1;
+  static_assert(NSTW == 2 || NSTW == 3, "weight ring of 2 or 3 stages");
+  constexpr int NGRP = 2 * TW * TX;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  __bf16 *xbuf = smem16;
+  __bf16 *wbuf = smem16 + 2 * XRUN;
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int M = F * H * W;
+  const int m0 = tm * BX, n0 = tn * BW;
+  const int cpt = Cin / BKH;
+  const int nst = 9 * cpt, ngrp = 3 * cpt;
+  const int K9 = 9 * Cin;
+  const __bf16 *zero = reinterpret_cast<const __bf16 *>(nafae_zero_page);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  // activation-run chunks of this lane: run row -> pixel (p0 - ROFF + row) + dy*W
+  const __bf16 *xp[NXC];
+  int xpix[NXC];
+#pragma unroll
+  for (int i = 0; i < NXC; i++) {
+    const int id = threadIdx.x + NT16 * i;
+    const int q = id & 3, rowg = id >> 2;
+    const int plane = rowg / RR, row = rowg - plane * RR;
+    const int slot = q ^ ((row >> 2) & 3);
+    xpix[i] = m0 - ROFF + row;
+    xp[i] = (plane ? Xlo : Xhi) + slot * 8;
+  }
+  const __bf16 *wp[NWC];
+  bool wok[NWC];
+#pragma unroll
+  for (int i = 0; i < NWC; i++) {
+    const int id = threadIdx.x + NT16 * i;
+    const int q = id & 3, rowg = id >> 2;
+    const int plane = rowg / BW, row = rowg - plane * BW;
+    const int slot = q ^ ((row >> 2) & 3);
+    const int n = n0 + row;
+    wok[i] = n < Cout;
+    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 + slot * 8;
+  }
+  // which taps of this lane's output pixels are inside the image
+  unsigned tapmask[TX];
+#pragma unroll
+  for (int j = 0; j < TX; j++) {
+    const int m = m0 + e.out_m(j);
+    unsigned mk = 0;
+    if (m < M) {
+      const int x = m % W, y = (m / W) % H;
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
+      }
+    }
+    tapmask[j] = mk;
+  }
+
+  auto issue_x = [&](int i, int grp) {  // chunk i of the run for group grp = (cc, dy)
+    const int cc = grp / 3, dy = grp - cc * 3 - 1;
+    const long pix = (long)xpix[i] + (long)dy * W;
+    const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * Cin + cc * BKH : zero;
+    char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  };
+  auto issue_w = [&](int i, int st) {  // chunk i of the weight tile for step st = (cc, tap)
+    const int cc = st / 9, tap = st - cc * 9;
+    const __bf16 *src = wok[i] ? wp[i] + tap * Cin + cc * BKH : zero;
+    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  };
+
+  // prologue: run 0, then the first DIST weight tiles
+#pragma unroll
+  for (int i = 0; i < NXC; i++) issue_x(i, 0);
+#pragma unroll
+  for (int d = 0; d < DIST; d++)
+    if (d < nst) {
+#pragma unroll
+      for (int i = 0; i < NWC; i++) issue_w(i, d);
+    }
+
+  const int r31 = lane & 31, hh = lane >> 5;
+  for (int st = 0; st < nst; st++) {
+    // everything issued after W(st) may stay in flight: that is what step st-1 issued (only when DIST == 2)
+    if (DIST == 1 || st + 1 >= nst) {
+      wait_vmcnt<0>();
+    } else {
+      const int sp = st - 1;
+      const bool run_prev = sp >= 0 && (sp % 3 == 0) && (sp / 3 + 1 < ngrp);
+      if (run_prev)
+        wait_vmcnt<NWC + NXC>();
+      else
+        wait_vmcnt<NWC>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const int grp = st / 3;
+    const int tap = st - (st / 9) * 9;
+    const int dx = tap - (tap / 3) * 3 - 1;
+    const bool do_x = (st % 3 == 0) && (grp + 1 < ngrp);
+    const bool do_w = st + DIST < nst;
+    // staging instructions of this step, handed out between MFMA groups: first the next run, then the next weight tile
+    auto between = [&](int g) {
+      if (g < NXC) {
+        if (do_x) issue_x(g, grp + 1);
+      } else if (g - NXC < NWC) {
+        if (do_w) issue_w(g - NXC, st + DIST);
+      }
+    };
+    if (NXC + NWC > NGRP) {
+#pragma unroll
+      for (int g = NGRP; g < NXC + NWC; g++) between(g);
+    }
+    const __bf16 *sX = xbuf + (size_t)(grp & 1) * XRUN;
+    const __bf16 *sW = wbuf + (size_t)(st % NSTW) * WST;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf16x8 xa[PL][TX], wa[PL][TW];
+#pragma unroll
+      for (int j = 0; j < TX; j++) {
+        const int rrow = e.wx * (TX * 32) + j * 32 + r31 + ROFF + dx;
+        const bool on = (tapmask[j] >> tap) & 1u;
+#pragma unroll
+        for (int p = 0; p < PL; p++) {
+          bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[p * RR * BKH + lds_off16(rrow, 2 * s + hh)]);
+          const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          xa[p][j] = on ? v : z;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PL; p++)
+#pragma unroll
+        for (int i = 0; i < TW; i++)
+          wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[p * BW * BKH + lds_off16(e.ww * (TW * 32) + i * 32 + r31, 2 * s + hh)]);
+#pragma unroll
+      for (int i = 0; i < TW; i++)
+#pragma unroll
+        for (int j = 0; j < TX; j++) {
+          e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xa[0][j], e.acc[i][j], 0, 0, 0);
+          e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[1][j], e.acc[i][j], 0, 0, 0);
+          e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], e.acc[i][j], 0, 0, 0);
+          const int g = s * TW * TX + i * TX + j;
+          if (g < NGRP) between(g);
+        }
+    }
+  }
+  epilogue<E, true>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+}
+
 // ------------------------------------------------------------------------------------------------ plane helpers
 __global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ in, __bf16 *__restrict__ hi,
                                                     __bf16 *__restrict__ lo, long n4) {
@@ -521,7 +697,34 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   return launched();
 }
 
-// A/B switch for the staging pipeline: NAFAE_BF16_PIPE=reg selects the register-staged kernels
+template <int BW, int WX, int WW, int NSTW>
+int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
+                    void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+  const int M = F * H * W;
+  const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
+  const size_t lds = (size_t)(2 * 320 * BKH * 2 + NSTW * BW * BKH * 2) * sizeof(__bf16);
+  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW>;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo,
+                     (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu,
+                     tiles_m, tiles_n);
+  return launched();
+}
+
+// A/B switches: NAFAE_BF16_PIPE=reg selects the register-staged kernels; NAFAE_CONV_RUN=0 disables the run-reuse conv
+inline bool use_run() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("NAFAE_CONV_RUN");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 inline bool use_dma() {
   static int v = -1;
   if (v < 0) {
@@ -591,6 +794,15 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
   if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
   const bool split = in_lo && w_lo;
   if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
+  if (use_dma() && split && use_run()) {
+    const int M = F * H * W;
+    if (Cout <= 64)
+      return launch_conv_run<64, 8, 1, 3>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+    if (Cout >= 256 && M >= 256 * 128)
+      return launch_conv_run<256, 2, 4, 2>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                           S(stream));
+    return launch_conv_run<128, 4, 2, 3>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+  }
   if (use_dma()) {
     const int M = F * H * W, K9 = 9 * Cin, act = relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE;
     if (Cout <= 64 && split)
