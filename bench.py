@@ -167,7 +167,7 @@ def main():
             "config": {"workload": "%s: %d frames 224x224 per GPU (Na=%d,Ns=%d), %d proposals/frame, %d query slots/segment, "
                                    "VGG16 random-init, full train step" % (a.workload.upper(), F, Na, Ns, Nb, Ne),
                        "frames_per_gpu": F, "proposals_per_frame": Nb, "queries_per_segment": Ne,
-                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": reducer.nbytes if reducer else 0},
+                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": reducer.nbytes if distributed else 0},
             "loss": round(float(loss), 5),
         }
         # dominant kernel: fc6 = [R,25088] x [4096,25088]^T on fp32 MFMA

@@ -212,6 +212,14 @@ int nafae_batchnorm_bwd(const float *g_y, const float *x, const float *weight, c
 /* out[j] = sum_i x[i, j]  (bias gradients).  */
 int nafae_colsum(const float *x, float *out, int rows, int cols, void *stream);
 
+/* One optimiser step over a flat fp32 buffer = torch.nn.utils.clip_grad_norm_(params, max_norm) followed by
+ * torch.optim.Adam(lr, betas, eps, weight_decay).step()  (model.py:773-774, :1077-1082), `step` = 1, 2, ...
+ * grads is overwritten with the clipped gradient; workspace: f32[256]; total_norm_out: f32[1] or NULL.
+ * Deterministic (fixed-order reductions).  */
+int nafae_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float max_norm, int step, float *workspace,
+                    float *total_norm_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

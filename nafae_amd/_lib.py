@@ -47,6 +47,7 @@ SIGNATURES = {
     "nafae_batchnorm_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "nafae_batchnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "nafae_colsum": (c_int, [P, P, c_int, c_int, P]),
+    "nafae_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int, P, P, P]),
 }
 
 

@@ -645,9 +645,60 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ optimiser step
+// clip_grad_norm_ + Adam (model.py:773-774, :1077-1082) over ONE flat buffer: pass 1 = per-block sums of squares in
+// a fixed order, pass 2 = every block re-adds the partials in the same order (bit-identical total on all blocks),
+// derives the clip coefficient and applies torch.optim.Adam's update (L2 weight decay folded into the gradient).
+constexpr int ADAM_NB = 256;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ g, long n, float *__restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += g[i] * g[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, long n, float lr, float beta1, float beta2,
+                                                   float eps, float wd, float max_norm, float bc1, float bc2_sqrt,
+                                                   const float *__restrict__ partial, float *__restrict__ norm_out) {
+  float tot = 0.f;
+  for (int k = 0; k < ADAM_NB; k++) tot += partial[k];
+  const float total_norm = sqrtf(tot);
+  float coef = max_norm / (total_norm + 1e-6f);   // torch.nn.utils.clip_grad_norm_
+  coef = coef > 1.0f ? 1.0f : coef;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = total_norm;
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float gi = g[i] * coef;
+    g[i] = gi;                                    // the clipped gradient stays observable, as in the reference
+    const float pi = p[i];
+    gi = gi + wd * pi;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);      // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int nafae_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float max_norm, int step, float *workspace,
+                    float *total_norm_out, void *stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !workspace || n <= 0 || step <= 0) return NAFAE_EINVAL;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(ADAM_NB), dim3(256), 0, S(stream), grads, (long)n, workspace);
+  hipLaunchKernelGGL(adam_kernel, dim3(ADAM_NB), dim3(256), 0, S(stream), params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1,
+                     beta2, eps, weight_decay, max_norm, bc1, bc2_sqrt, workspace, total_norm_out);
+  return launched();
+}
 
 int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, int Na, int Ns, int Nb, int Ne, int D,
                       float *S_max, int64_t *D_ind, void *stream) {

@@ -413,3 +413,14 @@ def colsum(x):
     out = torch.empty(cols, device=x.device, dtype=torch.float32)
     _rc(_lib.lib().nafae_colsum(_p(x), _p(out), rows, cols, _stream()), "nafae_colsum")
     return out
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, max_norm, step, workspace,
+              total_norm_out=None):
+    """clip_grad_norm_ + Adam over flat fp32 buffers (model.py:773-774)."""
+    for t in (params, grads, exp_avg, exp_avg_sq, workspace):
+        _chk(t)
+    _chk(total_norm_out)
+    _rc(_lib.lib().nafae_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), float(lr), float(beta1),
+                                   float(beta2), float(eps), float(weight_decay), float(max_norm), int(step), _p(workspace),
+                                   _p(total_norm_out), _stream()), "nafae_adam_step")

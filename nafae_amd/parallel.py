@@ -54,3 +54,42 @@ def broadcast_parameters(model, src=0, group=None):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+class FusedClipAdam:
+    """The reference's optimiser step -- clip_grad_norm_(all params, clip) then Adam(lr, weight_decay) over
+    DVSA + word_ebd + vis_ebd (model.py:773-774, :1077-1082) -- as ONE pair of HIP launches over flat buffers.
+    Only parameters that ever receive a gradient take part (DVSA's own parameters have grad None in the reference and
+    are skipped by both clip_grad_norm_ and Adam).  Parameters become views of a flat buffer; gradients are the
+    GradAllReducer's flat buffer, so DP needs no extra copies."""
+
+    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=100.0):
+        from . import ops
+        self._ops = ops
+        self.reducer = reducer
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        n = reducer.flat.numel()
+        dev = reducer.flat.device
+        self.flat_params = torch.empty(n, device=dev, dtype=torch.float32)
+        o = 0
+        with torch.no_grad():
+            for p in reducer.params:
+                k = p.numel()
+                self.flat_params[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_params[o:o + k].view_as(p)
+                o += k
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.workspace = torch.zeros(256, device=dev, dtype=torch.float32)
+        self.total_norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.step_count = 0
+        self.param_groups = [{"lr": lr}]          # the reference decays lr by editing param_groups (model.py:1084-1088)
+
+    def zero_grad(self):
+        self.reducer.zero_grad()
+
+    def step(self):
+        self.step_count += 1
+        self._ops.adam_step(self.flat_params, self.reducer.flat, self.exp_avg, self.exp_avg_sq, self.param_groups[0]["lr"],
+                            self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm, self.step_count,
+                            self.workspace, self.total_norm)

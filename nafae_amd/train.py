@@ -6,7 +6,7 @@ import torch
 from . import synthetic as syn
 from .config import cfg
 from .model import GroundModel, default_args
-from .parallel import GradAllReducer, trainable_parameters
+from .parallel import FusedClipAdam, GradAllReducer, trainable_parameters
 
 
 class Batch:
@@ -61,8 +61,11 @@ def train_step(model, optimizer, criterion, batch, args, reducer=None):
     loss.backward()
     if reducer is not None:
         reducer.allreduce()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
-    optimizer.step()
+    if isinstance(optimizer, FusedClipAdam):
+        optimizer.step()                          # clip_grad_norm_ + Adam in one pair of HIP launches
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
+        optimizer.step()
     return loss.detach(), D, D_sim, rois
 
 
@@ -82,7 +85,8 @@ def setup_training(args, device='cuda', seed=1234, distributed=False):
     model.train()
     model.DVSA.init_train()
     model.fasterRCNN.eval()                      # model.py:671-673
-    reducer = GradAllReducer(trainable_parameters(model)) if distributed else None
-    optimizer = make_optimizer(model, args)
+    # gradients always live in one flat buffer (all-reduced when world > 1); the optimiser step is the fused HIP one
+    reducer = GradAllReducer(trainable_parameters(model))
+    optimizer = FusedClipAdam(reducer, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip)
     criterion = torch.nn.L1Loss()
     return model, optimizer, criterion, reducer

@@ -180,3 +180,35 @@ def test_dropout_is_active_in_train_mode_only(gpu):
     assert 0.4 < frac0 < 0.6
     ve.eval()
     assert float((ve(x) == 0).float().mean()) < 0.01
+
+
+def test_fused_clip_adam_matches_torch(gpu):
+    """nafae_adam_step == clip_grad_norm_ + torch.optim.Adam (model.py:773-774, :1077-1082), incl. the clipping branch."""
+    from nafae_amd.parallel import FusedClipAdam, GradAllReducer
+    torch.manual_seed(0)
+    mods = [torch.nn.Linear(40, 24), torch.nn.Linear(12, 24), torch.nn.BatchNorm1d(24)]
+    ref = [torch.nn.Linear(40, 24), torch.nn.Linear(12, 24), torch.nn.BatchNorm1d(24)]
+    for a, b in zip(mods, ref):
+        b.load_state_dict(a.state_dict())
+    mods = [m.cuda() for m in mods]
+    ref = [m.cuda() for m in ref]
+    ps = [p for m in mods for p in m.parameters()]
+    rps = [p for m in ref for p in m.parameters()]
+    red = GradAllReducer(ps)
+    opt = FusedClipAdam(red, lr=1e-3, weight_decay=1e-5, max_norm=5.0)
+    topt = torch.optim.Adam(rps, lr=1e-3, weight_decay=1e-5)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for it in range(4):
+        scale = 10.0 if it % 2 == 0 else 0.01          # alternate clipped / unclipped steps
+        red.zero_grad()
+        for p, rp in zip(ps, rps):
+            gr = torch.randn(p.shape, device="cuda", generator=g) * scale
+            p.grad.copy_(gr)
+            rp.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_(rps, 5.0)
+        topt.step()
+        opt.step()
+        assert abs(float(opt.total_norm) - float(tn)) < 1e-4 * float(tn)
+        for p, rp in zip(ps, rps):
+            assert relerr(p.detach().cpu(), rp.detach().cpu()) < 1e-5
+            assert relerr(p.grad.cpu(), rp.grad.cpu()) < 1e-5
