@@ -90,3 +90,23 @@ def setup_training(args, device='cuda', seed=1234, distributed=False):
     optimizer = FusedClipAdam(reducer, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip)
     criterion = torch.nn.L1Loss()
     return model, optimizer, criterion, reducer
+
+
+def validate_segment(model, batch, vid_entities, img_ids, args, dets):
+    """Body of validate() for one video (model.py:869-947): chunked detector (stepRCNN), embeddings, DVSA in eval mode,
+    postprocess, record_det.  `dets` = [img_inds, obj_labels, obj_bboxes, obj_confs] is appended to in place."""
+    import numpy as np
+    from .evaluate import record_det
+    from .model import postprocess, stepRCNN
+    Nb = cfg.TEST.RPN_POST_NMS_TOP_N
+    Na, Ne = len(batch.entities_length), args.max_ent_len
+    with torch.no_grad():
+        rois, roi_feats, fc_feats = stepRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes, model)
+        vis_feats = model.vis_ebd(fc_feats)
+        word_feats = model.word_ebd(batch.glove_feats)
+        D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
+    Ns = batch.im_data.shape[0] // Na
+    boxes = rois[:, :, 1:5].reshape(-1, 4).cpu().numpy()
+    Dp, Sp = postprocess(D.cpu().numpy(), D_sim.cpu().numpy(), Na, Ns, Nb, Ne)
+    record_det(dets[0], dets[1], dets[2], dets[3], Nb, vid_entities, Dp, Sp, img_ids, boxes)
+    return float(margin_loss)

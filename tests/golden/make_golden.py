@@ -161,6 +161,49 @@ def gold_detector(m):
          pooled_sub=pooled[:, ::37], pooled_sum=pooled.double().sum(), state_keys=np.array(sorted(gm.state_dict().keys())))
 
 
+def gold_eval(m):
+    """record_det (model.py:477-487) + phrase/box accuracy (youcook_eval.py:135-336) on synthetic detections / gt."""
+    import contextlib, io
+    rs = np.random.RandomState(5)
+    classes = ['bowl', 'egg', 'pan', 'oil', 'salt']
+    num_imgs, Nb = 12, 6
+    recs = []
+    for i in range(num_imgs):
+        k = rs.randint(0, 4)
+        xy = rs.rand(k, 2) * 120
+        recs.append({'label': [classes[j] for j in rs.randint(0, 5, k)],
+                     'bbox': np.concatenate([xy, xy + 20 + rs.rand(k, 2) * 80], 1),
+                     'thr': [0.5] * k, 'img_ids': [i] * k})
+    # detections through the reference's record_det: Na=3 segments x Ns=4 frames, entity lists per segment
+    Na, Ns, Ne = 3, 4, 3
+    vid_entities = [['bowl', 'egg'], ['pan'], ['oil', 'salt', 'egg']]
+    D = rs.randint(0, Nb, (Na, Ns, Ne)) + (np.arange(Na)[:, None, None] * Ns * Nb + np.arange(Ns)[None, :, None] * Nb)
+    D_sim = rs.rand(Na, Ns, Ne)
+    img_ids = list(rs.permutation(num_imgs))          # frame ids of the Na*Ns sampled frames (not sorted)
+    bxy = rs.rand(Na * Ns * Nb, 2) * 120
+    infer_boxes = np.concatenate([bxy, bxy + 20 + rs.rand(Na * Ns * Nb, 2) * 80], 1)
+    # make some detections hit a gt box exactly
+    for f in range(0, Na * Ns, 2):
+        rec = recs[img_ids[f]]
+        if len(rec['label']):
+            infer_boxes[f * Nb:(f + 1) * Nb] = rec['bbox'][0] + rs.randn(Nb, 4) * 3
+    dets = [[], [], [], []]
+    m.record_det(dets[0], dets[1], dets[2], dets[3], Nb, vid_entities, D, D_sim, img_ids, infer_boxes)
+    from datasets.youcook_eval import box_accuracy, phrase_accuracy
+    with contextlib.redirect_stdout(io.StringIO()):
+        pa = phrase_accuracy(recs, dets, classes)
+        ba = box_accuracy(recs, dets, classes)
+    rec_lab = np.array(['|'.join(r['label']) for r in recs])
+    rec_box = np.zeros((num_imgs, 3, 4)); rec_n = np.zeros(num_imgs, dtype=int)
+    for i, r in enumerate(recs):
+        rec_n[i] = len(r['label']); rec_box[i, :rec_n[i]] = r['bbox']
+    save("eval", classes=np.array(classes), rec_lab=rec_lab, rec_box=rec_box, rec_n=rec_n, D=D, D_sim=D_sim,
+         img_ids=np.array(img_ids), infer_boxes=infer_boxes, Nb=np.int32(Nb),
+         ent=np.array(['|'.join(e) for e in vid_entities]),
+         det_img=np.array(dets[0]), det_lab=np.array(dets[1]), det_box=np.array(dets[2]), det_conf=np.array(dets[3]),
+         phrase_acc=np.float64(pa), box_acc=np.float64(ba))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(3)
@@ -171,3 +214,4 @@ if __name__ == "__main__":
     gold_embed(m)
     gold_proposal(m)
     gold_detector(m)
+    gold_eval(m)

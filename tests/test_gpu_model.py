@@ -212,3 +212,32 @@ def test_fused_clip_adam_matches_torch(gpu):
         for p, rp in zip(ps, rps):
             assert relerr(p.detach().cpu(), rp.detach().cpu()) < 1e-5
             assert relerr(p.grad.cpu(), rp.grad.cpu()) < 1e-5
+
+
+def test_validate_path_end_to_end(gpu):
+    """validate() body (model.py:869-947) on a synthetic video: stepRCNN -> embeddings -> DVSA(eval) -> postprocess ->
+    record_det -> evaluate_box, with gt boxes planted on the grounded boxes so the expected accuracy is known."""
+    from nafae_amd import evaluate as E
+    from nafae_amd.model import default_args
+    from nafae_amd.train import make_batch, setup_training, validate_segment
+    Na, Ns, Ne, Nb = 2, 3, 4, 8
+    gpu.TEST.RPN_POST_NMS_TOP_N = Nb
+    args = default_args(batch_size=Na, batch_size_val=Na, sample_num=Ns, max_ent_len=Ne)
+    model, _, _, _ = setup_training(args, seed=5)
+    model.eval(); model.DVSA.init_eval()
+    batch = make_batch(Na, Ns, Ne, H=96, W=80, seed=5, lens=[2, 3])
+    vid_entities = [['bowl', 'egg'], ['pan', 'oil', 'salt']]
+    img_ids = list(range(Na * Ns))
+    dets = [[], [], [], []]
+    loss = validate_segment(model, batch, vid_entities, img_ids, args, dets)
+    assert np.isfinite(loss) and len(dets[0]) == Ns * (2 + 3)
+    classes = ['bowl', 'egg', 'pan', 'oil', 'salt']
+    # gt = exactly the grounded boxes -> every query and every box is matched
+    recs = [{'label': [], 'bbox': [], 'thr': [], 'img_ids': []} for _ in img_ids]
+    for i, l, b in zip(dets[0], dets[1], dets[2]):
+        recs[i]['label'].append(l); recs[i]['bbox'].append(b); recs[i]['thr'].append(0.5); recs[i]['img_ids'].append(i)
+    assert abs(E.evaluate_box(recs, dets, classes) - 1.0) < 1e-5
+    # gt far away from everything -> zero
+    for r in recs:
+        r['bbox'] = [np.array([1000., 1000., 1010., 1010.]) for _ in r['bbox']]
+    assert E.evaluate_box(recs, dets, classes) == 0.0

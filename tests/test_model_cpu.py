@@ -80,3 +80,58 @@ def test_postprocess_matches_reference():
     Na, Ns, Nb, Ne, D = [int(x) for x in g["shape"]]
     Dp, Sp = postprocess(g["D_ind_eval"], g["D_sim_eval"], Na, Ns, Nb, Ne)
     assert np.array_equal(Dp, g["post_D"]) and np.array_equal(Sp, g["post_sim"])
+
+
+def test_evaluation_matches_reference():
+    """record_det + phrase/box accuracy against the imported reference's own outputs (tests/golden/eval.npz)."""
+    from nafae_amd import evaluate as E
+    g = np.load(os.path.join(G, "eval.npz"))
+    classes = g["classes"].tolist()
+    recs = []
+    for i in range(len(g["rec_n"])):
+        k = int(g["rec_n"][i])
+        recs.append({'label': g["rec_lab"][i].split('|')[:k] if k else [], 'bbox': g["rec_box"][i, :k],
+                     'thr': [0.5] * k, 'img_ids': [i] * k})
+    vid_entities = [e.split('|') for e in g["ent"].tolist()]
+    dets = [[], [], [], []]
+    E.record_det(dets[0], dets[1], dets[2], dets[3], int(g["Nb"]), vid_entities, g["D"], g["D_sim"], g["img_ids"].tolist(),
+                 g["infer_boxes"])
+    assert np.array_equal(np.array(dets[0]), g["det_img"]) and np.array(dets[1]).tolist() == g["det_lab"].tolist()
+    assert np.array_equal(np.array(dets[2]), g["det_box"]) and np.array_equal(np.array(dets[3]), g["det_conf"])
+    assert abs(E.phrase_accuracy(recs, dets, classes) - float(g["phrase_acc"])) < 1e-12
+    assert abs(E.box_accuracy(recs, dets, classes) - float(g["box_acc"])) < 1e-12
+    assert 0.0 < float(g["box_acc"]) < 1.0            # the fixture is not degenerate
+    assert E.evaluate_box(recs, dets, classes) == E.box_accuracy(recs, dets, classes)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """vis_ground_*.pth format (model.py:1115-1126) and the detector-only init (model.py:1056-1064)."""
+    import torch
+    from nafae_amd import checkpoint as C
+    from nafae_amd.config import cfg, reset_cfg
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fasterRCNN = torch.nn.Linear(4, 3)
+            self.vis_ebd = torch.nn.Linear(3, 2)
+    reset_cfg()
+    cfg.POOLING_MODE = 'align'
+    m1, m2 = Toy(), Toy()
+    opt = torch.optim.Adam(m1.parameters())
+    name = C.checkpoint_name(str(tmp_path), 'vgg16', 'YouCookII', 7, 3, 1290)
+    assert name.endswith(os.path.join('vgg16', 'YouCookII', 'vis_ground_7_3_1290.pth'))
+    C.save_ground_checkpoint(m1, opt, 7, 3, name)
+    ck = torch.load(name)
+    assert sorted(ck.keys()) == ['epoch', 'model', 'optimizer', 'pooling_mode', 'session'] and ck['pooling_mode'] == 'align'
+    cfg.POOLING_MODE = 'crop'
+    assert C.load_ground_checkpoint(m2, name, resume=True) == 4 and cfg.POOLING_MODE == 'align'
+    assert C.load_ground_checkpoint(m2, name, resume=False) == 3
+    assert all(torch.equal(a, b) for a, b in zip(m1.state_dict().values(), m2.state_dict().values()))
+    det = str(tmp_path / 'faster_rcnn_gnome.pth')
+    torch.save({'model': m1.fasterRCNN.state_dict()}, det)
+    m3 = Toy()
+    C.load_detector_checkpoint(m3, det)
+    assert torch.equal(m3.fasterRCNN.weight, m1.fasterRCNN.weight)
+    assert abs(C.adjust_learning_rate(opt, 1e-3, 25, 0.1, 20) - 1e-4) < 1e-12 and opt.param_groups[0]['lr'] == 1e-4
+    reset_cfg()
