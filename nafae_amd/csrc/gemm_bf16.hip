@@ -347,14 +347,15 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
 // per-lane mask says which taps of that lane's output pixel fall inside the image; the others are zeroed in registers.
 // Weights stream per tap through their own LDS ring exactly as in bf16_dma_kernel.  Step order: channel chunk (32) ->
 // dy -> dx; one raw barrier and one counted vmcnt wait per step.
-template <int BW, int WX, int WW, int NSTW>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT>
 __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
                                                            const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
                                                            const float *__restrict__ bias, float *__restrict__ Cf,
                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                            int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
-  constexpr int BX = 256, RR = 320, ROFF = 32, PL = 2;
-  using E = EngineH<BX, BW, WX, WW, true>;
+  // run length: 256 + 2 pixels are needed; 320 (split) / 384 (plain) rows make the chunk count a multiple of 512 lanes
+  constexpr int BX = 256, PL = SPLIT ? 2 : 1, RR = SPLIT ? 320 : 384, ROFF = 32;
+  using E = EngineH<BX, BW, WX, WW, SPLIT>;
   constexpr int TX = E::TX, TW = E::TW;
   constexpr int XRUN = RR * BKH * PL;   // bf16 elements per activation-run buffer
   constexpr int WST = BW * BKH * PL;    // bf16 elements per weight stage
@@ -502,15 +503,17 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
       for (int i = 0; i < TW; i++)
 #pragma unroll
         for (int j = 0; j < TX; j++) {
-          e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xa[0][j], e.acc[i][j], 0, 0, 0);
-          e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[1][j], e.acc[i][j], 0, 0, 0);
+          if (SPLIT) {
+            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PL - 1][i], xa[0][j], e.acc[i][j], 0, 0, 0);
+            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[PL - 1][j], e.acc[i][j], 0, 0, 0);
+          }
           e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], e.acc[i][j], 0, 0, 0);
           const int g = s * TW * TX + i * TX + j;
           if (g < NGRP) between(g);
         }
     }
   }
-  epilogue<E, true>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
 // ------------------------------------------------------------------------------------------------ plane helpers
@@ -697,13 +700,14 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   return launched();
 }
 
-template <int BW, int WX, int WW, int NSTW>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT>
 int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                     void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
   const int M = F * H * W;
   const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
-  const size_t lds = (size_t)(2 * 320 * BKH * 2 + NSTW * BW * BKH * 2) * sizeof(__bf16);
-  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW>;
+  constexpr int PL = SPLIT ? 2 : 1, RR = SPLIT ? 320 : 384;
+  const size_t lds = (size_t)(2 * RR * BKH * PL + NSTW * BW * BKH * PL) * sizeof(__bf16);
+  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -776,6 +780,9 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     if (split)
       return launch_dma<256, 128, 4, 2, true, false>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha,
                                                      act, 0, 0, 0, S(stream));
+    if (big && M >= 256 && N >= 256)
+      return launch_dma<256, 256, 2, 4, false, false, 3>(X_hi, nullptr, ldx, W_hi, nullptr, ldw, C_f32, C_hi, nullptr, ldc, bias, M, N,
+                                                         K, alpha, act, 0, 0, 0, S(stream));
     return launch_dma<256, 128, 4, 2, false, false>(X_hi, nullptr, ldx, W_hi, nullptr, ldw, C_f32, C_hi, nullptr, ldc, bias, M, N, K,
                                                     alpha, act, 0, 0, 0, S(stream));
   }
@@ -794,14 +801,26 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
   if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
   const bool split = in_lo && w_lo;
   if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
-  if (use_dma() && split && use_run()) {
+  if (use_dma() && use_run()) {
     const int M = F * H * W;
-    if (Cout <= 64)
-      return launch_conv_run<64, 8, 1, 3>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+    if (split) {
+      if (Cout <= 64)
+        return launch_conv_run<64, 8, 1, 3, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                                  S(stream));
+      if (Cout >= 256 && M >= 256 * 128)
+        return launch_conv_run<256, 2, 4, 2, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                                   S(stream));
+      return launch_conv_run<128, 4, 2, 3, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                                 S(stream));
+    }
+    // plain bf16 (BASELINE config C3): weight tiles of 128 / 256 rows fill the 512 lanes evenly; 64-row tiles do not,
+    // so the Cout <= 64 layer stays on the per-tap kernels below
     if (Cout >= 256 && M >= 256 * 128)
-      return launch_conv_run<256, 2, 4, 2>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
-                                           S(stream));
-    return launch_conv_run<128, 4, 2, 3>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+      return launch_conv_run<256, 2, 4, 3, false>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H, W, Cin, Cout,
+                                                  relu, S(stream));
+    if (Cout > 64)
+      return launch_conv_run<128, 4, 2, 3, false>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H, W, Cin, Cout,
+                                                  relu, S(stream));
   }
   if (use_dma()) {
     const int M = F * H * W, K9 = 9 * Cin, act = relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE;
