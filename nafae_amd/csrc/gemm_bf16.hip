@@ -516,6 +516,140 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
   epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
+// ------------------------------------------------------------------------------------------------ run-reuse conv, 3 taps / barrier
+// Same data flow as conv3x3_run_kernel for narrow layers (Cout <= 64, where a wave has only 12 MFMAs per tap and the
+// per-step barrier + waits cost as much as the matrix work): ONE barrier per row-offset group, i.e. per 3 taps.  The
+// three weight tap tiles of a group (8 KB each at 64 output channels) live in a 6-stage ring (2 groups), the
+// activation run ring is unchanged; every wait is vmcnt(0) on loads issued a whole group (36 MFMAs per wave) earlier.
+template <int BW, int WX, int WW>
+__global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
+                                                            const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+                                                            const float *__restrict__ bias, float *__restrict__ Cf,
+                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
+                                                            int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
+  constexpr int BX = 256, PL = 2, RR = 320, ROFF = 32;
+  using E = EngineH<BX, BW, WX, WW, true>;
+  constexpr int TX = E::TX, TW = E::TW;
+  constexpr int XRUN = RR * BKH * PL, WST = BW * BKH * PL;
+  constexpr int NXC = RR * 4 * PL / NT16, NWC = BW * 4 * PL / NT16;
+  static_assert(RR * 4 * PL % NT16 == 0 && BW * 4 * PL % NT16 == 0, "every lane active in every staging instruction");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  __bf16 *xbuf = smem16;              // 2 run buffers
+  __bf16 *wbuf = smem16 + 2 * XRUN;   // 6 weight stages: [group parity][tap in group]
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int M = F * H * W;
+  const int m0 = tm * BX, n0 = tn * BW;
+  const int cpt = Cin / BKH;
+  const int ngrp = 3 * cpt;
+  const int K9 = 9 * Cin;
+  const __bf16 *zero = reinterpret_cast<const __bf16 *>(nafae_zero_page);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  const __bf16 *xp[NXC];
+  int xpix[NXC];
+#pragma unroll
+  for (int i = 0; i < NXC; i++) {
+    const int id = threadIdx.x + NT16 * i;
+    const int q = id & 3, rowg = id >> 2;
+    const int plane = rowg / RR, row = rowg - plane * RR;
+    xpix[i] = m0 - ROFF + row;
+    xp[i] = (plane ? Xlo : Xhi) + (q ^ ((row >> 2) & 3)) * 8;
+  }
+  const __bf16 *wp[NWC];
+  bool wok[NWC];
+#pragma unroll
+  for (int i = 0; i < NWC; i++) {
+    const int id = threadIdx.x + NT16 * i;
+    const int q = id & 3, rowg = id >> 2;
+    const int plane = rowg / BW, row = rowg - plane * BW;
+    const int n = n0 + row;
+    wok[i] = n < Cout;
+    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 + (q ^ ((row >> 2) & 3)) * 8;
+  }
+  unsigned tapmask[TX];
+#pragma unroll
+  for (int j = 0; j < TX; j++) {
+    const int m = m0 + e.out_m(j);
+    unsigned mk = 0;
+    if (m < M) {
+      const int x = m % W, y = (m / W) % H;
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
+      }
+    }
+    tapmask[j] = mk;
+  }
+  // staging of one whole group g = (cc, dy): the run + its three weight tap tiles
+  auto issue_group = [&](int g) {
+    const int cc = g / 3, dyi = g - cc * 3;
+#pragma unroll
+    for (int i = 0; i < NXC; i++) {
+      const long pix = (long)xpix[i] + (long)(dyi - 1) * W;
+      const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * Cin + cc * BKH : zero;
+      char *dst = reinterpret_cast<char *>(xbuf + (size_t)(g & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+      for (int i = 0; i < NWC; i++) {
+        const __bf16 *src = wok[i] ? wp[i] + (dyi * 3 + t) * Cin + cc * BKH : zero;
+        char *dst = reinterpret_cast<char *>(wbuf + (size_t)((g & 1) * 3 + t) * WST) + (NT16 * i + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+      }
+  };
+  const int r31 = lane & 31, hh = lane >> 5;
+  issue_group(0);
+  for (int g = 0; g < ngrp; g++) {
+    wait_vmcnt<0>();                 // group g (issued one whole group of matrix work ago) has landed
+    __builtin_amdgcn_s_barrier();    // ... for every wave; and everyone is done with group g-1's buffers
+    if (g + 1 < ngrp) issue_group(g + 1);
+    const __bf16 *sX = xbuf + (size_t)(g & 1) * XRUN;
+    const int dyi = g - (g / 3) * 3;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int tap = dyi * 3 + t;
+      const __bf16 *sW = wbuf + (size_t)((g & 1) * 3 + t) * WST;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        bf16x8 xa[PL][TX], wa[PL][TW];
+#pragma unroll
+        for (int j = 0; j < TX; j++) {
+          const int rrow = e.wx * (TX * 32) + j * 32 + r31 + ROFF + t - 1;
+          const bool on = (tapmask[j] >> tap) & 1u;
+#pragma unroll
+          for (int p = 0; p < PL; p++) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[p * RR * BKH + lds_off16(rrow, 2 * s + hh)]);
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xa[p][j] = on ? v : z;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PL; p++)
+#pragma unroll
+          for (int i = 0; i < TW; i++)
+            wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[p * BW * BKH + lds_off16(e.ww * (TW * 32) + i * 32 + r31, 2 * s + hh)]);
+#pragma unroll
+        for (int i = 0; i < TW; i++)
+#pragma unroll
+          for (int j = 0; j < TX; j++) {
+            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xa[0][j], e.acc[i][j], 0, 0, 0);
+            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[1][j], e.acc[i][j], 0, 0, 0);
+            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], e.acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  }
+  epilogue<E, true>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+}
+
 // ------------------------------------------------------------------------------------------------ plane helpers
 __global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ in, __bf16 *__restrict__ hi,
                                                     __bf16 *__restrict__ lo, long n4) {
@@ -719,6 +853,24 @@ int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const voi
   return launched();
 }
 
+template <int BW, int WX, int WW>
+int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
+                     void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+  const int M = F * H * W;
+  const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
+  const size_t lds = (size_t)(2 * 320 * BKH * 2 + 6 * BW * BKH * 2) * sizeof(__bf16);
+  auto kern = conv3x3_run3_kernel<BW, WX, WW>;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo,
+                     (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu,
+                     tiles_m, tiles_n);
+  return launched();
+}
+
 // A/B switches: NAFAE_BF16_PIPE=reg selects the register-staged kernels; NAFAE_CONV_RUN=0 disables the run-reuse conv
 inline bool use_run() {
   static int v = -1;
@@ -804,9 +956,18 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
   if (use_dma() && use_run()) {
     const int M = F * H * W;
     if (split) {
-      if (Cout <= 64)
+      if (Cout <= 64) {
+        static int g3 = -1;  // NAFAE_CONV_RUN3=0: one barrier per tap instead of per 3-tap group (A/B)
+        if (g3 < 0) {
+          const char *e = getenv("NAFAE_CONV_RUN3");
+          g3 = (e && e[0] == '0') ? 0 : 1;
+        }
+        if (g3)
+          return launch_conv_run3<64, 8, 1>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                            S(stream));
         return launch_conv_run<64, 8, 1, 3, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                   S(stream));
+      }
       if (Cout >= 256 && M >= 256 * 128)
         return launch_conv_run<256, 2, 4, 2, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                    S(stream));
