@@ -34,19 +34,55 @@ constexpr int NT16 = 512;  // threads per workgroup
 
 __device__ __forceinline__ int lds_off16(int row, int slot) { return row * BKH + ((slot ^ ((row >> 2) & 3)) << 3); }
 
+// Operand-tile layout policy.  Two layouts of a split (hi, lo) operand exist, in HBM and in LDS alike:
+//   SEP  two separate planes, rows of 32 bf16 = 64 B each (also the only layout of plain bf16, PL = 1);
+//   IL   "I32": hi and lo interleaved per 32-element piece, [.., C/32, 2, 32]: one 128-B line holds hi(32)|lo(32) of one
+//        k-tile, so a staging instruction covers 8 rows x one FULL line instead of 16 rows x half a line -- half the
+//        L1/L2 requests per byte (measured 12 % on the fc6 GEMM).  LDS rows are 128 B, 8 slots XOR-swizzled by
+//        (row>>1)&7, the conflict-free pattern of the fp32 engine.
+// A staging chunk c (16 B) always lands at LDS byte c*16 of its tile (LDS-DMA destinations are wave-linear).
+template <bool IL, int PL>
+struct TileLayout {
+  // bf16-element offset of k-slot s (0..3) of plane p of row r inside a tile of NR rows
+  template <int NR>
+  static __device__ __forceinline__ int frag(int r, int p, int s) {
+    if (IL) return r * (2 * BKH) + ((((p << 2) | s) ^ ((r >> 1) & 7)) << 3);
+    return p * NR * BKH + lds_off16(r, s);
+  }
+  // staging chunk c of a tile of NR rows -> (row, plane, logical k-slot) it must fetch
+  template <int NR>
+  static __device__ __forceinline__ void decode(int c, int &row, int &plane, int &slot) {
+    if (IL) {
+      row = c >> 3;
+      const int l = (c & 7) ^ ((row >> 1) & 7);
+      plane = l >> 2;
+      slot = l & 3;
+    } else {
+      const int rg = c >> 2;
+      plane = rg / NR;
+      row = rg - plane * NR;
+      slot = (c & 3) ^ ((row >> 2) & 3);
+    }
+  }
+  static constexpr int KTS = IL ? 2 * BKH : BKH;  // elements to advance per k-tile along a row
+  static constexpr int RS = IL ? 2 : 1;           // row-stride multiplier (a row holds both planes)
+};
+
 __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
   hi = (__bf16)v;
   lo = (__bf16)(v - (float)hi);
 }
 
 // BX: rows of the activation side (m), BW: rows of the weight side (n); WX x WW waves.
-template <int BX, int BW, int WX, int WW, bool SPLIT>
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool IL = false>
 struct EngineH {
   static_assert(WX * WW == 8, "8 waves per workgroup");
+  static_assert(!IL || SPLIT, "the interleaved layout is for split (hi, lo) operands");
   static constexpr int TX = BX / WX / 32;
   static constexpr int TW = BW / WW / 32;
   static_assert(TX >= 1 && TW >= 1, "tile too small");
   static constexpr int PL = SPLIT ? 2 : 1;
+  using L = TileLayout<IL, PL>;
   static constexpr int CHUNKS = (BX + BW) * 4 * PL;  // 16-byte chunks per stage
   static constexpr int NCH = (CHUNKS + NT16 - 1) / NT16;  // per thread (the last one may be partial)
   static constexpr int STAGE = (BX + BW) * BKH * PL;  // bf16 elements per LDS stage
@@ -112,20 +148,26 @@ struct EngineH {
       for (int p = 0; p < PL; p++) {
 #pragma unroll
         for (int j = 0; j < TX; j++)
-          xa[p][j] = *reinterpret_cast<const bf16x8 *>(&sX[p * BX * BKH + lds_off16(wx * (TX * 32) + j * 32 + r31, 2 * s + h)]);
+          xa[p][j] = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<BX>(wx * (TX * 32) + j * 32 + r31, p, 2 * s + h)]);
 #pragma unroll
         for (int i = 0; i < TW; i++)
-          wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[p * BW * BKH + lds_off16(ww * (TW * 32) + i * 32 + r31, 2 * s + h)]);
+          wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(ww * (TW * 32) + i * 32 + r31, p, 2 * s + h)]);
       }
 #pragma unroll
       for (int i = 0; i < TW; i++)
 #pragma unroll
         for (int j = 0; j < TX; j++) {
+#ifdef NAFAE_SETPRIO
+          __builtin_amdgcn_s_setprio(1);
+#endif
           if (SPLIT) {  // small cross terms first, the dominant hi*hi last
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xa[0][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[1][j], acc[i][j], 0, 0, 0);
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], acc[i][j], 0, 0, 0);
+#ifdef NAFAE_SETPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
           between(s * TW * TX + i * TX + j);
         }
     }

@@ -25,10 +25,16 @@ __device__ __forceinline__ bf16x8 ldg8(const __bf16 *p, bool ok) {
 }
 
 // shared epilogue: acc -> act(alpha*acc + bias) -> fp32 matrix and/or bf16 planes, row stride ldc
+// (planes written in the interleaved I32 layout when Clo == Chi + 32: see plane_il())
+__device__ __forceinline__ bool plane_il(const void *hi, const void *lo) {
+  return lo != nullptr && reinterpret_cast<const char *>(lo) == reinterpret_cast<const char *>(hi) + 64;
+}
+
 template <class E, bool SPLIT>
 __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, float alpha, const float *__restrict__ bias,
                                          int act, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
                                          __bf16 *__restrict__ Clo, int ldc) {
+  const bool oil = SPLIT && plane_il(Chi, Clo);
 #pragma unroll
   for (int j = 0; j < E::TX; j++) {
     const int m = m0 + e.out_m(j);
@@ -57,8 +63,9 @@ __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, flo
             hi[q] = a;
             lo[q] = b;
           }
-          *reinterpret_cast<bf16x4 *>(Chi + o) = hi;
-          if (SPLIT && Clo) *reinterpret_cast<bf16x4 *>(Clo + o) = lo;
+          const size_t op = oil ? (size_t)m * (2 * ldc) + ((n >> 5) << 6) + (n & 31) : o;
+          *reinterpret_cast<bf16x4 *>(Chi + op) = hi;
+          if (SPLIT && Clo) *reinterpret_cast<bf16x4 *>(Clo + op) = lo;
         }
       }
   }
@@ -218,16 +225,23 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST>
-__global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo, int ldx,
-                                                        const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo, int ldw,
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST, bool IL>
+__global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const __bf16 *Xlo, int ldx, const __bf16 *Whi,
+                                                        const __bf16 *Wlo, int ldw,
                                                         float *__restrict__ Cf, __bf16 *__restrict__ Chi,
                                                         __bf16 *__restrict__ Clo, int ldc, const float *__restrict__ bias,
                                                         int M, int N, int K, float alpha, int act, int tiles_m, int tiles_n,
                                                         int H, int W, int Cin) {
-  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  using E = EngineH<BX, BW, WX, WW, SPLIT, IL>;
+  using L = typename E::L;
   static_assert(E::CHUNKS % NT16 == 0, "LDS-DMA path needs every lane active in every staging instruction");
   static_assert(NST == 2 || NST == 3, "ring of 2 or 3 LDS stages");
+  if (IL) {  // both planes of a row live in one 2x-wide row: lo = hi + 32, row stride and k-tile step double
+    Xlo = Xhi + BKH;
+    Wlo = Whi + BKH;
+    ldx *= 2;
+    ldw *= 2;
+  }
   constexpr int DIST = NST - 1;  // k-tiles in flight ahead of the one being computed
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   E e;
@@ -245,21 +259,18 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
   unsigned tapmask[E::NCH];  // CONV: bit t set <=> tap t of this lane's pixel lies inside the image
 #pragma unroll
   for (int i = 0; i < E::NCH; i++) {
-    const int id = threadIdx.x + NT16 * i;
-    const int q = id & 3;  // physical 16-byte slot inside the row == where this lane's bytes land
-    int rowg = id >> 2;
+    const int id = threadIdx.x + NT16 * i;  // this lane's bytes land at LDS byte id*16 of the stage
     isw[i] = id >= E::XCH;
-    int plane, row;
-    if (!isw[i]) {
-      plane = rowg / BX;
-      row = rowg - plane * BX;
-    } else {
-      rowg -= BX * E::PL;
-      plane = rowg / BW;
-      row = rowg - plane * BW;
-    }
-    const int slot = q ^ ((row >> 2) & 3);  // logical k-slot this lane must fetch (inverse swizzle on the source)
+    int plane, row, slot;  // logical (row, plane, k-slot) to fetch: the inverse swizzle sits on the source address
+    if (!isw[i])
+      L::template decode<BX>(id, row, plane, slot);
+    else
+      L::template decode<BW>(id - E::XCH, row, plane, slot);
     const bool dbg_zero = act == -1;        // timing experiment only (act = -1): every staging load hits the zero page
+    if (act == -4 && !IL) {  // timing experiment only: 8 full 128-B lines per staging instruction instead of 16 half lines
+      slot = (id & 3) + 4 * (row & 1);
+      row &= ~1;
+    }
     kslot[i] = slot * 8;
     tapmask[i] = 0x1ffu;
     if (!isw[i]) {
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
   const int wave = threadIdx.x >> 6;
   // one staging instruction (chunk i of k-tile kt -> LDS stage `stage`)
   const bool dbg_l2 = act == -2;            // timing experiment only: re-read the first 4 k-tiles (everything L2-resident)
-  const int kstep = (act == -3) ? 2 * BKH : BKH;  // timing experiment only (act = -3): hi/lo interleaved per 32-k piece
+  const int kstep = (act == -3 || act == -4) ? 2 * BKH : L::KTS;  // (-3/-4: timing experiments only)
   auto issue_one = [&](int i, int kt, int stage) {
     if (dbg_l2) kt &= 3;
     int aoff = kt * BKH, tap = 0;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
       tap = kt / cpt;
       const int cc = kt - tap * cpt;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      aoff = (dy * W + dx) * Cin + cc * BKH;
+      aoff = (dy * W + dx) * Cin * L::RS + cc * L::KTS;
     }
     char *sbase = reinterpret_cast<char *>(smem16) + (size_t)stage * E::STAGE * sizeof(__bf16);
     bool v = ok[i];
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
       src = gp[i] + aoff;
     } else {
       if (!CONV) v = v && (kt * BKH + kslot[i] < K);
-      src = gp[i] + kt * kstep;
+      src = gp[i] + (size_t)kt * kstep;   // (CONV weights: kt = tap*cpt + cc, K-contiguous, so the same step applies)
     }
     if (!v) src = zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -330,6 +341,8 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
 #pragma unroll
       for (int i = NGRP; i < E::NCH; i++) issue_one(i, kt + DIST, nstage);
     }
+    // (measured: handing the staging instructions out between MFMA groups beats issuing them all behind the barrier
+    // even with only one tile in flight -- 4.23 vs 4.58 ms at the fc6 shape)
     e.compute(smem16 + (size_t)(kt % NST) * E::STAGE, [&](int g) {
       if (g < E::NCH && g < NGRP && more) issue_one(g, kt + DIST, nstage);
     });
@@ -347,15 +360,20 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *__restrict
 // per-lane mask says which taps of that lane's output pixel fall inside the image; the others are zeroed in registers.
 // Weights stream per tap through their own LDS ring exactly as in bf16_dma_kernel.  Step order: channel chunk (32) ->
 // dy -> dx; one raw barrier and one counted vmcnt wait per step.
-template <int BW, int WX, int WW, int NSTW, bool SPLIT>
-__global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
-                                                           const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL>
+__global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
                                                            const float *__restrict__ bias, float *__restrict__ Cf,
                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                            int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
   // run length: 256 + 2 pixels are needed; 320 (split) / 384 (plain) rows make the chunk count a multiple of 512 lanes
   constexpr int BX = 256, PL = SPLIT ? 2 : 1, RR = SPLIT ? 320 : 384, ROFF = 32;
-  using E = EngineH<BX, BW, WX, WW, SPLIT>;
+  using E = EngineH<BX, BW, WX, WW, SPLIT, IL>;
+  using L = typename E::L;
+  if (IL) {
+    Xlo = Xhi + BKH;
+    Wlo = Whi + BKH;
+  }
+  const int CinS = Cin * L::RS;  // elements per pixel row / per weight tap (both planes when interleaved)
   constexpr int TX = E::TX, TW = E::TW;
   constexpr int XRUN = RR * BKH * PL;   // bf16 elements per activation-run buffer
   constexpr int WST = BW * BKH * PL;    // bf16 elements per weight stage
@@ -385,10 +403,8 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
   int xpix[NXC];
 #pragma unroll
   for (int i = 0; i < NXC; i++) {
-    const int id = threadIdx.x + NT16 * i;
-    const int q = id & 3, rowg = id >> 2;
-    const int plane = rowg / RR, row = rowg - plane * RR;
-    const int slot = q ^ ((row >> 2) & 3);
+    int plane, row, slot;
+    L::template decode<RR>(threadIdx.x + NT16 * i, row, plane, slot);
     xpix[i] = m0 - ROFF + row;
     xp[i] = (plane ? Xlo : Xhi) + slot * 8;
   }
@@ -396,13 +412,11 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
   bool wok[NWC];
 #pragma unroll
   for (int i = 0; i < NWC; i++) {
-    const int id = threadIdx.x + NT16 * i;
-    const int q = id & 3, rowg = id >> 2;
-    const int plane = rowg / BW, row = rowg - plane * BW;
-    const int slot = q ^ ((row >> 2) & 3);
+    int plane, row, slot;
+    L::template decode<BW>(threadIdx.x + NT16 * i, row, plane, slot);
     const int n = n0 + row;
     wok[i] = n < Cout;
-    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 + slot * 8;
+    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
   }
   // which taps of this lane's output pixels are inside the image
   unsigned tapmask[TX];
@@ -424,14 +438,14 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
   auto issue_x = [&](int i, int grp) {  // chunk i of the run for group grp = (cc, dy)
     const int cc = grp / 3, dy = grp - cc * 3 - 1;
     const long pix = (long)xpix[i] + (long)dy * W;
-    const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * Cin + cc * BKH : zero;
+    const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * CinS + cc * L::KTS : zero;
     char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   };
   auto issue_w = [&](int i, int st) {  // chunk i of the weight tile for step st = (cc, tap)
     const int cc = st / 9, tap = st - cc * 9;
-    const __bf16 *src = wok[i] ? wp[i] + tap * Cin + cc * BKH : zero;
+    const __bf16 *src = wok[i] ? wp[i] + tap * CinS + cc * L::KTS : zero;
     char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + wave * 64) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
         const bool on = (tapmask[j] >> tap) & 1u;
 #pragma unroll
         for (int p = 0; p < PL; p++) {
-          bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[p * RR * BKH + lds_off16(rrow, 2 * s + hh)]);
+          bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, 2 * s + hh)]);
           const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
           xa[p][j] = on ? v : z;
         }
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
       for (int p = 0; p < PL; p++)
 #pragma unroll
         for (int i = 0; i < TW; i++)
-          wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[p * BW * BKH + lds_off16(e.ww * (TW * 32) + i * 32 + r31, 2 * s + hh)]);
+          wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * 32 + r31, p, 2 * s + hh)]);
 #pragma unroll
       for (int i = 0; i < TW; i++)
 #pragma unroll
@@ -521,14 +535,19 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *__restr
 // per-step barrier + waits cost as much as the matrix work): ONE barrier per row-offset group, i.e. per 3 taps.  The
 // three weight tap tiles of a group (8 KB each at 64 output channels) live in a 6-stage ring (2 groups), the
 // activation run ring is unchanged; every wait is vmcnt(0) on loads issued a whole group (36 MFMAs per wave) earlier.
-template <int BW, int WX, int WW>
-__global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
-                                                            const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+template <int BW, int WX, int WW, bool IL>
+__global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
                                                             const float *__restrict__ bias, float *__restrict__ Cf,
                                                             __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                             int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
   constexpr int BX = 256, PL = 2, RR = 320, ROFF = 32;
-  using E = EngineH<BX, BW, WX, WW, true>;
+  using E = EngineH<BX, BW, WX, WW, true, IL>;
+  using L = typename E::L;
+  if (IL) {
+    Xlo = Xhi + BKH;
+    Wlo = Whi + BKH;
+  }
+  const int CinS = Cin * L::RS;
   constexpr int TX = E::TX, TW = E::TW;
   constexpr int XRUN = RR * BKH * PL, WST = BW * BKH * PL;
   constexpr int NXC = RR * 4 * PL / NT16, NWC = BW * 4 * PL / NT16;
@@ -552,22 +571,20 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__rest
   int xpix[NXC];
 #pragma unroll
   for (int i = 0; i < NXC; i++) {
-    const int id = threadIdx.x + NT16 * i;
-    const int q = id & 3, rowg = id >> 2;
-    const int plane = rowg / RR, row = rowg - plane * RR;
+    int plane, row, slot;
+    L::template decode<RR>(threadIdx.x + NT16 * i, row, plane, slot);
     xpix[i] = m0 - ROFF + row;
-    xp[i] = (plane ? Xlo : Xhi) + (q ^ ((row >> 2) & 3)) * 8;
+    xp[i] = (plane ? Xlo : Xhi) + slot * 8;
   }
   const __bf16 *wp[NWC];
   bool wok[NWC];
 #pragma unroll
   for (int i = 0; i < NWC; i++) {
-    const int id = threadIdx.x + NT16 * i;
-    const int q = id & 3, rowg = id >> 2;
-    const int plane = rowg / BW, row = rowg - plane * BW;
+    int plane, row, slot;
+    L::template decode<BW>(threadIdx.x + NT16 * i, row, plane, slot);
     const int n = n0 + row;
     wok[i] = n < Cout;
-    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 + (q ^ ((row >> 2) & 3)) * 8;
+    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
   }
   unsigned tapmask[TX];
 #pragma unroll
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__rest
 #pragma unroll
     for (int i = 0; i < NXC; i++) {
       const long pix = (long)xpix[i] + (long)(dyi - 1) * W;
-      const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * Cin + cc * BKH : zero;
+      const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * CinS + cc * L::KTS : zero;
       char *dst = reinterpret_cast<char *>(xbuf + (size_t)(g & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -599,7 +616,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__rest
     for (int t = 0; t < 3; t++)
 #pragma unroll
       for (int i = 0; i < NWC; i++) {
-        const __bf16 *src = wok[i] ? wp[i] + (dyi * 3 + t) * Cin + cc * BKH : zero;
+        const __bf16 *src = wok[i] ? wp[i] + (dyi * 3 + t) * CinS + cc * L::KTS : zero;
         char *dst = reinterpret_cast<char *>(wbuf + (size_t)((g & 1) * 3 + t) * WST) + (NT16 * i + wave * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -626,7 +643,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__rest
           const bool on = (tapmask[j] >> tap) & 1u;
 #pragma unroll
           for (int p = 0; p < PL; p++) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[p * RR * BKH + lds_off16(rrow, 2 * s + hh)]);
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, 2 * s + hh)]);
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             xa[p][j] = on ? v : z;
           }
@@ -635,7 +652,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__rest
         for (int p = 0; p < PL; p++)
 #pragma unroll
           for (int i = 0; i < TW; i++)
-            wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[p * BW * BKH + lds_off16(e.ww * (TW * 32) + i * 32 + r31, 2 * s + hh)]);
+            wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * 32 + r31, p, 2 * s + hh)]);
 #pragma unroll
         for (int i = 0; i < TW; i++)
 #pragma unroll
@@ -651,8 +668,11 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *__rest
 }
 
 // ------------------------------------------------------------------------------------------------ plane helpers
-__global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ in, __bf16 *__restrict__ hi,
-                                                    __bf16 *__restrict__ lo, long n4) {
+// element e of a dense tensor whose last dimension is a multiple of 32 -> offset of its hi part in the I32 layout
+__device__ __forceinline__ long il_off(long e) { return ((e >> 5) << 6) + (e & 31); }
+
+__global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ in, __bf16 *hi, __bf16 *lo, long n4) {
+  const bool il = plane_il(hi, lo);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 v = reinterpret_cast<const f32x4 *>(in)[i];
     bf16x4 h, l;
@@ -663,20 +683,22 @@ __global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ in
       h[q] = a;
       l[q] = b;
     }
-    reinterpret_cast<bf16x4 *>(hi)[i] = h;
-    if (lo) reinterpret_cast<bf16x4 *>(lo)[i] = l;
+    const long o = il ? il_off(4 * i) : 4 * i;
+    *reinterpret_cast<bf16x4 *>(hi + o) = h;
+    if (lo) *reinterpret_cast<bf16x4 *>(lo + o) = l;
   }
 }
 
-__global__ __launch_bounds__(256) void merge_kernel(const __bf16 *__restrict__ hi, const __bf16 *__restrict__ lo,
-                                                    float *__restrict__ out, long n4) {
+__global__ __launch_bounds__(256) void merge_kernel(const __bf16 *hi, const __bf16 *lo, float *__restrict__ out, long n4) {
+  const bool il = plane_il(hi, lo);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const bf16x4 h = reinterpret_cast<const bf16x4 *>(hi)[i];
+    const long o = il ? il_off(4 * i) : 4 * i;
+    const bf16x4 h = *reinterpret_cast<const bf16x4 *>(hi + o);
     f32x4 v;
 #pragma unroll
     for (int q = 0; q < 4; q++) v[q] = (float)h[q];
     if (lo) {
-      const bf16x4 l = reinterpret_cast<const bf16x4 *>(lo)[i];
+      const bf16x4 l = *reinterpret_cast<const bf16x4 *>(lo + o);
 #pragma unroll
       for (int q = 0; q < 4; q++) v[q] += (float)l[q];
     }
@@ -686,8 +708,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const __bf16 *__restrict__ h
 
 // First VGG layer (Cin = 3), fp32 NCHW frames in, bf16 planes out (NHWC, 64 channels).
 __global__ __launch_bounds__(256) void conv1_bf16_kernel(const float *__restrict__ in, const float *__restrict__ w,
-                                                         const float *__restrict__ bias, __bf16 *__restrict__ ohi,
-                                                         __bf16 *__restrict__ olo, int F, int H, int W) {
+                                                         const float *__restrict__ bias, __bf16 *ohi, __bf16 *olo, int F,
+                                                         int H, int W) {
   __shared__ float sw[27 * 64];
   __shared__ float sb[64];
   for (int i = threadIdx.x; i < 27 * 64; i += 256) {
@@ -727,20 +749,23 @@ __global__ __launch_bounds__(256) void conv1_bf16_kernel(const float *__restrict
     h[c >> 3][c & 7] = a;
     l[c >> 3][c & 7] = b;
   }
-  bf16x8 *oh = reinterpret_cast<bf16x8 *>(ohi + p * 64 + cg);
+  // 16 channels cg..cg+15 sit inside one 32-channel piece in either layout
+  const long o = plane_il(ohi, olo) ? p * 128 + ((cg >> 5) << 6) + (cg & 31) : p * 64 + cg;
+  bf16x8 *oh = reinterpret_cast<bf16x8 *>(ohi + o);
   oh[0] = h[0];
   oh[1] = h[1];
   if (olo) {
-    bf16x8 *ol = reinterpret_cast<bf16x8 *>(olo + p * 64 + cg);
+    bf16x8 *ol = reinterpret_cast<bf16x8 *>(olo + o);
     ol[0] = l[0];
     ol[1] = l[1];
   }
 }
 
 // 2x2/2 max-pool on NHWC planes: the (hi, lo) pair of the largest element is copied unchanged.
-__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const __bf16 *__restrict__ ihi, const __bf16 *__restrict__ ilo,
-                                                           __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo, int F, int H,
-                                                           int W, int C) {
+__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const __bf16 *ihi, const __bf16 *ilo, __bf16 *ohi, __bf16 *olo, int F,
+                                                           int H, int W, int C) {
+  const bool il = plane_il(ihi, ilo);   // (input and output use the same plane layout)
+  const int PS8 = il ? C / 4 : C / 8;   // bf16x8 units per pixel row behind ONE plane pointer
   const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
   const long total = (long)F * Ho * Wo * C8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -750,8 +775,9 @@ __global__ __launch_bounds__(256) void maxpool_bf16_kernel(const __bf16 *__restr
     t /= Wo;
     const int y = t % Ho;
     const long n = t / Ho;
-    const long base = ((n * H + 2 * y) * W + 2 * x) * (long)C8 + c;
-    const long offs[4] = {0, C8, (long)W * C8, (long)W * C8 + C8};
+    const int cu = il ? ((c >> 2) << 3) + (c & 3) : c;   // bf16x8 unit of channel group c inside its pixel row
+    const long base = ((n * H + 2 * y) * W + 2 * x) * (long)PS8 + cu;
+    const long offs[4] = {0, PS8, (long)W * PS8, (long)W * PS8 + PS8};
     bf16x8 bh = reinterpret_cast<const bf16x8 *>(ihi)[base];
     bf16x8 bl = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ilo) bl = reinterpret_cast<const bf16x8 *>(ilo)[base];
@@ -769,8 +795,9 @@ __global__ __launch_bounds__(256) void maxpool_bf16_kernel(const __bf16 *__restr
         }
       }
     }
-    reinterpret_cast<bf16x8 *>(ohi)[i] = bh;
-    if (olo) reinterpret_cast<bf16x8 *>(olo)[i] = bl;
+    const long oo = ((n * Ho + y) * Wo + x) * (long)PS8 + cu;
+    reinterpret_cast<bf16x8 *>(ohi)[oo] = bh;
+    if (olo) reinterpret_cast<bf16x8 *>(olo)[oo] = bl;
   }
 }
 
@@ -815,14 +842,18 @@ int launch_conv(const void *Xhi, const void *Xlo, const void *Whi, const void *W
   return launched();
 }
 
-template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST = 3>
+inline bool host_il(const void *hi, const void *lo) {
+  return lo != nullptr && reinterpret_cast<const char *>(lo) == reinterpret_cast<const char *>(hi) + 64;
+}
+
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST = 3, bool IL = false>
 int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const void *Wlo, int ldw, float *Cf, void *Chi,
                void *Clo, int ldc, const float *bias, int M, int N, int K, float alpha, int act, int H, int W, int Cin,
                hipStream_t st) {
   using E = EngineH<BX, BW, WX, WW, SPLIT>;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
   const size_t lds = NST * E::STAGE * sizeof(__bf16);
-  auto kern = bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST>;
+  auto kern = bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -834,14 +865,14 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   return launched();
 }
 
-template <int BW, int WX, int WW, int NSTW, bool SPLIT>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL = false>
 int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                     void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
   const int M = F * H * W;
   const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
   constexpr int PL = SPLIT ? 2 : 1, RR = SPLIT ? 320 : 384;
   const size_t lds = (size_t)(2 * RR * BKH * PL + NSTW * BW * BKH * PL) * sizeof(__bf16);
-  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT>;
+  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -853,13 +884,13 @@ int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const voi
   return launched();
 }
 
-template <int BW, int WX, int WW>
+template <int BW, int WX, int WW, bool IL = false>
 int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                      void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
   const int M = F * H * W;
   const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
   const size_t lds = (size_t)(2 * 320 * BKH * 2 + 6 * BW * BKH * 2) * sizeof(__bf16);
-  auto kern = conv3x3_run3_kernel<BW, WX, WW>;
+  auto kern = conv3x3_run3_kernel<BW, WX, WW, IL>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -917,18 +948,29 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                        void *stream) {
   if (!X_hi || !W_hi || (!C_f32 && !C_hi) || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((K & 7) || (ldx & 7) || (ldw & 7) || (N & 3) || (ldc & 3) || !al16(X_hi) || !al16(W_hi)) return NAFAE_EINVAL;
-  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && (act > 0 || act < -3)) return NAFAE_EINVAL;   // < 0: timing experiments
+  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && (act > 0 || act < -4)) return NAFAE_EINVAL;   // < 0: timing experiments
   const bool split = X_lo && W_lo;
   if (!split && (X_lo || W_lo)) return NAFAE_EINVAL;
+  if (host_il(X_hi, X_lo) && !use_dma()) return NAFAE_EINVAL;  // I32 operands: LDS-DMA kernels only
   if (use_dma()) {
     static int big = -1;  // NAFAE_BF16_TILE=128 forces the 256x128 tile (A/B experiments)
     if (big < 0) {
       const char *e = getenv("NAFAE_BF16_TILE");
       big = (e && atoi(e) == 128) ? 0 : 1;
     }
-    if (split && big && M >= 256 && N >= 256)  // 256x256 tile, 2-stage ring: 21 B/clk/CU of staging instead of 31
+    const bool il = split && host_il(X_hi, X_lo) && host_il(W_hi, W_lo);  // interleaved I32 operands (K % 32 == 0)
+    if (split && (host_il(X_hi, X_lo) != host_il(W_hi, W_lo))) return NAFAE_EINVAL;
+    if (il && (K & 31)) return NAFAE_EINVAL;
+    if (split && big && M >= 256 && N >= 256) {  // 256x256 tile, 2-stage ring: 21 B/clk/CU of staging instead of 31
+      if (il)
+        return launch_dma<256, 256, 2, 4, true, false, 2, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N,
+                                                                K, alpha, act, 0, 0, 0, S(stream));
       return launch_dma<256, 256, 2, 4, true, false, 2>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K,
                                                         alpha, act, 0, 0, 0, S(stream));
+    }
+    if (il)
+      return launch_dma<256, 128, 4, 2, true, false, 3, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K,
+                                                              alpha, act, 0, 0, 0, S(stream));
     if (split)
       return launch_dma<256, 128, 4, 2, true, false>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha,
                                                      act, 0, 0, 0, S(stream));
@@ -953,24 +995,40 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
   if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
   const bool split = in_lo && w_lo;
   if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
+  if (host_il(in_hi, in_lo) && !(use_dma() && use_run())) return NAFAE_EINVAL;  // I32 operands: run-reuse kernels only
   if (use_dma() && use_run()) {
     const int M = F * H * W;
     if (split) {
+      const bool il = host_il(in_hi, in_lo);
+      if (il != host_il(w_hi, w_lo)) return NAFAE_EINVAL;   // both operands in the same plane layout
       if (Cout <= 64) {
         static int g3 = -1;  // NAFAE_CONV_RUN3=0: one barrier per tap instead of per 3-tap group (A/B)
         if (g3 < 0) {
           const char *e = getenv("NAFAE_CONV_RUN3");
           g3 = (e && e[0] == '0') ? 0 : 1;
         }
+        if (g3 && il)
+          return launch_conv_run3<64, 8, 1, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
+                                                  S(stream));
         if (g3)
           return launch_conv_run3<64, 8, 1>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                             S(stream));
+        if (il)
+          return launch_conv_run<64, 8, 1, 3, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout,
+                                                          relu, S(stream));
         return launch_conv_run<64, 8, 1, 3, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                   S(stream));
       }
-      if (Cout >= 256 && M >= 256 * 128)
+      if (Cout >= 256 && M >= 256 * 128) {
+        if (il)
+          return launch_conv_run<256, 2, 4, 2, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout,
+                                                           relu, S(stream));
         return launch_conv_run<256, 2, 4, 2, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                    S(stream));
+      }
+      if (il)
+        return launch_conv_run<128, 4, 2, 3, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout,
+                                                         relu, S(stream));
       return launch_conv_run<128, 4, 2, 3, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                  S(stream));
     }

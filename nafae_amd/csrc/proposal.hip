@@ -312,11 +312,13 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
 // Same fused RoIAlignAvg on bf16 planes (hi [, lo]): feature value = hi + lo (split-bf16), output re-split.
 // 128 threads per ROI, 4 adjacent channels per thread (8-byte plane loads / stores).
-__global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf16 *__restrict__ fhi,
-                                                                      const __bf16 *__restrict__ flo, int H, int W, int C,
-                                                                      const float *__restrict__ rois, float scale,
-                                                                      __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo) {
+// Planes may be separate tensors or interleaved per 32 channels (lo == hi + 32 elements: "I32", see bf16_tile.h).
+__global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf16 *fhi, const __bf16 *flo, int H, int W, int C,
+                                                                      const float *__restrict__ rois, float scale, __bf16 *ohi,
+                                                                      __bf16 *olo) {
   const int n = blockIdx.x;
+  const bool il = flo != nullptr && reinterpret_cast<const char *>(flo) == reinterpret_cast<const char *>(fhi) + 64;
+  const int CS = il ? 2 * C : C;  // elements per pixel row behind one plane pointer
   const RoiGeom g = roi_geom(rois + (long)n * 5, scale, AS, AS);
   __shared__ int s_hs[AS], s_ws[AS], s_hv[AS], s_wv[AS];
   __shared__ float s_hr[AS], s_wr[AS];
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf
     s_wr[p] = w - (float)wsp;
   }
   __syncthreads();
-  const long img = (long)g.img * H * W * C;
-  const long ob = (long)n * PS * PS * C;
+  const long img = (long)g.img * H * W * CS;
+  const long ob = (long)n * PS * PS * CS;
   auto ld4 = [&](long off) -> f32x4 {
     const bf16x4_t h = *reinterpret_cast<const bf16x4_t *>(fhi + off);
     f32x4 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
@@ -356,8 +358,9 @@ __global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf
       for (int pw = 0; pw < AS; pw++) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (s_hv[ph] && s_wv[pw]) {
-          const long p = img + ((long)s_hs[ph] * W + s_ws[pw]) * C + c;
-          const f32x4 ul = ld4(p), ur = ld4(p + C), dl = ld4(p + (long)W * C), dr = ld4(p + (long)W * C + C);
+          const int co = il ? ((c >> 5) << 6) + (c & 31) : c;   // 4 channels c..c+3 stay inside one 32-channel piece
+          const long p = img + ((long)s_hs[ph] * W + s_ws[pw]) * CS + co;
+          const f32x4 ul = ld4(p), ur = ld4(p + CS), dl = ld4(p + (long)W * CS), dr = ld4(p + (long)W * CS + CS);
 #pragma unroll
           for (int q = 0; q < 4; q++) v[q] = bilerp(ul[q], ur[q], dl[q], dr[q], s_hr[ph], s_wr[pw]);
         }
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf
             hv[q] = hq;
             lv[q] = (__bf16)(sv - (float)hq);
           }
-          const long o = ob + ((ph - 1) * PS + pw) * (long)C + c;
+          const long o = ob + ((ph - 1) * PS + pw) * (long)CS + (il ? ((c >> 5) << 6) + (c & 31) : c);
           *reinterpret_cast<bf16x4_t *>(ohi + o) = hv;
           if (olo) *reinterpret_cast<bf16x4_t *>(olo + o) = lv;
         }

@@ -125,10 +125,11 @@ class _fasterRCNN(nn.Module):
                 if self.precision not in ('bf16x3', 'bf16'):
                     raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16', got %r" % (self.precision,))
                 sp = self.precision == 'bf16x3'
-                P['convs_h'] = [(ops.split_bf16(w, sp), b) for (w, b) in P['convs']]
-                P['rpn_w_h'] = ops.split_bf16(P['rpn_w'], sp)
-                P['fc6_w_h'] = ops.split_bf16(P['fc6_w'], sp)
-                P['fc7_w_h'] = ops.split_bf16(P['fc7_w'], sp)
+                il = sp   # split planes travel interleaved per 32 channels ("I32": full 128-B lines per request)
+                P['convs_h'] = [(ops.split_bf16(w, sp, il), b) for (w, b) in P['convs']]
+                P['rpn_w_h'] = ops.split_bf16(P['rpn_w'], sp, il)
+                P['fc6_w_h'] = ops.split_bf16(P['fc6_w'], sp, il)
+                P['fc7_w_h'] = ops.split_bf16(P['fc7_w'], sp, il)
                 # the fp32 copies of the big matrices are not needed on this path
                 P['convs'] = None
                 P['fc6_w'] = None
@@ -142,7 +143,8 @@ class _fasterRCNN(nn.Module):
         """RCNN_base (vgg16_rpn.py:38) -> NHWC [F, H/16, W/16, 512] (fp32 tensor, or ops.Planes in the bf16 modes)."""
         P = self._pack()
         if self.precision != 'f32':
-            x = ops.conv1_3x3_relu_bf16(im_data.contiguous(), P['conv1_w'], P['conv1_b'], split=self.precision == 'bf16x3')
+            x = ops.conv1_3x3_relu_bf16(im_data.contiguous(), P['conv1_w'], P['conv1_b'], split=self.precision == 'bf16x3',
+                                        il=self.precision == 'bf16x3')
             li = 0
             for v in VGG_CFG_D[1:]:
                 if v == 'M':
@@ -268,8 +270,8 @@ class vgg16(_fasterRCNN):
         R = pool5.shape[0]
         x = pool5.permute(0, 2, 3, 1).contiguous().view(R, -1)          # (ph,pw,c) order of the packed fc6
         if self.precision != 'f32':
-            _, fc6 = ops.gemm_nt_bf16(ops.split_bf16(x, self.precision == 'bf16x3'), P['fc6_w_h'], P['fc6_b'],
-                                      act=ops.ACT_RELU)
+            sp = self.precision == 'bf16x3'
+            _, fc6 = ops.gemm_nt_bf16(ops.split_bf16(x, sp, sp), P['fc6_w_h'], P['fc6_b'], act=ops.ACT_RELU)
             return ops.gemm_nt_bf16(fc6, P['fc7_w_h'], P['fc7_b'], act=ops.ACT_RELU, want_f32=True, want_planes=False)[0]
         fc6 = ops.gemm_nt(x, P['fc6_w'], P['fc6_b'], act=ops.ACT_RELU)
         return ops.gemm_nt(fc6, P['fc7_w'], P['fc7_b'], act=ops.ACT_RELU)

@@ -158,103 +158,131 @@ def nhwc_to_nchw(x):
 
 # ------------------------------------------------------------------------------------------------ bf16 / bf16x3 planes
 class Planes:
-    """An fp32 tensor carried as bf16 planes: value = hi (+ lo).  lo is None in plain-bf16 mode."""
-    __slots__ = ("hi", "lo")
+    """An fp32 tensor carried as bf16 planes: value = hi (+ lo).
+    lo is None in plain-bf16 mode.  Two storage layouts of a split tensor (include/nafae_hip.h):
+      il=False  two separate dense tensors of the logical shape;
+      il=True   "I32": ONE buffer [..., C/32, 2, 32] with hi and lo interleaved per 32 elements of the last dimension
+                (C % 32 == 0); `hi` is that buffer viewed as [..., 2C] and `lo` aliases it 32 elements further
+                (lo.data_ptr() == hi.data_ptr() + 64), which is how the C ABI recognises the layout."""
+    __slots__ = ("hi", "lo", "il", "shape")
 
-    def __init__(self, hi, lo=None):
-        self.hi, self.lo = hi, lo
-
-    @property
-    def shape(self):
-        return self.hi.shape
+    def __init__(self, hi, lo=None, il=False, shape=None):
+        self.hi, self.lo, self.il = hi, lo, il
+        self.shape = tuple(shape) if shape is not None else tuple(hi.shape)
 
     def view(self, *shape):
-        return Planes(self.hi.view(*shape), None if self.lo is None else self.lo.view(*shape))
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        numel = 1
+        for d in self.shape:
+            numel *= d
+        shape = list(shape)
+        if -1 in shape:
+            known = 1
+            for d in shape:
+                if d != -1:
+                    known *= d
+            shape[shape.index(-1)] = numel // known
+        if self.il:
+            if shape[-1] % 32:
+                raise NafaeOpError("I32 planes: the last dimension of a view must stay a multiple of 32")
+            return Planes(self.hi.view(*shape[:-1], 2 * shape[-1]), self.lo, True, shape)
+        return Planes(self.hi.view(*shape), None if self.lo is None else self.lo.view(*shape), False, shape)
 
 
-def split_bf16(x, split=True):
+def _alloc_planes(shape, device, split, il):
+    shape = tuple(shape)
+    if il:
+        if not split or shape[-1] % 32:
+            raise NafaeOpError("I32 planes need split=True and a last dimension that is a multiple of 32")
+        buf = torch.empty(shape[:-1] + (2 * shape[-1],), device=device, dtype=torch.bfloat16)
+        return Planes(buf, buf.view(-1)[32:], True, shape)
+    hi = torch.empty(shape, device=device, dtype=torch.bfloat16)
+    return Planes(hi, torch.empty(shape, device=device, dtype=torch.bfloat16) if split else None, False, shape)
+
+
+def _chk_planes(P, name="planes"):
+    _chk(P.hi, torch.bfloat16, name + ".hi")
+    if P.lo is not None and not P.il:
+        _chk(P.lo, torch.bfloat16, name + ".lo")
+
+
+def split_bf16(x, split=True, il=False):
     _chk(x)
-    hi = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
-    lo = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if split else None
-    _rc(_lib.lib().nafae_split_bf16(_p(x), _p(hi), _p(lo), x.numel(), _stream()), "nafae_split_bf16")
-    return Planes(hi, lo)
+    P = _alloc_planes(x.shape, x.device, split, il)
+    _rc(_lib.lib().nafae_split_bf16(_p(x), _p(P.hi), _p(P.lo), x.numel(), _stream()), "nafae_split_bf16")
+    return P
 
 
 def merge_bf16(pl):
-    _chk(pl.hi, torch.bfloat16); _chk(pl.lo, torch.bfloat16)
-    out = torch.empty(pl.hi.shape, device=pl.hi.device, dtype=torch.float32)
+    _chk_planes(pl)
+    out = torch.empty(pl.shape, device=pl.hi.device, dtype=torch.float32)
     _rc(_lib.lib().nafae_merge_bf16(_p(pl.hi), _p(pl.lo), _p(out), out.numel(), _stream()), "nafae_merge_bf16")
     return out
 
 
-def _outs(shape, device, want_f32, want_planes, split):
-    cf = torch.empty(shape, device=device, dtype=torch.float32) if want_f32 else None
-    ch = torch.empty(shape, device=device, dtype=torch.bfloat16) if want_planes else None
-    cl = torch.empty(shape, device=device, dtype=torch.bfloat16) if (want_planes and split) else None
-    return cf, ch, cl
-
-
 def gemm_nt_bf16(X, Wt, bias=None, alpha=1.0, act=ACT_NONE, want_f32=False, want_planes=True):
-    """act(alpha * X @ W.T + bias) on the bf16 matrix cores; X, Wt are Planes ([M,K], [N,K]).
-    Returns (f32 tensor or None, Planes or None)."""
-    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16); _chk(Wt.hi, torch.bfloat16); _chk(Wt.lo, torch.bfloat16)
-    _chk(bias)
-    M, K = X.hi.shape
-    N = Wt.hi.shape[0]
+    """act(alpha * X @ W.T + bias) on the bf16 matrix cores; X, Wt are Planes ([M,K], [N,K]) in the same layout.
+    Returns (f32 tensor or None, Planes or None); output planes use X's layout when N allows it."""
+    _chk_planes(X, "X"); _chk_planes(Wt, "W"); _chk(bias)
+    M, K = X.shape
+    N = Wt.shape[0]
     split = X.lo is not None
-    if (Wt.lo is not None) != split or Wt.hi.shape[1] != K:
+    if (Wt.lo is not None) != split or Wt.shape[1] != K or X.il != Wt.il:
         raise NafaeOpError("gemm_nt_bf16: operand mismatch")
-    cf, ch, cl = _outs((M, N), X.hi.device, want_f32, want_planes, split)
-    _rc(_lib.lib().nafae_gemm_nt_bf16(_p(X.hi), _p(X.lo), K, _p(Wt.hi), _p(Wt.lo), K, _p(cf), _p(ch), _p(cl), N, _p(bias), M, N, K,
+    cf = torch.empty(M, N, device=X.hi.device, dtype=torch.float32) if want_f32 else None
+    C = _alloc_planes((M, N), X.hi.device, split, X.il and N % 32 == 0) if want_planes else Planes(None, None, False, (M, N))
+    _rc(_lib.lib().nafae_gemm_nt_bf16(_p(X.hi), _p(X.lo), K, _p(Wt.hi), _p(Wt.lo), K, _p(cf), _p(C.hi), _p(C.lo), N, _p(bias), M, N, K,
                                       float(alpha), int(act), _stream()), "nafae_gemm_nt_bf16")
-    return cf, (Planes(ch, cl) if want_planes else None)
+    return cf, (C if want_planes else None)
 
 
 def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True):
     """X Planes [F,H,W,Cin], Wt Planes [Cout,3,3,Cin] -> (f32 or None, Planes or None) of [F,H,W,Cout]."""
-    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16); _chk(Wt.hi, torch.bfloat16); _chk(Wt.lo, torch.bfloat16)
-    _chk(bias)
-    F, H, W, Cin = X.hi.shape
-    Cout = Wt.hi.shape[0]
+    _chk_planes(X, "X"); _chk_planes(Wt, "W"); _chk(bias)
+    F, H, W, Cin = X.shape
+    Cout = Wt.shape[0]
     split = X.lo is not None
-    if (Wt.lo is not None) != split or Wt.hi.numel() != Cout * 9 * Cin:
+    n_w = 1
+    for d in Wt.shape:
+        n_w *= d
+    if (Wt.lo is not None) != split or n_w != Cout * 9 * Cin or X.il != Wt.il:
         raise NafaeOpError("conv3x3_bf16: operand mismatch")
-    cf, ch, cl = _outs((F, H, W, Cout), X.hi.device, want_f32, want_planes, split)
-    _rc(_lib.lib().nafae_conv3x3_bf16(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), _p(cf), _p(ch), _p(cl), F, H, W, Cin, Cout,
-                                      int(bool(relu)), _stream()), "nafae_conv3x3_bf16")
-    return cf, (Planes(ch, cl) if want_planes else None)
+    cf = torch.empty(F, H, W, Cout, device=X.hi.device, dtype=torch.float32) if want_f32 else None
+    C = (_alloc_planes((F, H, W, Cout), X.hi.device, split, X.il and Cout % 32 == 0) if want_planes
+         else Planes(None, None, False, (F, H, W, Cout)))
+    _rc(_lib.lib().nafae_conv3x3_bf16(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), _p(cf), _p(C.hi), _p(C.lo), F, H, W, Cin,
+                                      Cout, int(bool(relu)), _stream()), "nafae_conv3x3_bf16")
+    return cf, (C if want_planes else None)
 
 
-def conv1_3x3_relu_bf16(x_nchw, w27, bias, split=True):
+def conv1_3x3_relu_bf16(x_nchw, w27, bias, split=True, il=False):
     _chk(x_nchw); _chk(w27); _chk(bias)
     F, C, H, W = x_nchw.shape
     if C != 3 or w27.numel() != 64 * 27:
         raise NafaeOpError("conv1: expects Cin=3, Cout=64")
-    hi = torch.empty(F, H, W, 64, device=x_nchw.device, dtype=torch.bfloat16)
-    lo = torch.empty_like(hi) if split else None
-    _rc(_lib.lib().nafae_conv1_3x3_relu_bf16(_p(x_nchw), _p(w27), _p(bias), _p(hi), _p(lo), F, H, W, _stream()),
+    P = _alloc_planes((F, H, W, 64), x_nchw.device, split, il)
+    _rc(_lib.lib().nafae_conv1_3x3_relu_bf16(_p(x_nchw), _p(w27), _p(bias), _p(P.hi), _p(P.lo), F, H, W, _stream()),
         "nafae_conv1_3x3_relu_bf16")
-    return Planes(hi, lo)
+    return P
 
 
 def maxpool2x2_bf16(X):
-    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16)
-    F, H, W, C = X.hi.shape
-    hi = torch.empty(F, H // 2, W // 2, C, device=X.hi.device, dtype=torch.bfloat16)
-    lo = torch.empty_like(hi) if X.lo is not None else None
-    _rc(_lib.lib().nafae_maxpool2x2_bf16(_p(X.hi), _p(X.lo), _p(hi), _p(lo), F, H, W, C, _stream()), "nafae_maxpool2x2_bf16")
-    return Planes(hi, lo)
+    _chk_planes(X)
+    F, H, W, C = X.shape
+    P = _alloc_planes((F, H // 2, W // 2, C), X.hi.device, X.lo is not None, X.il)
+    _rc(_lib.lib().nafae_maxpool2x2_bf16(_p(X.hi), _p(X.lo), _p(P.hi), _p(P.lo), F, H, W, C, _stream()), "nafae_maxpool2x2_bf16")
+    return P
 
 
 def roi_align_avg_nhwc_bf16(X, rois, spatial_scale):
-    _chk(X.hi, torch.bfloat16); _chk(X.lo, torch.bfloat16); _chk(rois)
-    F, H, W, C = X.hi.shape
+    _chk_planes(X); _chk(rois)
+    F, H, W, C = X.shape
     N = rois.shape[0]
-    hi = torch.empty(N, 7, 7, C, device=rois.device, dtype=torch.bfloat16)
-    lo = torch.empty_like(hi) if X.lo is not None else None
-    _rc(_lib.lib().nafae_roi_align_avg_nhwc_bf16(_p(X.hi), _p(X.lo), F, H, W, C, _p(rois), N, float(spatial_scale), _p(hi), _p(lo),
+    P = _alloc_planes((N, 7, 7, C), rois.device, X.lo is not None, X.il)
+    _rc(_lib.lib().nafae_roi_align_avg_nhwc_bf16(_p(X.hi), _p(X.lo), F, H, W, C, _p(rois), N, float(spatial_scale), _p(P.hi), _p(P.lo),
                                                  _stream()), "nafae_roi_align_avg_nhwc_bf16")
-    return Planes(hi, lo)
+    return P
 
 
 # ------------------------------------------------------------------------------------------------ proposals

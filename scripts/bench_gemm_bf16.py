@@ -18,7 +18,7 @@ bias = torch.zeros(N, device='cuda')
 for split in (True, False):
     Xp, Wp = ops.split_bf16(A, split), ops.split_bf16(B, split)
     nprod = 3 if split else 1
-    for act, tag in ((1, 'real'), (-1, 'zero-page loads'), (-2, 'L2-resident loads')):
+    for act, tag in ((1, 'real'), (-1, 'zero-page loads'), (-2, 'L2-resident loads'), (-4, 'full-line requests')):
         ms = timeit(lambda: ops.gemm_nt_bf16(Xp, Wp, bias, act=act, want_f32=False, want_planes=True))
         print("gemm fc6 split=%s %-16s %.3f ms  alg %.0f TF  mfma %.0f TF (%.1f%% of 2.5PF)" % (split, tag, ms, 2*M*N*K/ms/1e9, nprod*2*M*N*K/ms/1e9, nprod*2*M*N*K/ms/1e9/25))
     if split:

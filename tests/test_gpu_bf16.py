@@ -41,13 +41,19 @@ def test_split_merge_roundtrip(ops):
     y = ops.merge_bf16(p).cpu()
     assert float(((y - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
     assert torch.equal(p.hi.cpu(), x.to(torch.bfloat16))
+    # interleaved "I32" layout: [.., C/32, 2, 32]; same values, lo aliases hi + 32 elements
+    q = ops.split_bf16(dev(x), il=True)
+    assert q.lo.data_ptr() == q.hi.data_ptr() + 64 and tuple(q.hi.shape) == (1000, 128) and q.shape == (1000, 64)
+    assert torch.equal(ops.merge_bf16(q).cpu(), y)
+    b = q.hi.cpu().view(1000, 2, 2, 32)
+    assert torch.equal(b[:, :, 0].reshape(1000, 64), p.hi.cpu()) and torch.equal(b[:, :, 1].reshape(1000, 64), p.lo.cpu())
     p1 = ops.split_bf16(dev(x), split=False)
     assert p1.lo is None and torch.equal(ops.merge_bf16(p1).cpu(), x.to(torch.bfloat16).float())
 
 
 @pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 200, 200), (257, 72, 512), (16, 512, 200), (1, 4, 8),
-                                   (513, 132, 40), (1000, 4096, 64)])
+                                   (513, 132, 40), (1000, 4096, 64), (700, 320, 96)])
 def test_gemm_nt_bf16(ops, split, M, N, K):
     A, B, bias = rnd(1, M, K), rnd(2, N, K), rnd(3, N)
     ref = 0.37 * (A.double() @ B.double().T) + bias.double()
@@ -57,6 +63,11 @@ def test_gemm_nt_bf16(ops, split, M, N, K):
     assert relerr(ops.merge_bf16(cp).cpu(), ref) < (2 * TOL[split] if split else 2e-2)
     cf2, _ = ops.gemm_nt_bf16(Xp, Wp, dev(bias), alpha=0.37, act=1, want_f32=True, want_planes=False)
     assert relerr(cf2.cpu(), torch.relu(ref)) < TOL[split]
+    if split and K % 32 == 0:      # same contraction on interleaved (I32) operands: bit-identical accumulation order
+        Xi, Wi = ops.split_bf16(dev(A), True, il=True), ops.split_bf16(dev(B), True, il=True)
+        ci, cpi = ops.gemm_nt_bf16(Xi, Wi, dev(bias), alpha=0.37, act=0, want_f32=True, want_planes=True)
+        assert torch.equal(ci.cpu(), cf.cpu())
+        assert cpi.il == (N % 32 == 0) and torch.equal(ops.merge_bf16(cpi).cpu(), ops.merge_bf16(cp).cpu())
 
 
 def test_gemm_nt_bf16_orientation_exact(ops):
@@ -85,6 +96,12 @@ def test_conv3x3_bf16(ops, split, Fr, H, W, Cin, Cout, relu):
     cf, cp = ops.conv3x3_bf16(xp, wp, dev(b), relu=relu, want_f32=True, want_planes=True)
     assert relerr(cf.cpu().permute(0, 3, 1, 2), ref) < TOL[split]
     assert relerr(ops.merge_bf16(cp).cpu().permute(0, 3, 1, 2), ref) < 2 * TOL[split]
+    if split:                      # interleaved (I32) planes: identical results
+        xi = ops.split_bf16(dev(x.permute(0, 2, 3, 1).contiguous()), True, il=True)
+        wi = ops.split_bf16(dev(w.permute(0, 2, 3, 1).contiguous()), True, il=True)
+        ci, cpi = ops.conv3x3_bf16(xi, wi, dev(b), relu=relu, want_f32=True, want_planes=True)
+        assert torch.equal(ci.cpu(), cf.cpu())
+        assert cpi.il == (Cout % 32 == 0) and torch.equal(ops.merge_bf16(cpi).cpu(), ops.merge_bf16(cp).cpu())
 
 
 def test_conv1_maxpool_roialign_planes(ops):
@@ -110,6 +127,13 @@ def test_conv1_maxpool_roialign_planes(ops):
     ref = N.roi_align_avg(fm, rois, 7, 1 / 16.)
     out = ops.merge_bf16(ops.roi_align_avg_nhwc_bf16(fp, dev(rois), 1 / 16.)).cpu().permute(0, 3, 1, 2).numpy()
     assert relerr(out, ref) < 2e-5
+    # the same three plane kernels on interleaved (I32) planes give identical values
+    pi = ops.conv1_3x3_relu_bf16(dev(x), dev(w.reshape(64, 27)), dev(b), il=True)
+    assert pi.il and torch.equal(ops.merge_bf16(pi).cpu(), ops.merge_bf16(p).cpu())
+    assert torch.equal(ops.merge_bf16(ops.maxpool2x2_bf16(pi)).cpu(), ops.merge_bf16(q).cpu())
+    fi = ops.split_bf16(dev(torch.from_numpy(f).permute(0, 2, 3, 1).contiguous()), il=True)
+    outi = ops.merge_bf16(ops.roi_align_avg_nhwc_bf16(fi, dev(rois), 1 / 16.)).cpu().permute(0, 3, 1, 2).numpy()
+    assert np.array_equal(outi, out)
 
 
 def _detector(seed, precision):
