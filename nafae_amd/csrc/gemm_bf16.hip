@@ -360,13 +360,16 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
 // per-lane mask says which taps of that lane's output pixel fall inside the image; the others are zeroed in registers.
 // Weights stream per tap through their own LDS ring exactly as in bf16_dma_kernel.  Step order: channel chunk (32) ->
 // dy -> dx; one raw barrier and one counted vmcnt wait per step.
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX = 256>
 __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
                                                            const float *__restrict__ bias, float *__restrict__ Cf,
                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                            int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
   // run length: 256 + 2 pixels are needed; 320 (split) / 384 (plain) rows make the chunk count a multiple of 512 lanes
-  constexpr int BX = 256, PL = SPLIT ? 2 : 1, RR = SPLIT ? 320 : 384, ROFF = 32;
+  // BX = 224 (7 x 32 pixels, run of 256 rows starting 16 pixels early) exists for tile-count quantisation: layers whose
+  // pixel count is 49 * 2^k give 3.06 / 1.53 / 0.77 workgroups per CU with 256-pixel tiles but 3.5 / 1.75 / 0.875 with 224
+  static_assert(BX == 256 || (BX == 224 && SPLIT), "tile of 256 pixels, or 224 for the split path");
+  constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384), ROFF = BX == 224 ? 16 : 32;
   using E = EngineH<BX, BW, WX, WW, SPLIT, IL>;
   using L = typename E::L;
   if (IL) {
@@ -865,14 +868,14 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   return launched();
 }
 
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL = false>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL = false, int BX = 256>
 int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                     void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
   const int M = F * H * W;
-  const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
-  constexpr int PL = SPLIT ? 2 : 1, RR = SPLIT ? 320 : 384;
+  const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
+  constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384);
   const size_t lds = (size_t)(2 * RR * BKH * PL + NSTW * BW * BKH * PL) * sizeof(__bf16);
-  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL>;
+  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1019,6 +1022,19 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
         return launch_conv_run<64, 8, 1, 3, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                   S(stream));
       }
+      // 224-pixel tiles when that lowers ceil(workgroups / 256 CUs) * pixels-per-tile (tile-count quantisation)
+      static int q224 = -1;
+      if (q224 < 0) {
+        const char *e = getenv("NAFAE_CONV_224");
+        q224 = (e && e[0] == '1') ? 1 : 0;   // measured slower than 256-pixel tiles (1x8 wave grid re-reads X 8x): off
+      }
+      auto cost = [&](int bx, int bw) {
+        const long wg = (long)((M + bx - 1) / bx) * ((Cout + bw - 1) / bw);
+        return ((wg + 255) / 256) * (long)bx * bw;
+      };
+      if (il && q224 && Cout >= 256 && M >= 256 * 128 && cost(224, 256) < cost(256, 256))
+        return launch_conv_run<256, 1, 8, 2, true, true, 224>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin,
+                                                              Cout, relu, S(stream));
       if (Cout >= 256 && M >= 256 * 128) {
         if (il)
           return launch_conv_run<256, 2, 4, 2, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout,

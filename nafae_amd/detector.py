@@ -87,6 +87,8 @@ class _fasterRCNN(nn.Module):
         #   'bf16'   plain bf16 operands (BASELINE config C3; parity at bf16 tolerance only).
         self.precision = os.environ.get("NAFAE_PRECISION", "bf16x3")
         self.materialize_pooled = True     # bf16 modes: also hand out pooled_feat as fp32 (API parity)
+        self.conv_streams = int(os.environ.get("NAFAE_CONV_STREAMS", "1"))
+        self._streams = None
 
     # ------------------------------------------------------------------ weights -> kernel layout
     def _pack_key(self):
@@ -139,12 +141,10 @@ class _fasterRCNN(nn.Module):
         return P
 
     # ------------------------------------------------------------------ forward
-    def base_features(self, im_data):
-        """RCNN_base (vgg16_rpn.py:38) -> NHWC [F, H/16, W/16, 512] (fp32 tensor, or ops.Planes in the bf16 modes)."""
-        P = self._pack()
+    def _base_features_one(self, im_data, P):
         if self.precision != 'f32':
-            x = ops.conv1_3x3_relu_bf16(im_data.contiguous(), P['conv1_w'], P['conv1_b'], split=self.precision == 'bf16x3',
-                                        il=self.precision == 'bf16x3')
+            sp = self.precision == 'bf16x3'
+            x = ops.conv1_3x3_relu_bf16(im_data.contiguous(), P['conv1_w'], P['conv1_b'], split=sp, il=sp)
             li = 0
             for v in VGG_CFG_D[1:]:
                 if v == 'M':
@@ -164,6 +164,40 @@ class _fasterRCNN(nn.Module):
                 x = ops.conv3x3_relu(x, w, b, relu=True)
                 li += 1
         return x
+
+    def base_features(self, im_data):
+        """RCNN_base (vgg16_rpn.py:38) -> NHWC [F, H/16, W/16, 512] (fp32 tensor, or ops.Planes in the bf16 modes).
+
+        With `self.conv_streams` = 2 the frame batch is cut in two halves that run the conv stack on two HIP streams:
+        several layers launch 0.77 / 1.53 / 3.06 workgroups per CU (49 * 2^k pixels in 256-pixel tiles, one 140 KB-LDS
+        workgroup per CU), so a quarter of the chip idles in the last round of every such launch; the other half-batch's
+        kernels fill those CUs.  Frames are independent until the loss tail, so the results are bit-identical."""
+        P = self._pack()
+        F = im_data.shape[0]
+        ns = self.conv_streams
+        if ns < 2 or F < 2 * 8 or F % ns:
+            return self._base_features_one(im_data, P)
+        main = torch.cuda.current_stream()
+        if self._streams is None or len(self._streams) != ns:
+            self._streams = [torch.cuda.Stream() for _ in range(ns)]
+        outs = []
+        per = F // ns
+        for k, st in enumerate(self._streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                chunk = im_data[k * per:(k + 1) * per]
+                chunk.record_stream(st)
+                outs.append(self._base_features_one(chunk, P))
+        for st in self._streams:
+            main.wait_stream(st)
+        if isinstance(outs[0], ops.Planes):
+            hi = torch.cat([o.hi for o in outs], 0)
+            shape = (F,) + tuple(outs[0].shape[1:])
+            if outs[0].il:
+                return ops.Planes(hi, hi.view(-1)[32:], True, shape)
+            lo = torch.cat([o.lo for o in outs], 0) if outs[0].lo is not None else None
+            return ops.Planes(hi, lo, False, shape)
+        return torch.cat(outs, 0)
 
     def proposals(self, base_feat, im_info):
         """RCNN_rpn in eval mode (rpn/rpn.py:58-79 + proposal_layer.py:49-171)."""

@@ -6,10 +6,10 @@ g = torch.Generator(device='cuda').manual_seed(0)
 M, N, K = 8192, 4096, 25088
 A = torch.randn(M, K, device='cuda', generator=g); B = torch.randn(N, K, device='cuda', generator=g) * 0.01
 bias = torch.zeros(N, device='cuda')
-Xp, Wp = ops.split_bf16(A, True), ops.split_bf16(B, True)
+Xp, Wp = ops.split_bf16(A, True, True), ops.split_bf16(B, True, True)   # interleaved I32 planes, as the detector uses
 del A, B
 x = torch.randn(64, 56, 56, 256, device='cuda', generator=g); w = torch.randn(256, 3, 3, 256, device='cuda', generator=g) * 0.02
-xp, wp = ops.split_bf16(x, True), ops.split_bf16(w, True); cb = torch.zeros(256, device='cuda')
+xp, wp = ops.split_bf16(x, True, True), ops.split_bf16(w, True, True); cb = torch.zeros(256, device='cuda')
 for _ in range(3):
     ops.gemm_nt_bf16(Xp, Wp, bias, act=1, want_f32=False, want_planes=True)
     ops.conv3x3_bf16(xp, wp, cb)
