@@ -83,6 +83,15 @@ int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, in
 int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                   float alpha, int accumulate, void *stream);
 
+/* Same contraction over a device-side list of rows: C = alpha * sum_{j < *count} A[rows[j], :]^T B[rows[j], :].
+ * rows: int32 [max_rows] ascending, count: int32 [1] (both on the device; nothing is read back).  C is overwritten.
+ * Used with nafae_nonzero_rows: the gradient wrt the visual embedding is exactly zero on >= 85 % of its rows.  */
+int nafae_gemm_tn_rows(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N,
+                       const int32_t *rows, const int32_t *count, int max_rows, float alpha, void *stream);
+/* idx_out[0 .. *count_out) = ascending indices of the rows of x [rows, cols] that hold a non-zero; flag_ws: int32[rows].  */
+int nafae_nonzero_rows(const float *x, int rows, int cols, int32_t *flag_ws, int32_t *idx_out, int32_t *count_out,
+                       void *stream);
+
 /* First VGG layer: 3x3 conv (pad 1) + bias + ReLU, Cin = 3, Cout = 64.  in: NCHW [F,3,H,W] exactly as
  * the reference feeds it (model.py:692-698); w: [64, 27] (= OIHW flattened); out: NHWC [F,H,W,64].
  * Replaces RCNN_base[0:2] (vgg16_rpn.py:38).  */
@@ -125,6 +134,10 @@ int nafae_proposals(const float *boxes, const float *scores, const int32_t *orde
  * RCNN_top.0.weight).  C % 2 == 0, C <= 1024.  */
 int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, const float *rois, int N,
                              float spatial_scale, float *out, void *stream);
+
+/* Frame preprocessing on device: uint8 [F,H,W,3] (BGR, as decoded) -> float NCHW [F,3,H,W] minus 127.5.
+ * Replaces `img.astype(np.float32) - 127.5` (lib/datasets/youcook2.py:212-214) + the permute of model.py:692-698.  */
+int nafae_frames_u8_to_nchw_f32(const uint8_t *frames_hwc, float *out_nchw, int F, int H, int W, void *stream);
 
 /* Layout helpers (weight re-layout at load; API-parity views): [N,C,H,W] <-> [N,H,W,C].  */
 int nafae_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream);

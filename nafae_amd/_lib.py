@@ -22,6 +22,8 @@ SIGNATURES = {
     "nafae_roi_align_forward": (c_int, [c_int, c_int, c_float, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
     "nafae_gemm_nt": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_float, c_int, P]),
     "nafae_gemm_tn": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    "nafae_gemm_tn_rows": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_float, P]),
+    "nafae_nonzero_rows": (c_int, [P, c_int, c_int, P, P, P, P]),
     "nafae_conv1_3x3_relu": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "nafae_conv3x3_relu": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "nafae_maxpool2x2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
@@ -29,6 +31,7 @@ SIGNATURES = {
     "nafae_sort_desc": (c_int, [P, P, c_int, c_int, P]),
     "nafae_proposals": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, P, P, P, P]),
     "nafae_roi_align_avg_nhwc": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, P, P]),
+    "nafae_frames_u8_to_nchw_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
     "nafae_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_split_bf16": (c_int, [P, P, P, c_int64, P]),

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const float *__restri
                                                            const float *__restrict__ B, int ldb,
                                                            float *__restrict__ C, int ldc, int M, int N, int K,
                                                            float alpha, int accumulate, int tiles_m, int tiles_n,
-                                                           int k_chunk) {
+                                                           int k_chunk, const int *__restrict__ rows,
+                                                           const int *__restrict__ count_ptr) {
   constexpr int TM = BM / 64, TN = BN / 64;  // waves 2 x 2
   constexpr int NA = BM / 32, NB = BN / 32;  // float4 chunks per thread per tile (32*BM/4/256)
   constexpr int STAGE = (BM + BN) * BK;
@@ -203,6 +204,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const float *__restri
   const int ks = blockIdx.x / tiles;  // split-K slice (atomic accumulate when > 1 slice)
   tile_coords(blockIdx.x - ks * tiles, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
+  if (rows) {  // row-gathered contraction: k runs over the first *count_ptr entries of `rows` (device-side count)
+    K = *count_ptr;
+    const int splits = gridDim.x / tiles;
+    k_chunk = ((((K + BK - 1) / BK) + splits - 1) / splits) * BK;
+  }
   const int k_begin = ks * k_chunk;
   const int k_end = min(K, k_begin + k_chunk);
   const int nk = (k_end - k_begin + BK - 1) / BK;
@@ -222,14 +228,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const float *__restri
       int c = tid + NTHREADS * i;
       int kr = c / (BM / 4), mc = c % (BM / 4);
       int k = k_begin + kt * BK + kr, m = m0 + mc * 4;
-      ra[i] = ldg4(A + (size_t)k * lda + m, k < k_end && m < M);
+      const bool okk = k < k_end;
+      const int rk = (rows && okk) ? rows[k] : k;
+      ra[i] = ldg4(A + (size_t)rk * lda + m, okk && m < M);
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) {
       int c = tid + NTHREADS * i;
       int kr = c / (BN / 4), nc = c % (BN / 4);
       int k = k_begin + kt * BK + kr, n = n0 + nc * 4;
-      rb[i] = ldg4(B + (size_t)k * ldb + n, k < k_end && n < N);
+      const bool okk = k < k_end;
+      const int rk = (rows && okk) ? rows[k] : k;
+      rb[i] = ldg4(B + (size_t)rk * ldb + n, okk && n < N);
     }
   };
   auto store = [&](float *stage) {
@@ -376,6 +386,22 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
   }
 }
 
+// uint8 HWC (BGR, as cv2.imread yields) -> float NCHW minus 127.5: the reference's per-frame preprocessing
+// (lib/datasets/youcook2.py:212-214) plus the NHWC->NCHW permute of the train loop (model.py:692-698), on device,
+// so frames cross PCIe as 1 byte per sample instead of 4.
+__global__ __launch_bounds__(256) void frames_u8_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int F, int H,
+                                                        int W) {
+  const long hw = (long)H * W, total = (long)F * hw;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const long f = p / hw, r = p - f * hw;
+    const uint8_t *px = in + p * 3;
+    float *o = out + f * 3 * hw + r;
+    o[0] = (float)px[0] - 127.5f;
+    o[hw] = (float)px[1] - 127.5f;
+    o[2 * hw] = (float)px[2] - 127.5f;
+  }
+}
+
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 // launch failures (bad configuration, missing code object, wrong runtime) must be loud, never silent
 inline int launched() { return hipGetLastError() == hipSuccess ? NAFAE_OK : NAFAE_ELAUNCH; }
@@ -439,7 +465,25 @@ int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, in
     if (e != hipSuccess) return NAFAE_EINVAL;
   }
   hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tiles * splits), dim3(NTHREADS), lds, S(stream), A, lda, B, ldb, C,
-                     ldc, M, N, K, alpha, accumulate, tiles_m, tiles_n, k_chunk);
+                     ldc, M, N, K, alpha, accumulate, tiles_m, tiles_n, k_chunk, nullptr, nullptr);
+  return launched();
+}
+
+int nafae_gemm_tn_rows(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, const int32_t *rows,
+                       const int32_t *count, int max_rows, float alpha, void *stream) {
+  if (!A || !B || !C || !rows || !count || M <= 0 || N <= 0 || max_rows <= 0) return NAFAE_EINVAL;
+  if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
+  constexpr int BM = 128, BN = 128;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * (BM + BN) * BK * sizeof(float);
+  const int tiles = tiles_m * tiles_n;
+  int splits = 1;
+  while (tiles * splits < 512 && splits < 8) splits *= 2;   // the k range is only known on the device: fixed split count
+  hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, S(stream));
+  if (e != hipSuccess) return NAFAE_EINVAL;
+  // (gridDim.x > tiles selects the atomic epilogue; with a single slice plain stores are used)
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tiles * splits), dim3(NTHREADS), lds, S(stream), A, lda, B, ldb, C, ldc, M,
+                     N, max_rows, alpha, 0, tiles_m, tiles_n, 0, rows, count);
   return launched();
 }
 
@@ -486,6 +530,14 @@ int nafae_nhwc_to_nchw(const float *in, float *out, int N, int C, int H, int W, 
   int rows = H * W, cols = C;
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, S(stream), in, out,
                      rows, cols);
+  return launched();
+}
+
+int nafae_frames_u8_to_nchw_f32(const uint8_t *frames_hwc, float *out_nchw, int F, int H, int W, void *stream) {
+  if (!frames_hwc || !out_nchw || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
+  const long total = (long)F * H * W;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(frames_u8_kernel, dim3(blocks), dim3(256), 0, S(stream), frames_hwc, out_nchw, F, H, W);
   return launched();
 }
 

@@ -645,6 +645,51 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ non-zero rows
+// The gradient wrt the visual embedding is non-zero only on the rows some (frame, query) picked as its arg-max (plus
+// the clustering rows): >= 85 % of the R rows are exactly zero.  rowflag + compact build the ascending list of the
+// others on the device, and the weight-gradient GEMM contracts over that list only (nafae_gemm_tn_rows).
+__global__ __launch_bounds__(256) void rowflag_kernel(const float *__restrict__ x, int rows, int cols, int *__restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  bool nz = false;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (size_t)r * cols + c);
+    nz = nz || v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f;
+  }
+  const unsigned long long any = __ballot(nz);
+  if (lane == 0) flag[r] = any != 0ull;
+}
+
+__global__ __launch_bounds__(1024) void compact_kernel(const int *__restrict__ flag, int rows, int *__restrict__ idx,
+                                                       int *__restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r0 = 0; r0 < rows; r0 += 1024) {
+    const int r = r0 + threadIdx.x;
+    const bool f = r < rows && flag[r] != 0;
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (f) idx[off + before] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += wsum[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[0] = base;
+}
+
 // ------------------------------------------------------------------------------------------------ optimiser step
 // clip_grad_norm_ + Adam (model.py:773-774, :1077-1082) over ONE flat buffer: pass 1 = per-block sums of squares in
 // a fixed order, pass 2 = every block re-adds the partials in the same order (bit-identical total on all blocks),
@@ -687,6 +732,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
 }  // namespace
 
 extern "C" {
+
+int nafae_nonzero_rows(const float *x, int rows, int cols, int32_t *flag_ws, int32_t *idx_out, int32_t *count_out,
+                       void *stream) {
+  if (!x || !flag_ws || !idx_out || !count_out || rows <= 0 || cols <= 0 || (cols & 3)) return NAFAE_EINVAL;
+  hipLaunchKernelGGL(rowflag_kernel, dim3((rows + 3) / 4), dim3(256), 0, S(stream), x, rows, cols, flag_ws);
+  hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, S(stream), flag_ws, rows, idx_out, count_out);
+  return launched();
+}
 
 int nafae_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_norm, int step, float *workspace,

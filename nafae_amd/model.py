@@ -111,7 +111,9 @@ class _VisEbdFn(torch.autograd.Function):
         feats, y, mask = ctx.saved_tensors
         with ops.timed("vis_ebd_bwd"):
             gpre = ops.dropout_tanh_bwd(gy.contiguous(), y, mask, ctx.scale)
-            gw = ops.gemm_tn(gpre, feats, alpha=0.01)               # [D, 4096]
+            # only the arg-max (and clustering) rows carry gradient: contract over those rows alone
+            rows, count = ops.nonzero_rows(gpre)
+            gw = ops.gemm_tn_rows(gpre, feats, rows, count, alpha=0.01)   # [D, 4096]
             gb = ops.colsum(gpre)
         return None, gw, gb, None, None
 

@@ -109,6 +109,28 @@ def gemm_tn(A, B, alpha=1.0, out=None, accumulate=False):
     return out
 
 
+def nonzero_rows(x):
+    """-> (idx int32 [rows] (first `count` valid, ascending), count int32 [1]) -- all on the device, no host sync."""
+    _chk(x)
+    rows, cols = x.shape
+    flag = torch.empty(rows, device=x.device, dtype=torch.int32)
+    idx = torch.empty(rows, device=x.device, dtype=torch.int32)
+    count = torch.empty(1, device=x.device, dtype=torch.int32)
+    _rc(_lib.lib().nafae_nonzero_rows(_p(x), rows, cols, _p(flag), _p(idx), _p(count), _stream()), "nafae_nonzero_rows")
+    return idx, count
+
+
+def gemm_tn_rows(A, B, rows, count, alpha=1.0):
+    """alpha * sum over the listed rows r of A[r,:]^T B[r,:]; A [K,M], B [K,N]."""
+    _chk(A); _chk(B); _chk(rows, torch.int32); _chk(count, torch.int32)
+    K, M = A.shape
+    N = B.shape[1]
+    out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_gemm_tn_rows(_p(A), M, _p(B), N, _p(out), N, M, N, _p(rows), _p(count), K, float(alpha), _stream()),
+        "nafae_gemm_tn_rows")
+    return out
+
+
 def conv1_3x3_relu(x_nchw, w27, bias):
     _chk(x_nchw); _chk(w27); _chk(bias)
     F, C, H, W = x_nchw.shape
@@ -137,6 +159,17 @@ def maxpool2x2(x_nhwc):
     F, H, W, C = x_nhwc.shape
     out = torch.empty(F, H // 2, W // 2, C, device=x_nhwc.device, dtype=torch.float32)
     _rc(_lib.lib().nafae_maxpool2x2(_p(x_nhwc), _p(out), F, H, W, C, _stream()), "nafae_maxpool2x2")
+    return out
+
+
+def frames_u8_to_nchw_f32(frames_u8):
+    """uint8 [F,H,W,3] BGR -> float32 [F,3,H,W] minus 127.5 (youcook2.py:212-214 + model.py:692-698)."""
+    _chk(frames_u8, torch.uint8, "frames")
+    F, H, W, C = frames_u8.shape
+    if C != 3:
+        raise NafaeOpError("frames must be [F,H,W,3]")
+    out = torch.empty(F, 3, H, W, device=frames_u8.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_frames_u8_to_nchw_f32(_p(frames_u8), _p(out), F, H, W, _stream()), "nafae_frames_u8_to_nchw_f32")
     return out
 
 

@@ -110,3 +110,17 @@ def validate_segment(model, batch, vid_entities, img_ids, args, dets):
     Dp, Sp = postprocess(D.cpu().numpy(), D_sim.cpu().numpy(), Na, Ns, Nb, Ne)
     record_det(dets[0], dets[1], dets[2], dets[3], Nb, vid_entities, Dp, Sp, img_ids, boxes)
     return float(margin_loss)
+
+
+def combine_batches_synthetic(Na, Ns, Ne, H=224, W=224, seed=1234, vocab=('bowl', 'egg', 'pan', 'oil', 'salt', 'water')):
+    """The 8-tuple the reference's DataLoader hands to train()/validate() (lib/datasets/youcook2.py:254-308,
+    unpacked at model.py:684), filled with synthetic content of the right shapes and types:
+    (im_blobs float32 [F,H,W,3] BGR-127.5, entities [str], entities_length [Na], frm_length [Na], rl_seg_inds [Na],
+     seg_nums [Na], im_paths [F], img_ids [F])."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    lens = syn.entity_lengths(Na, Ne, seed=seed)
+    blobs = rs.randint(0, 255, (Na * Ns, H, W, 3)).astype(np.float32) - 127.5
+    entities = [vocab[i] for l in lens for i in rs.randint(0, len(vocab), l)]
+    im_paths = ['synthetic/vid%03d/%04d%06d.jpg' % (a, a, s) for a in range(Na) for s in range(Ns)]   # genframes.py:97 naming
+    return blobs, entities, lens, [Ns] * Na, list(range(Na)), [Na] * Na, im_paths, list(range(Na * Ns))

@@ -68,6 +68,20 @@ def test_gemm_tn(ops, K, M, N):
     assert relerr(out, ref) < TOL
 
 
+@pytest.mark.parametrize("K,M,N,frac", [(4000, 512, 256, 0.1), (1000, 128, 132, 0.0), (2049, 64, 64, 1.0), (70, 4, 8, 0.5)])
+def test_gemm_tn_rows_and_nonzero_rows(ops, K, M, N, frac):
+    A, B = rnd(14, K, M), rnd(15, K, N)
+    keep = torch.rand(K, generator=torch.Generator().manual_seed(K)) < frac
+    if frac == 0.5:
+        keep[0] = keep[-1] = True
+    A = A * keep[:, None]
+    rows, count = ops.nonzero_rows(dev(A))
+    n = int(count.cpu())
+    assert n == int(keep.sum()) and rows.cpu()[:n].tolist() == torch.nonzero(keep).view(-1).tolist()
+    out = ops.gemm_tn_rows(dev(A), dev(B), rows, count, alpha=0.01).cpu()
+    assert relerr(out, 0.01 * (A.double().T @ B.double())) < TOL if n else float(out.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("Fr,H,W,Cin,Cout,relu", [(2, 14, 14, 64, 64, True), (1, 6, 5, 32, 132, False),
                                                   (3, 9, 11, 96, 512, True), (1, 28, 28, 128, 128, True)])
 def test_conv3x3(ops, Fr, H, W, Cin, Cout, relu):
@@ -101,6 +115,14 @@ def test_maxpool_and_layout(ops):
     assert torch.equal(ops.nhwc_to_nchw(dev(xh)).cpu(), x)
     y = rnd(13, 3, 37, 5, 7)
     assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(dev(y))).cpu(), y)
+
+
+def test_frames_u8_preprocessing(ops):
+    """uint8 BGR HWC -> float NCHW - 127.5: youcook2.py:212-214 followed by the permute of model.py:692-698 (bit-exact)."""
+    fr = torch.randint(0, 256, (3, 20, 18, 3), generator=torch.Generator().manual_seed(4), dtype=torch.int32).to(torch.uint8)
+    ref = (fr.numpy().astype(np.float32) - 127.5).transpose(0, 3, 1, 2)
+    out = ops.frames_u8_to_nchw_f32(dev(fr)).cpu().numpy()
+    assert np.array_equal(out, ref)
 
 
 # ------------------------------------------------------------------------------------------------ proposal path
