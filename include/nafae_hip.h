@@ -168,9 +168,11 @@ int nafae_conv1_3x3_relu_bf16(const float *in_nchw, const float *w, const float 
                               int F, int H, int W, void *stream);
 int nafae_maxpool2x2_bf16(const void *in_hi, const void *in_lo, void *out_hi, void *out_lo, int F, int H, int W,
                           int C, void *stream);                                          /* C % 8 == 0 */
+/* out_f32 (may be NULL): the same values as a dense fp32 [N,7,7,C] tensor (what nafae_merge_bf16 would give), written
+ * in the same pass -- the reference's `pooled_feat` return value without a second sweep.  */
 int nafae_roi_align_avg_nhwc_bf16(const void *feat_hi, const void *feat_lo, int F, int H, int W, int C,
                                   const float *rois, int N, float spatial_scale, void *out_hi, void *out_lo,
-                                  void *stream);
+                                  float *out_f32, void *stream);
 
 /* ---- similarity + loss (DVSA.forward, model.py:517-614) ---------------------------------------- */
 

@@ -315,7 +315,7 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 // Planes may be separate tensors or interleaved per 32 channels (lo == hi + 32 elements: "I32", see bf16_tile.h).
 __global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf16 *fhi, const __bf16 *flo, int H, int W, int C,
                                                                       const float *__restrict__ rois, float scale, __bf16 *ohi,
-                                                                      __bf16 *olo) {
+                                                                      __bf16 *olo, float *__restrict__ of32) {
   const int n = blockIdx.x;
   const bool il = flo != nullptr && reinterpret_cast<const char *>(flo) == reinterpret_cast<const char *>(fhi) + 64;
   const int CS = il ? 2 * C : C;  // elements per pixel row behind one plane pointer
@@ -370,13 +370,16 @@ __global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf
 #pragma unroll
         for (int pw = 0; pw < PS; pw++) {
           bf16x4_t hv, lv;
+          f32x4 fv;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const float sv = (((prev[pw][q] + prev[pw + 1][q]) + cur[pw][q]) + cur[pw + 1][q]) / 4.0f;
             const __bf16 hq = (__bf16)sv;
             hv[q] = hq;
             lv[q] = (__bf16)(sv - (float)hq);
+            fv[q] = olo ? (float)hq + (float)lv[q] : (float)hq;   // exactly what merging the planes would give
           }
+          if (of32) *reinterpret_cast<f32x4 *>(of32 + (long)n * PS * PS * C + ((ph - 1) * PS + pw) * (long)C + c) = fv;
           const long o = ob + ((ph - 1) * PS + pw) * (long)CS + (il ? ((c >> 5) << 6) + (c & 31) : c);
           *reinterpret_cast<bf16x4_t *>(ohi + o) = hv;
           if (olo) *reinterpret_cast<bf16x4_t *>(olo + o) = lv;
@@ -471,12 +474,12 @@ int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, cons
 }
 
 int nafae_roi_align_avg_nhwc_bf16(const void *feat_hi, const void *feat_lo, int F, int H, int W, int C, const float *rois,
-                                  int N, float spatial_scale, void *out_hi, void *out_lo, void *stream) {
+                                  int N, float spatial_scale, void *out_hi, void *out_lo, float *out_f32, void *stream) {
   if (!feat_hi || !rois || !out_hi || F <= 0 || H < 2 || W < 2 || C <= 0 || N <= 0) return NAFAE_EINVAL;
   if (C & 3) return NAFAE_EINVAL;
   if ((feat_lo == nullptr) != (out_lo == nullptr)) return NAFAE_EINVAL;
   hipLaunchKernelGGL(roi_align_avg_nhwc_bf16_kernel, dim3(N), dim3(128), 0, S(stream), (const __bf16 *)feat_hi,
-                     (const __bf16 *)feat_lo, H, W, C, rois, spatial_scale, (__bf16 *)out_hi, (__bf16 *)out_lo);
+                     (const __bf16 *)feat_lo, H, W, C, rois, spatial_scale, (__bf16 *)out_hi, (__bf16 *)out_lo, out_f32);
   return launched();
 }
 

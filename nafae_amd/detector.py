@@ -233,15 +233,16 @@ class _fasterRCNN(nn.Module):
                 rois, roi_scores = self.proposals(base_feat, im_info)
             R = rois.shape[0] * rois.shape[1]
             if self.precision != 'f32':
-                with ops.timed("roi_align"):
-                    pooled = ops.roi_align_avg_nhwc_bf16(base_feat, rois.view(R, 5), 1.0 / 16.0)
+                with ops.timed("roi_align"):   # planes for fc6 and (API parity) the fp32 pooled_feat in one pass
+                    if self.materialize_pooled:
+                        pooled_pl, pooled = ops.roi_align_avg_nhwc_bf16(base_feat, rois.view(R, 5), 1.0 / 16.0, want_f32=True)
+                    else:
+                        pooled_pl, pooled = ops.roi_align_avg_nhwc_bf16(base_feat, rois.view(R, 5), 1.0 / 16.0), None
                 with ops.timed("fc6"):
-                    _, fc6 = ops.gemm_nt_bf16(pooled.view(R, -1), P['fc6_w_h'], P['fc6_b'], act=ops.ACT_RELU)
+                    _, fc6 = ops.gemm_nt_bf16(pooled_pl.view(R, -1), P['fc6_w_h'], P['fc6_b'], act=ops.ACT_RELU)
                 with ops.timed("fc7"):
                     fc7, _ = ops.gemm_nt_bf16(fc6, P['fc7_w_h'], P['fc7_b'], act=ops.ACT_RELU, want_f32=True,
                                               want_planes=False)
-                with ops.timed("pooled_f32"):
-                    pooled = ops.merge_bf16(pooled) if self.materialize_pooled else None
             else:
                 with ops.timed("roi_align"):
                     pooled = ops.roi_align_avg_nhwc(base_feat, rois.view(R, 5), 1.0 / 16.0)  # [R,7,7,512]

@@ -308,14 +308,16 @@ def maxpool2x2_bf16(X):
     return P
 
 
-def roi_align_avg_nhwc_bf16(X, rois, spatial_scale):
+def roi_align_avg_nhwc_bf16(X, rois, spatial_scale, want_f32=False):
+    """-> Planes [N,7,7,C] (and, with want_f32, the same values as an fp32 tensor written in the same pass)."""
     _chk_planes(X); _chk(rois)
     F, H, W, C = X.shape
     N = rois.shape[0]
     P = _alloc_planes((N, 7, 7, C), rois.device, X.lo is not None, X.il)
+    f32 = torch.empty(N, 7, 7, C, device=rois.device, dtype=torch.float32) if want_f32 else None
     _rc(_lib.lib().nafae_roi_align_avg_nhwc_bf16(_p(X.hi), _p(X.lo), F, H, W, C, _p(rois), N, float(spatial_scale), _p(P.hi), _p(P.lo),
-                                                 _stream()), "nafae_roi_align_avg_nhwc_bf16")
-    return P
+                                                 _p(f32), _stream()), "nafae_roi_align_avg_nhwc_bf16")
+    return (P, f32) if want_f32 else P
 
 
 # ------------------------------------------------------------------------------------------------ proposals

@@ -134,6 +134,8 @@ def test_conv1_maxpool_roialign_planes(ops):
     fi = ops.split_bf16(dev(torch.from_numpy(f).permute(0, 2, 3, 1).contiguous()), il=True)
     outi = ops.merge_bf16(ops.roi_align_avg_nhwc_bf16(fi, dev(rois), 1 / 16.)).cpu().permute(0, 3, 1, 2).numpy()
     assert np.array_equal(outi, out)
+    pl, f32 = ops.roi_align_avg_nhwc_bf16(fi, dev(rois), 1 / 16., want_f32=True)
+    assert torch.equal(f32, ops.merge_bf16(pl))       # the fused fp32 copy == merging the planes
 
 
 def _detector(seed, precision):
