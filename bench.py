@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run detector and tail of a step back to back on one stream (default: the frozen detector of step "
+                         "k+1 overlaps the embedding/loss/backward/optimiser tail of step k on a second HIP stream)")
     ap.add_argument("--no-other-precisions", action="store_true",
                     help="skip the short extra runs in the other two arithmetic modes (N = 1 only)")
     ap.add_argument("--precision", default=os.environ.get("NAFAE_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
@@ -122,7 +125,7 @@ def main():
     from nafae_amd import ops
     from nafae_amd.config import cfg, cfg_from_file, reset_cfg
     from nafae_amd.model import default_args
-    from nafae_amd.train import make_batch, setup_training, train_step
+    from nafae_amd.train import PipelinedTrainer, make_batch, setup_training, train_step
 
     Na, Ns, Nb, Ne = WORKLOADS[a.workload]
     reset_cfg()
@@ -138,13 +141,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        train_step(model, opt, crit, batch, args, reducer)
+    pipe = None if a.no_pipeline else PipelinedTrainer(model, opt, crit, args, reducer)
+
+    def run_steps(n):
+        """exactly n detector forwards and n tails; everything is enqueued inside the caller's timed region"""
+        if pipe is None:
+            for _ in range(n):
+                loss, _, _, _ = train_step(model, opt, crit, batch, args, reducer)
+            return loss
+        pipe.submit(batch)
+        for i in range(n):
+            loss, _, _, _ = pipe.step(batch if i + 1 < n else None)
+        return loss
+
+    if a.warmup:
+        run_steps(a.warmup)
     sync()
     ops.profile_reset(enable=True)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, _, _, _ = train_step(model, opt, crit, batch, args, reducer)
+    loss = run_steps(a.steps)
     sync()
     dt = time.perf_counter() - t0
     prof = ops.profile_summary()
@@ -167,7 +182,8 @@ def main():
             "config": {"workload": "%s: %d frames 224x224 per GPU (Na=%d,Ns=%d), %d proposals/frame, %d query slots/segment, "
                                    "VGG16 random-init, full train step" % (a.workload.upper(), F, Na, Ns, Nb, Ne),
                        "frames_per_gpu": F, "proposals_per_frame": Nb, "queries_per_segment": Ne,
-                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": reducer.nbytes if distributed else 0},
+                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
+                       "step_pipeline": "detector(k+1) overlaps tail(k) on a second stream" if pipe else "sequential"},
             "loss": round(float(loss), 5),
         }
         # dominant kernel: fc6 = [R,25088] x [4096,25088]^T on fp32 MFMA

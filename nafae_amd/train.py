@@ -32,10 +32,13 @@ def build_model(args=None, device='cuda', seed=1234, heads=False):
     sd = syn.detector_state(seed=seed, heads=heads)
     model.fasterRCNN.load_state_dict(sd, strict=heads)
     g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():       # deterministic trainable weights (same on every rank)
-        for p in trainable_parameters(model):
+    with torch.no_grad():       # deterministic trainable parameters: every rank / every run starts from the same model
+        for name, p in list(model.vis_ebd.named_parameters()) + list(model.word_ebd.named_parameters()):
             if p.dim() > 1:
                 p.copy_(torch.randn(p.shape, generator=g) * (1.0 / p.shape[1]) ** 0.5)
+            elif name.endswith('fc1.bias'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+            # (BatchNorm weight / bias keep their deterministic 1 / 0 defaults)
     return model.to(device)
 
 
@@ -69,6 +72,60 @@ def train_step(model, optimizer, criterion, batch, args, reducer=None):
     return loss.detach(), D, D_sim, rois
 
 
+class PipelinedTrainer:
+    """Software pipeline over training steps: the frozen detector forward of step k+1 runs on its own HIP stream while
+    the embedding / loss / backward / all-reduce / optimiser tail of step k runs on the main stream.
+
+    Legal because the detector is frozen (model.py:706-707 runs it under no_grad and nothing the optimiser updates feeds
+    it), so its output for batch k+1 does not depend on step k.  The tail is ~1.3 ms of small, latency-bound kernels
+    (one-workgroup loss tail, 8.8 MB all-reduce, Adam) that leave most CUs idle; the conv / fc kernels of the next
+    step fill them.  This is the overlap SURVEY.md section 8(e) asks for ("overlap with the detector forward of the next
+    step"), applied to the whole tail.  Every step still does exactly one detector forward and one tail."""
+
+    def __init__(self, model, optimizer, criterion, args, reducer):
+        self.model, self.optimizer, self.criterion, self.args, self.reducer = model, optimizer, criterion, args, reducer
+        self.det_stream = torch.cuda.Stream()
+        self.pending = None
+
+    def submit(self, batch):
+        """Enqueue the detector forward for `batch` on the detector stream (returns immediately)."""
+        main = torch.cuda.current_stream()
+        self.det_stream.wait_stream(main)          # inputs (and any weight re-packing) issued so far are visible
+        with torch.cuda.stream(self.det_stream):
+            with torch.no_grad():
+                rois, roi_scores, roi_feats, fc_feats = self.model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes,
+                                                                              batch.num_boxes)
+            ev = torch.cuda.Event()
+            ev.record(self.det_stream)
+        self.pending = (batch, rois, fc_feats, ev)
+
+    def step(self, next_batch=None):
+        """Finish the step whose detector forward was submitted last; first put `next_batch`'s detector in flight."""
+        assert self.pending is not None, "call submit(batch) first"
+        batch, rois, fc_feats, ev = self.pending
+        self.pending = None
+        if next_batch is not None:
+            self.submit(next_batch)
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        for t in (rois, fc_feats):                 # produced on the detector stream, consumed here
+            t.record_stream(main)
+        model, args = self.model, self.args
+        vis_feats = model.vis_ebd(fc_feats)
+        word_feats = model.word_ebd(batch.glove_feats)
+        self.reducer.zero_grad()
+        D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
+        loss = self.criterion(margin_loss, torch.zeros_like(margin_loss))
+        loss.backward()
+        self.reducer.allreduce()
+        if isinstance(self.optimizer, FusedClipAdam):
+            self.optimizer.step()
+        else:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
+            self.optimizer.step()
+        return loss.detach(), D, D_sim, rois
+
+
 def eval_step(model, batch):
     """Forward of validate() (model.py:875-947) for one segment batch."""
     with torch.no_grad():
@@ -82,6 +139,9 @@ def eval_step(model, batch):
 
 def setup_training(args, device='cuda', seed=1234, distributed=False):
     model = build_model(args, device=device, seed=seed)
+    if distributed:
+        from .parallel import broadcast_parameters
+        broadcast_parameters(model, src=0)       # belt and braces: replicas start bit-identical
     model.train()
     model.DVSA.init_train()
     model.fasterRCNN.eval()                      # model.py:671-673

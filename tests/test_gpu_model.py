@@ -241,3 +241,24 @@ def test_validate_path_end_to_end(gpu):
     for r in recs:
         r['bbox'] = [np.array([1000., 1000., 1010., 1010.]) for _ in r['bbox']]
     assert E.evaluate_box(recs, dets, classes) == 0.0
+
+
+def test_pipelined_trainer_equals_sequential(gpu):
+    """detector(k+1) overlapped with tail(k) on a second stream gives the same training trajectory as the sequential
+    loop (the detector is frozen, so nothing it computes depends on the previous optimiser step)."""
+    from nafae_amd.model import default_args
+    from nafae_amd.train import PipelinedTrainer, make_batch, setup_training, train_step
+    Na, Ns, Ne, Nb = 2, 4, 8, 16
+    gpu.TEST.RPN_POST_NMS_TOP_N = Nb
+    args = default_args(batch_size=Na, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13, dropout_rate=0.0)
+    batches = [make_batch(Na, Ns, Ne, H=96, W=80, seed=10 + i, lens=[3, 5]) for i in range(4)]
+    m1, o1, c1, r1 = setup_training(args, seed=3)
+    seq = [float(train_step(m1, o1, c1, b, args, r1)[0]) for b in batches]
+    m2, o2, c2, r2 = setup_training(args, seed=3)
+    pipe = PipelinedTrainer(m2, o2, c2, args, r2)
+    pipe.submit(batches[0])
+    par = [float(pipe.step(batches[i + 1] if i + 1 < len(batches) else None)[0]) for i in range(len(batches))]
+    torch.cuda.synchronize()
+    assert np.allclose(seq, par, rtol=1e-5), (seq, par)
+    assert len(set(seq)) > 1                                        # the trajectory actually moves
+    assert relerr(m2.vis_ebd.fc1.weight.detach().cpu(), m1.vis_ebd.fc1.weight.detach().cpu()) < 1e-5
