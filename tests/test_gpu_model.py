@@ -262,3 +262,31 @@ def test_pipelined_trainer_equals_sequential(gpu):
     assert np.allclose(seq, par, rtol=1e-5), (seq, par)
     assert len(set(seq)) > 1                                        # the trajectory actually moves
     assert relerr(m2.vis_ebd.fc1.weight.detach().cpu(), m1.vis_ebd.fc1.weight.detach().cpu()) < 1e-5
+
+
+def test_reference_default_shapes(gpu):
+    """The reference's own default configuration (model.py:109-111,181-183,214-216; cfgs/vgg16.yml:14): Na=8 segments x
+    Ns=5 frames of 224x224, Nb=20 proposals per frame, Ne=13 query slots -- R=800, Q=104, none of them tile multiples."""
+    from nafae_amd.config import cfg_from_file, reset_cfg
+    from nafae_amd.model import default_args
+    from nafae_amd.train import eval_step, make_batch, setup_training, train_step
+    from oracle import dvsa as O
+    reset_cfg()
+    cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
+    args = default_args(Delta=10.0, vis_lam=4.13, dropout_rate=0.0)
+    Na, Ns, Ne, Nb = args.batch_size, args.sample_num, args.max_ent_len, gpu.TEST.RPN_POST_NMS_TOP_N
+    assert (Na, Ns, Ne, Nb) == (8, 5, 13, 20)
+    model, opt, crit, red = setup_training(args, seed=11)
+    batch = make_batch(Na, Ns, Ne, seed=11)
+    with torch.no_grad():
+        rois, _, pooled, fc7 = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+    assert tuple(rois.shape) == (40, 20, 5) and tuple(fc7.shape) == (800, 4096) and tuple(pooled.shape) == (800, 512, 7, 7)
+    V, W = model.vis_ebd(fc7), model.word_ebd(batch.glove_feats)
+    D, Ds, L = model.DVSA(V, W, batch.entities_length)
+    Do, Dso, Lo = O.dvsa_forward(V.detach().cpu(), W.detach().cpu(), batch.entities_length, Na, Nb, Ne, 10.0, 4.13, "train")
+    assert torch.equal(D.cpu(), Do) and relerr(Ds.detach().cpu(), Dso) < TOL and abs(float(L) - float(Lo)) < TOL * abs(float(Lo))
+    l0 = float(train_step(model, opt, crit, batch, args, red)[0])
+    l1 = float(train_step(model, opt, crit, batch, args, red)[0])
+    assert np.isfinite([l0, l1]).all() and l1 != l0
+    reset_cfg()
+    cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
