@@ -198,7 +198,7 @@ def main():
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),
                                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "algorithmic_tflops": round(fl / (fc6["avg_ms"] * 1e-3) / 1e12, 2),
-                               "traffic": (pmc_traffic({"f32": "gemm_nt_fc6", "bf16x3": "gemm_bf16x3_fc6_256x256"}.get(a.precision, ""))
+                               "traffic": (pmc_traffic({"f32": "gemm_nt_fc6", "bf16x3": "gemm_bf16x3_fc6_256x256_il"}.get(a.precision, ""))
                                            if a.workload == "c2" else None),
                                "algorithmic": 4.0 * (R * 25088 + 4096 * 25088 + R * 4096),
                                "avg_ms": round(fc6["avg_ms"], 4), "launches": fc6["n"]}

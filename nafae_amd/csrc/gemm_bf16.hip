@@ -36,14 +36,14 @@ __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, flo
                                          __bf16 *__restrict__ Clo, int ldc) {
   const bool oil = SPLIT && plane_il(Chi, Clo);
 #pragma unroll
-  for (int j = 0; j < E::TX; j++) {
-    const int m = m0 + e.out_m(j);
+  for (int j = 0; j < E::NJ; j++) {
+    const int m = m0 + e.pm(j);
     if (m >= M) continue;
 #pragma unroll
-    for (int i = 0; i < E::TW; i++)
+    for (int i = 0; i < E::NI; i++)
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int n = n0 + e.out_n(i, g);
+      for (int g = 0; g < E::NG; g++) {
+        const int n = n0 + e.pn(i, g);
         if (n >= N) continue;
         f32x4 v;
 #pragma unroll
@@ -225,14 +225,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST, bool IL>
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST, bool IL, bool S16>
 __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const __bf16 *Xlo, int ldx, const __bf16 *Whi,
                                                         const __bf16 *Wlo, int ldw,
                                                         float *__restrict__ Cf, __bf16 *__restrict__ Chi,
                                                         __bf16 *__restrict__ Clo, int ldc, const float *__restrict__ bias,
                                                         int M, int N, int K, float alpha, int act, int tiles_m, int tiles_n,
                                                         int H, int W, int Cin) {
-  using E = EngineH<BX, BW, WX, WW, SPLIT, IL>;
+  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, S16>;
   using L = typename E::L;
   static_assert(E::CHUNKS % NT16 == 0, "LDS-DMA path needs every lane active in every staging instruction");
   static_assert(NST == 2 || NST == 3, "ring of 2 or 3 LDS stages");
@@ -267,10 +267,6 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
     else
       L::template decode<BW>(id - E::XCH, row, plane, slot);
     const bool dbg_zero = act == -1;        // timing experiment only (act = -1): every staging load hits the zero page
-    if (act == -4 && !IL) {  // timing experiment only: 8 full 128-B lines per staging instruction instead of 16 half lines
-      slot = (id & 3) + 4 * (row & 1);
-      row &= ~1;
-    }
     kslot[i] = slot * 8;
     tapmask[i] = 0x1ffu;
     if (!isw[i]) {
@@ -297,7 +293,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
   const int wave = threadIdx.x >> 6;
   // one staging instruction (chunk i of k-tile kt -> LDS stage `stage`)
   const bool dbg_l2 = act == -2;            // timing experiment only: re-read the first 4 k-tiles (everything L2-resident)
-  const int kstep = (act == -3 || act == -4) ? 2 * BKH : L::KTS;  // (-3/-4: timing experiments only)
+  constexpr int kstep = L::KTS;
   auto issue_one = [&](int i, int kt, int stage) {
     if (dbg_l2) kt &= 3;
     int aoff = kt * BKH, tap = 0;
@@ -325,7 +321,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
 #pragma unroll
     for (int i = 0; i < E::NCH; i++) issue_one(i, kt, stage);
   };
-  constexpr int NGRP = 2 * E::TW * E::TX;  // accumulator-tile groups per k-tile
+  constexpr int NGRP = E::NGRP;  // accumulator-tile groups per k-tile
 
   issue(0, 0);
   if (DIST > 1 && nk > 1) issue(1, 1);
@@ -360,7 +356,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
 // per-lane mask says which taps of that lane's output pixel fall inside the image; the others are zeroed in registers.
 // Weights stream per tap through their own LDS ring exactly as in bf16_dma_kernel.  Step order: channel chunk (32) ->
 // dy -> dx; one raw barrier and one counted vmcnt wait per step.
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX = 256>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16>
 __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
                                                            const float *__restrict__ bias, float *__restrict__ Cf,
                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
@@ -370,14 +366,14 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
   // pixel count is 49 * 2^k give 3.06 / 1.53 / 0.77 workgroups per CU with 256-pixel tiles but 3.5 / 1.75 / 0.875 with 224
   static_assert(BX == 256 || (BX == 224 && SPLIT), "tile of 256 pixels, or 224 for the split path");
   constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384), ROFF = BX == 224 ? 16 : 32;
-  using E = EngineH<BX, BW, WX, WW, SPLIT, IL>;
+  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, S16>;
   using L = typename E::L;
   if (IL) {
     Xlo = Xhi + BKH;
     Wlo = Whi + BKH;
   }
   const int CinS = Cin * L::RS;  // elements per pixel row / per weight tap (both planes when interleaved)
-  constexpr int TX = E::TX, TW = E::TW;
+  constexpr int TX = E::TX, TW = E::TW, NI = E::NI, NJ = E::NJ, MS = E::MS;
   constexpr int XRUN = RR * BKH * PL;   // bf16 elements per activation-run buffer
   constexpr int WST = BW * BKH * PL;    // bf16 elements per weight stage
   constexpr int NXC = RR * 4 * PL / NT16;
@@ -385,7 +381,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
   static_assert(RR * 4 * PL % NT16 == 0 && BW * 4 * PL % NT16 == 0, "every lane active in every staging instruction");
   constexpr int DIST = NSTW - 1;
   static_assert(NSTW == 2 || NSTW == 3, "weight ring of 2 or 3 stages");
-  constexpr int NGRP = 2 * TW * TX;
+  constexpr int NGRP = E::NGRP;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   __bf16 *xbuf = smem16;
   __bf16 *wbuf = smem16 + 2 * XRUN;
@@ -422,10 +418,10 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
     wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
   }
   // which taps of this lane's output pixels are inside the image
-  unsigned tapmask[TX];
+  unsigned tapmask[NJ];
 #pragma unroll
-  for (int j = 0; j < TX; j++) {
-    const int m = m0 + e.out_m(j);
+  for (int j = 0; j < NJ; j++) {
+    const int m = m0 + e.pm(j);
     unsigned mk = 0;
     if (m < M) {
       const int x = m % W, y = (m / W) % H;
@@ -464,7 +460,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
       for (int i = 0; i < NWC; i++) issue_w(i, d);
     }
 
-  const int r31 = lane & 31, hh = lane >> 5;
+  const int fr = e.frow();
   for (int st = 0; st < nst; st++) {
     // everything issued after W(st) may stay in flight: that is what step st-1 issued (only when DIST == 2)
     if (DIST == 1 || st + 1 >= nst) {
@@ -498,36 +494,33 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
     const __bf16 *sX = xbuf + (size_t)(grp & 1) * XRUN;
     const __bf16 *sW = wbuf + (size_t)(st % NSTW) * WST;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      bf16x8 xa[PL][TX], wa[PL][TW];
+    for (int s = 0; s < E::KSTEPS; s++) {
+      const int sl = e.fslot(s);
+      bf16x8 xa[NJ][PL];
 #pragma unroll
-      for (int j = 0; j < TX; j++) {
-        const int rrow = e.wx * (TX * 32) + j * 32 + r31 + ROFF + dx;
+      for (int j = 0; j < NJ; j++) {
+        const int rrow = e.wx * (TX * 32) + j * MS + fr + ROFF + dx;
         const bool on = (tapmask[j] >> tap) & 1u;
 #pragma unroll
         for (int p = 0; p < PL; p++) {
-          bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, 2 * s + hh)]);
+          bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, sl)]);
           const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-          xa[p][j] = on ? v : z;
+          xa[j][p] = on ? v : z;
         }
       }
 #pragma unroll
-      for (int p = 0; p < PL; p++)
+      for (int i = 0; i < NI; i++) {
+        bf16x8 wa[PL];
 #pragma unroll
-        for (int i = 0; i < TW; i++)
-          wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * 32 + r31, p, 2 * s + hh)]);
+        for (int p = 0; p < PL; p++)
+          wa[p] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * MS + fr, p, sl)]);
 #pragma unroll
-      for (int i = 0; i < TW; i++)
-#pragma unroll
-        for (int j = 0; j < TX; j++) {
-          if (SPLIT) {
-            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PL - 1][i], xa[0][j], e.acc[i][j], 0, 0, 0);
-            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[PL - 1][j], e.acc[i][j], 0, 0, 0);
-          }
-          e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], e.acc[i][j], 0, 0, 0);
-          const int g = s * TW * TX + i * TX + j;
+        for (int j = 0; j < NJ; j++) {
+          e.mma(i, j, wa, xa[j]);
+          const int g = s * NI * NJ + i * NJ + j;
           if (g < NGRP) between(g);
         }
+      }
     }
   }
   epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
@@ -538,20 +531,20 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
 // per-step barrier + waits cost as much as the matrix work): ONE barrier per row-offset group, i.e. per 3 taps.  The
 // three weight tap tiles of a group (8 KB each at 64 output channels) live in a 6-stage ring (2 groups), the
 // activation run ring is unchanged; every wait is vmcnt(0) on loads issued a whole group (36 MFMAs per wave) earlier.
-template <int BW, int WX, int WW, bool IL>
+template <int BW, int WX, int WW, bool IL, bool S16>
 __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
                                                             const float *__restrict__ bias, float *__restrict__ Cf,
                                                             __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                             int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
   constexpr int BX = 256, PL = 2, RR = 320, ROFF = 32;
-  using E = EngineH<BX, BW, WX, WW, true, IL>;
+  using E = EngineH<BX, BW, WX, WW, true, IL, S16>;
   using L = typename E::L;
   if (IL) {
     Xlo = Xhi + BKH;
     Wlo = Whi + BKH;
   }
   const int CinS = Cin * L::RS;
-  constexpr int TX = E::TX, TW = E::TW;
+  constexpr int TX = E::TX, TW = E::TW, NI = E::NI, NJ = E::NJ, MS = E::MS;
   constexpr int XRUN = RR * BKH * PL, WST = BW * BKH * PL;
   constexpr int NXC = RR * 4 * PL / NT16, NWC = BW * 4 * PL / NT16;
   static_assert(RR * 4 * PL % NT16 == 0 && BW * 4 * PL % NT16 == 0, "every lane active in every staging instruction");
@@ -589,10 +582,10 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, c
     wok[i] = n < Cout;
     wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
   }
-  unsigned tapmask[TX];
+  unsigned tapmask[NJ];
 #pragma unroll
-  for (int j = 0; j < TX; j++) {
-    const int m = m0 + e.out_m(j);
+  for (int j = 0; j < NJ; j++) {
+    const int m = m0 + e.pm(j);
     unsigned mk = 0;
     if (m < M) {
       const int x = m % W, y = (m / W) % H;
@@ -625,7 +618,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, c
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
       }
   };
-  const int r31 = lane & 31, hh = lane >> 5;
+  const int fr = e.frow();
   issue_group(0);
   for (int g = 0; g < ngrp; g++) {
     wait_vmcnt<0>();                 // group g (issued one whole group of matrix work ago) has landed
@@ -638,32 +631,29 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, c
       const int tap = dyi * 3 + t;
       const __bf16 *sW = wbuf + (size_t)((g & 1) * 3 + t) * WST;
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
-        bf16x8 xa[PL][TX], wa[PL][TW];
+      for (int s = 0; s < E::KSTEPS; s++) {
+        const int sl = e.fslot(s);
+        bf16x8 xa[NJ][PL], wa[NI][PL];
 #pragma unroll
-        for (int j = 0; j < TX; j++) {
-          const int rrow = e.wx * (TX * 32) + j * 32 + r31 + ROFF + t - 1;
+        for (int j = 0; j < NJ; j++) {
+          const int rrow = e.wx * (TX * 32) + j * MS + fr + ROFF + t - 1;
           const bool on = (tapmask[j] >> tap) & 1u;
 #pragma unroll
           for (int p = 0; p < PL; p++) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, 2 * s + hh)]);
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, sl)]);
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            xa[p][j] = on ? v : z;
+            xa[j][p] = on ? v : z;
           }
         }
 #pragma unroll
-        for (int p = 0; p < PL; p++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
-          for (int i = 0; i < TW; i++)
-            wa[p][i] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * 32 + r31, p, 2 * s + hh)]);
+          for (int p = 0; p < PL; p++)
+            wa[i][p] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * MS + fr, p, sl)]);
 #pragma unroll
-        for (int i = 0; i < TW; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
-          for (int j = 0; j < TX; j++) {
-            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xa[0][j], e.acc[i][j], 0, 0, 0);
-            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[1][j], e.acc[i][j], 0, 0, 0);
-            e.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xa[0][j], e.acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < NJ; j++) e.mma(i, j, wa[i], xa[j]);
       }
     }
   }
@@ -849,6 +839,17 @@ inline bool host_il(const void *hi, const void *lo) {
   return lo != nullptr && reinterpret_cast<const char *>(lo) == reinterpret_cast<const char *>(hi) + 64;
 }
 
+// MFMA shape of the LDS-DMA kernels: v_mfma_f32_32x32x16_bf16 by default; NAFAE_MFMA=16 selects 16x16x32 (measured at C2:
+// fc6 3.53 vs 3.55 ms, fc7 0.63 vs 0.66, conv stack 7.58 vs 7.26 -- no clock gain here, the loops are not MFMA-issue bound)
+inline bool use_s16() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("NAFAE_MFMA");
+    v = (e && atoi(e) == 16) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST = 3, bool IL = false>
 int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const void *Wlo, int ldw, float *Cf, void *Chi,
                void *Clo, int ldc, const float *bias, int M, int N, int K, float alpha, int act, int H, int W, int Cin,
@@ -856,7 +857,8 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   using E = EngineH<BX, BW, WX, WW, SPLIT>;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
   const size_t lds = NST * E::STAGE * sizeof(__bf16);
-  auto kern = bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL>;
+  auto kern = use_s16() ? bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, true>
+                         : bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, false>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -875,7 +877,8 @@ int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const voi
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
   constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384);
   const size_t lds = (size_t)(2 * RR * BKH * PL + NSTW * BW * BKH * PL) * sizeof(__bf16);
-  auto kern = conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX>;
+  auto kern = use_s16() ? conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, true>
+                         : conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, false>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -893,7 +896,7 @@ int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const vo
   const int M = F * H * W;
   const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
   const size_t lds = (size_t)(2 * 320 * BKH * 2 + 6 * BW * BKH * 2) * sizeof(__bf16);
-  auto kern = conv3x3_run3_kernel<BW, WX, WW, IL>;
+  auto kern = use_s16() ? conv3x3_run3_kernel<BW, WX, WW, IL, true> : conv3x3_run3_kernel<BW, WX, WW, IL, false>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -951,7 +954,7 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                        void *stream) {
   if (!X_hi || !W_hi || (!C_f32 && !C_hi) || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((K & 7) || (ldx & 7) || (ldw & 7) || (N & 3) || (ldc & 3) || !al16(X_hi) || !al16(W_hi)) return NAFAE_EINVAL;
-  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && (act > 0 || act < -4)) return NAFAE_EINVAL;   // < 0: timing experiments
+  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && (act > 0 || act < -2)) return NAFAE_EINVAL;   // -1 / -2: timing experiments
   const bool split = X_lo && W_lo;
   if (!split && (X_lo || W_lo)) return NAFAE_EINVAL;
   if (host_il(X_hi, X_lo) && !use_dma()) return NAFAE_EINVAL;  // I32 operands: LDS-DMA kernels only

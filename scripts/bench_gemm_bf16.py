@@ -15,33 +15,12 @@ def timeit(fn, n=it):
 M, N, K = 8192, 4096, 25088
 A = torch.randn(M, K, device='cuda', generator=g); B = torch.randn(N, K, device='cuda', generator=g) * 0.01
 bias = torch.zeros(N, device='cuda')
-for split in (True, False):
-    Xp, Wp = ops.split_bf16(A, split), ops.split_bf16(B, split)
+for split, il in ((True, True), (True, False), (False, False)):
+    Xp, Wp = ops.split_bf16(A, split, il), ops.split_bf16(B, split, il)
     nprod = 3 if split else 1
-    for act, tag in ((1, 'real'), (-1, 'zero-page loads'), (-2, 'L2-resident loads'), (-4, 'full-line requests')):
+    for act, tag in ((1, 'real'), (-1, 'zero-page loads'), (-2, 'L2-resident loads')):
         ms = timeit(lambda: ops.gemm_nt_bf16(Xp, Wp, bias, act=act, want_f32=False, want_planes=True))
-        print("gemm fc6 split=%s %-16s %.3f ms  alg %.0f TF  mfma %.0f TF (%.1f%% of 2.5PF)" % (split, tag, ms, 2*M*N*K/ms/1e9, nprod*2*M*N*K/ms/1e9, nprod*2*M*N*K/ms/1e9/25))
-    if split:
-        # experiment: hi/lo interleaved per 32-element piece -> each 128-B line holds hi(32)|lo(32) of one k-tile
-        def inter(P):
-            R, Kk = P.hi.shape
-            t = torch.stack([P.hi.view(R, Kk // 32, 32), P.lo.view(R, Kk // 32, 32)], 2).contiguous().view(R, 2 * Kk)
-            return t
-        Xi, Wi = inter(Xp), inter(Wp)
-        import ctypes
-        from nafae_amd import _lib
-        cl = torch.empty(M, N, device='cuda', dtype=torch.bfloat16); ch = torch.empty_like(cl)
-        def run_inter():
-            rc = _lib.lib().nafae_gemm_nt_bf16(ctypes.c_void_p(Xi.data_ptr()), ctypes.c_void_p(Xi.data_ptr() + 64), 2 * K,
-                                               ctypes.c_void_p(Wi.data_ptr()), ctypes.c_void_p(Wi.data_ptr() + 64), 2 * K,
-                                               None, ctypes.c_void_p(ch.data_ptr()), ctypes.c_void_p(cl.data_ptr()), N,
-                                               ctypes.c_void_p(bias.data_ptr()), M, N, K, 1.0, -3, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-            assert rc == 0, rc
-        ms = timeit(run_inter)
-        print("gemm fc6 split=True interleaved-lines   %.3f ms  mfma %.0f TF (%.1f%%)" % (ms, 3*2*M*N*K/ms/1e9, 3*2*M*N*K/ms/1e9/25))
-        ref = ops.gemm_nt_bf16(Xp, Wp, bias, act=0, want_f32=False, want_planes=True)[1]
-        print("   interleaved result matches:", float((ops.merge_bf16(ops.Planes(ch, cl)) - ops.merge_bf16(ref)).abs().max()))
-        del Xi, Wi
+        print("gemm fc6 split=%s il=%s %-16s %.3f ms  alg %.0f TF  mfma %.0f TF (%.1f%% of 2.5PF)" % (split, il, tag, ms, 2*M*N*K/ms/1e9, nprod*2*M*N*K/ms/1e9, nprod*2*M*N*K/ms/1e9/25))
     del Xp, Wp
 del A, B
 for (F, H, Cin, Cout) in ((64, 224, 64, 64), (64, 112, 128, 128), (64, 56, 256, 256), (64, 28, 512, 512), (64, 14, 512, 512)):
@@ -49,7 +28,7 @@ for (F, H, Cin, Cout) in ((64, 224, 64, 64), (64, 112, 128, 128), (64, 56, 256, 
     cb = torch.zeros(Cout, device='cuda')
     fl = 2.0 * F * H * H * Cout * 9 * Cin
     for split in (True, False):
-        xp, wp = ops.split_bf16(x, split), ops.split_bf16(w, split)
+        xp, wp = ops.split_bf16(x, split, split), ops.split_bf16(w, split, split)
         ms = timeit(lambda: ops.conv3x3_bf16(xp, wp, cb))
         nprod = 3 if split else 1
         print("conv %dx%d %d->%d split=%s %.3f ms alg %.0f TF mfma %.0f TF (%.1f%%)" % (H, H, Cin, Cout, split, ms, fl/ms/1e9, nprod*fl/ms/1e9, nprod*fl/ms/1e9/25))
