@@ -104,6 +104,10 @@ def main():
                          "k+1 overlaps the embedding/loss/backward/optimiser tail of step k on a second HIP stream)")
     ap.add_argument("--no-other-precisions", action="store_true",
                     help="skip the short extra runs in the other two arithmetic modes (N = 1 only)")
+    ap.add_argument("--dp-mode", default="replica", choices=["replica", "exact"],
+                    help="N > 1: 'replica' = per-GPU minibatch of whole segments, local loss, averaged gradients (default, "
+                         "BASELINE.json's DP); 'exact' = ONE global batch of N x the segments, frames sharded over the GPUs, "
+                         "S_max all-gathered, summed partial gradients (equals a 1-GPU step on the global batch)")
     ap.add_argument("--precision", default=os.environ.get("NAFAE_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the detector contractions: exact fp32 MFMA | split-bf16 (fp32-accurate to ~1e-5) | bf16")
     a = ap.parse_args()
@@ -125,26 +129,37 @@ def main():
     from nafae_amd import ops
     from nafae_amd.config import cfg, cfg_from_file, reset_cfg
     from nafae_amd.model import default_args
-    from nafae_amd.train import PipelinedTrainer, make_batch, setup_training, train_step
+    from nafae_amd.train import PipelinedTrainer, make_batch, setup_training, shard_frames, train_step, train_step_exact
 
     Na, Ns, Nb, Ne = WORKLOADS[a.workload]
     reset_cfg()
     cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
     cfg.TEST.RPN_POST_NMS_TOP_N = Nb
-    args = default_args(batch_size=Na, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
+    exact = a.dp_mode == "exact"
+    Na_model = Na * world if exact else Na          # exact mode: ONE batch of world*Na segments, every rank sees all queries
+    args = default_args(batch_size=Na_model, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
     model, opt, crit, reducer = setup_training(args, device=dev, seed=1234, distributed=distributed)
     model.fasterRCNN.precision = a.precision
-    batch = make_batch(Na, Ns, Ne, seed=1234 + rank, device=dev)
+    if exact:
+        if args.dropout_rate:
+            torch.manual_seed(1234)                 # word-side dropout masks must agree across ranks
+        batch = shard_frames(make_batch(Na_model, Ns, Ne, seed=1234, device=dev), rank, world)
+    else:
+        batch = make_batch(Na, Ns, Ne, seed=1234 + rank, device=dev)
 
     def sync():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe = None if a.no_pipeline else PipelinedTrainer(model, opt, crit, args, reducer)
+    pipe = None if (a.no_pipeline or exact) else PipelinedTrainer(model, opt, crit, args, reducer)
 
     def run_steps(n):
         """exactly n detector forwards and n tails; everything is enqueued inside the caller's timed region"""
+        if exact:
+            for _ in range(n):
+                loss, _, _, _ = train_step_exact(model, opt, crit, batch, args, reducer)
+            return loss
         if pipe is None:
             for _ in range(n):
                 loss, _, _, _ = train_step(model, opt, crit, batch, args, reducer)
@@ -176,13 +191,14 @@ def main():
         out = {
             "metric": "frames/sec + region-query-pairs/sec through sim+loss",
             "value": round(frames_per_s, 2), "unit": "frames/s",
-            "pairs_per_s": round(world * R * Q * a.steps / dt, 1),
+            # replica DP: every rank pairs its own R regions with its own Q queries; exact mode: one global R x Q problem
+            "pairs_per_s": round(world * R * Q * (world if exact else 1) * a.steps / dt, 1),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "%s: %d frames 224x224 per GPU (Na=%d,Ns=%d), %d proposals/frame, %d query slots/segment, "
                                    "VGG16 random-init, full train step" % (a.workload.upper(), F, Na, Ns, Nb, Ne),
                        "frames_per_gpu": F, "proposals_per_frame": Nb, "queries_per_segment": Ne,
-                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
+                       "parallelism": ("dp%d" % world) + ("-exact-global-batch" if exact else ""), "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
                        "step_pipeline": "detector(k+1) overlaps tail(k) on a second stream" if pipe else "sequential"},
             "loss": round(float(loss), 5),
         }

@@ -64,6 +64,18 @@ int nafae_roi_align_forward(int aligned_height, int aligned_width, float spatial
                             const float *features, int B, int C, int H, int W, const float *rois,
                             int N, float *output, void *stream);
 
+/* Replaces  int roi_align_backward_cuda(int aligned_height, int aligned_width, float spatial_scale,
+ *                THCudaTensor *top_grad, THCudaTensor *rois, THCudaTensor *bottom_grad)
+ *                                                           lib/model/roi_align/src/roi_align_cuda.c:42-79
+ * top_grad [N,C,AH,AW], rois [N,5], bottom_grad [B,C,H,W] -- ACCUMULATES into bottom_grad exactly as
+ * ROIAlignBackward does (roi_align_kernel.cu:93-141): the caller zero-fills it first
+ * (functions/roi_align.py:38-39).  fp32 atomic adds, so the summation order -- and the last bit -- is
+ * unspecified, as in the reference.  Not on the grounding hot path (the detector runs under no_grad,
+ * model.py:706); provided so that the B2 boundary is complete. */
+int nafae_roi_align_backward(int aligned_height, int aligned_width, float spatial_scale,
+                             const float *top_grad, const float *rois, int N, float *bottom_grad,
+                             int B, int C, int H, int W, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused / batched hot-path ops (what the Python host mirror in nafae_amd/ calls).
  * Internal activation layout is NHWC ("pixel-major, channel-contiguous") so that the K dimension of
@@ -207,6 +219,19 @@ int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const f
                   const int32_t *ent_len, int Na, int Ns, int Nb, int Ne, int D, int train,
                   const void *workspace, const float *pre_scale, const float *grad_scale, float *dV, float *dW,
                   void *stream);
+
+/* Frame-sharded forms of the two calls above (multi-GPU "exact global batch" mode): a rank holds F
+ * whole frames of the global batch (V [F*Nb, D]) and ALL Q = Na*Ne query rows.  Na, Ns, Ne are the GLOBAL batch
+ * dimensions (they size Q and the loss workspace); S_max / D_ind / dS are this rank's F rows of the global [Na*Ns, Q]
+ * arrays.  cluster_rows != 0 on the rank whose shard starts at global frame 0: the clustering gradient (rows
+ * [0, Nb) of V, reference quirk model.py:562-569) is added there from `workspace`.  dW is this rank's PARTIAL sum over
+ * its frames; the ranks' dW (or the parameter gradients that follow from it) are summed by the caller.  */
+int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne,
+                             int D, float *S_max, int64_t *D_ind, void *stream);
+int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, const float *W,
+                         const int32_t *ent_len, int F, int Na, int Ns, int Nb, int Ne, int D, int cluster_rows,
+                         const void *workspace, const float *pre_scale, const float *grad_scale, float *dV,
+                         float *dW, void *stream);
 
 /* ---- small embedding-tail ops (model.py:624-642) ------------------------------------------------ */
 

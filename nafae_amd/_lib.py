@@ -20,6 +20,7 @@ SIGNATURES = {
     "nafae_version": (c_int, [ctypes.c_char_p, c_int]),
     "nafae_nms": (c_int, [P, P, P, c_int, c_int, c_float, P]),
     "nafae_roi_align_forward": (c_int, [c_int, c_int, c_float, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
+    "nafae_roi_align_backward": (c_int, [c_int, c_int, c_float, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "nafae_gemm_nt": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_float, c_int, P]),
     "nafae_gemm_tn": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "nafae_gemm_tn_rows": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_float, P]),
@@ -45,6 +46,8 @@ SIGNATURES = {
     "nafae_loss_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "nafae_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, P, P, P]),
     "nafae_sim_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "nafae_sim_max_fwd_frames": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "nafae_sim_bwd_frames": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "nafae_dropout_tanh": (c_int, [P, P, c_float, P, c_int64, P]),
     "nafae_dropout_tanh_bwd": (c_int, [P, P, P, c_float, P, c_int64, P]),
     "nafae_batchnorm_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),

@@ -244,6 +244,33 @@ __global__ __launch_bounds__(256) void roi_align_nchw_kernel(long nthreads, cons
   top[index] = out;
 }
 
+// Drop-in for ROIAlignBackward (roi_align_kernel.cu:93-141): one thread per top element scatters its gradient to the four
+// taps with hardware fp32 atomic adds (the reference uses atomicAdd too, so the summation order is unspecified on both
+// sides).  Float/double mixing as written there: upper taps in double rounded once, lower taps in float.
+__global__ __launch_bounds__(256) void roi_align_bwd_nchw_kernel(long nthreads, const float *__restrict__ top_diff,
+                                                                 float scale, int H, int W, int C, int AH, int AW,
+                                                                 const float *__restrict__ rois, float *bottom_diff) {
+  const long index = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (index >= nthreads) return;
+  const int pw = index % AW;
+  const int ph = (index / AW) % AH;
+  const int c = (index / AW / AH) % C;
+  const int n = index / AW / AH / C;
+  const RoiGeom g = roi_geom(rois + (long)n * 5, scale, AH, AW);
+  const float h = (float)ph * g.bin_h + g.start_h;
+  const float w = (float)pw * g.bin_w + g.start_w;
+  if (h < 0 || h >= H || w < 0 || w >= W) return;
+  const int hs = (int)fminf(floorf(h), (float)(H - 2));
+  const int ws = (int)fminf(floorf(w), (float)(W - 2));
+  const float hr = h - (float)hs, wr = w - (float)ws;
+  const float td = top_diff[index];
+  float *p = bottom_diff + (((long)g.img * C + c) * H + hs) * W + ws;
+  unsafeAtomicAdd(p, (float)((double)td * (1. - (double)hr) * (double)(1.f - wr)));
+  unsafeAtomicAdd(p + 1, (float)((double)td * (1. - (double)hr) * (double)wr));
+  unsafeAtomicAdd(p + W, (td * hr) * (1.f - wr));
+  unsafeAtomicAdd(p + W + 1, (td * hr) * wr);
+}
+
 // Fused RoIAlignAvg on NHWC: one workgroup per ROI, a thread owns 2 adjacent channels and walks the 8x8 sample
 // grid row by row keeping the previous sample row in registers, so each 7x7 output bin is produced from
 // registers and written once, channel-contiguous (coalesced 512 B per wave).
@@ -462,6 +489,17 @@ int nafae_roi_align_forward(int AH, int AW, float scale, const float *features, 
   const long total = (long)N * C * AH * AW;
   hipLaunchKernelGGL(roi_align_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), total,
                      features, scale, H, W, C, AH, AW, rois, output);
+  return launched();
+}
+
+int nafae_roi_align_backward(int AH, int AW, float scale, const float *top_grad, const float *rois, int N,
+                             float *bottom_grad, int B, int C, int H, int W, void *stream) {
+  if (!top_grad || !rois || !bottom_grad || AH < 2 || AW < 2 || B <= 0 || C <= 0 || H < 2 || W < 2 || N <= 0)
+    return NAFAE_EINVAL;
+  const long total = (long)N * C * AH * AW;
+  if ((total + 255) / 256 > 0x7fffffffL) return NAFAE_ELIMIT;
+  hipLaunchKernelGGL(roi_align_bwd_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), total,
+                     top_grad, scale, H, W, C, AH, AW, rois, bottom_grad);
   return launched();
 }
 

@@ -753,17 +753,23 @@ int nafae_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_
   return launched();
 }
 
-int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, int Na, int Ns, int Nb, int Ne, int D,
-                      float *S_max, int64_t *D_ind, void *stream) {
+int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
+                             float *S_max, int64_t *D_ind, void *stream) {
   if (!V || !W || !ent_len || !S_max || !D_ind) return NAFAE_EINVAL;
-  if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  if (Na <= 0 || F <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
   using E = Engine<128, 32, 4, 1>;
-  const int Q = Na * Ne, F = Na * Ns;
+  const int Q = Na * Ne;
   if (F > 65535) return NAFAE_ELIMIT;
   const size_t lds = (2 * E::STAGE + 128 * 33 + 2 * 8 * 32) * sizeof(float);
   hipLaunchKernelGGL(sim_max_kernel, dim3((Q + 31) / 32, F), dim3(NTHREADS), lds, S(stream), V, W, ent_len, Nb, Ne, Q, D,
                      S_max, D_ind);
   return launched();
+}
+
+int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, int Na, int Ns, int Nb, int Ne, int D,
+                      float *S_max, int64_t *D_ind, void *stream) {
+  if (Na <= 0 || Ns <= 0) return NAFAE_EINVAL;
+  return nafae_sim_max_fwd_frames(V, W, ent_len, Na * Ns, Nb, Na, Ne, D, S_max, D_ind, stream);
 }
 
 int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D) {
@@ -799,19 +805,27 @@ int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V,
   return launched();
 }
 
-int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const float *W, const int32_t *ent_len,
-                  int Na, int Ns, int Nb, int Ne, int D, int train, const void *workspace, const float *pre_scale,
-                  const float *grad_scale, float *dV, float *dW, void *stream) {
+int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, const float *W, const int32_t *ent_len,
+                         int F, int Na, int Ns, int Nb, int Ne, int D, int cluster_rows, const void *workspace,
+                         const float *pre_scale, const float *grad_scale, float *dV, float *dW, void *stream) {
   if (!dS || !D_ind || !V || !W || !ent_len || !dV || !dW) return NAFAE_EINVAL;
-  if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  if (F <= 0 || Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
   if (D > 256 * MAXCH) return NAFAE_ELIMIT;
-  if (train && !workspace) return NAFAE_EINVAL;
+  if (cluster_rows && !workspace) return NAFAE_EINVAL;
   const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
-  const int F = Na * Ns, Q = Na * Ne, R = F * Nb;
-  hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, train,
+  const int Q = Na * Ne, R = F * Nb;
+  hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, cluster_rows,
                      Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
   hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3((Q + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, V, F, Nb, Q, D, grad_scale, dW);
   return launched();
+}
+
+int nafae_sim_bwd(const float *dS, const int64_t *D_ind, const float *V, const float *W, const int32_t *ent_len,
+                  int Na, int Ns, int Nb, int Ne, int D, int train, const void *workspace, const float *pre_scale,
+                  const float *grad_scale, float *dV, float *dW, void *stream) {
+  if (Na <= 0 || Ns <= 0) return NAFAE_EINVAL;
+  return nafae_sim_bwd_frames(dS, D_ind, V, W, ent_len, Na * Ns, Na, Ns, Nb, Ne, D, train, workspace, pre_scale, grad_scale,
+                              dV, dW, stream);
 }
 
 int nafae_dropout_tanh(const float *x, const uint8_t *mask, float scale, float *y, int64_t n, void *stream) {

@@ -374,6 +374,20 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     return out
 
 
+def roi_align_backward(top_grad, rois, feature_size, spatial_scale):
+    """Drop-in for roi_align_backward_cuda (roi_align_cuda.c:42-79) as RoIAlignFunction.backward calls it
+    (functions/roi_align.py:33-46): returns the zero-initialised-then-accumulated grad_input [B,C,H,W]."""
+    _chk(top_grad); _chk(rois)
+    B, C, H, W = feature_size
+    N, C2, AH, AW = top_grad.shape
+    if rois.shape != (N, 5) or C2 != C:
+        raise NafaeOpError("top_grad must be [N,C,AH,AW] and rois [N,5]")
+    out = torch.zeros(B, C, H, W, device=top_grad.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_roi_align_backward(int(AH), int(AW), float(spatial_scale), _p(top_grad), _p(rois), N, _p(out), B, C, H, W,
+                                            _stream()), "nafae_roi_align_backward")
+    return out
+
+
 def roi_align_avg_nhwc(feat_nhwc, rois, spatial_scale):
     """feat [F,H,W,C], rois [N,5] -> [N,7,7,C]."""
     _chk(feat_nhwc); _chk(rois)
@@ -398,6 +412,38 @@ def sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne):
     _rc(_lib.lib().nafae_sim_max_fwd(_p(V), _p(W), _p(ent_len), Na, Ns, Nb, Ne, D, _p(S_max), _p(D_ind), _stream()),
         "nafae_sim_max_fwd")
     return S_max, D_ind
+
+
+def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne):
+    """Frame-sharded sim+max: V holds F whole frames ([F*Nb, D]) of a global batch with Na segments; W holds all
+    Q = Na*Ne query rows.  -> this rank's rows of S_max / D_ind, [F, Q]."""
+    _chk(V); _chk(W); _chk(ent_len, torch.int32)
+    D = V.shape[1]
+    Q = Na * Ne
+    if V.shape[0] % Nb or W.shape[0] != Q or W.shape[1] != D:
+        raise NafaeOpError("sim_max_fwd_frames: shape mismatch V %s W %s (Nb,Na,Ne)=(%d,%d,%d)"
+                           % (tuple(V.shape), tuple(W.shape), Nb, Na, Ne))
+    F = V.shape[0] // Nb
+    S_max = torch.empty(F, Q, device=V.device, dtype=torch.float32)
+    D_ind = torch.empty(F, Q, device=V.device, dtype=torch.int64)
+    _rc(_lib.lib().nafae_sim_max_fwd_frames(_p(V), _p(W), _p(ent_len), F, Nb, Na, Ne, D, _p(S_max), _p(D_ind), _stream()),
+        "nafae_sim_max_fwd_frames")
+    return S_max, D_ind
+
+
+def sim_bwd_frames(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, cluster_rows, workspace, pre_scale=None, grad_scale=None):
+    """Backward of sim_max_fwd_frames for this rank's F frames: dV [F*Nb, D] and the PARTIAL dW [Q, D]."""
+    _chk(dS); _chk(D_ind, torch.int64); _chk(V); _chk(W); _chk(ent_len, torch.int32); _chk(pre_scale); _chk(grad_scale)
+    D = V.shape[1]
+    F = V.shape[0] // Nb
+    if tuple(dS.shape) != (F, Na * Ne) or tuple(D_ind.shape) != (F, Na * Ne) or not dS.is_contiguous() or not D_ind.is_contiguous():
+        raise NafaeOpError("sim_bwd_frames: dS / D_ind must be contiguous [F, Na*Ne]")
+    dV = torch.empty_like(V)
+    dW = torch.empty_like(W)
+    _rc(_lib.lib().nafae_sim_bwd_frames(_p(dS), _p(D_ind), _p(V), _p(W), _p(ent_len), F, Na, Ns, Nb, Ne, D,
+                                        int(bool(cluster_rows)), _p(workspace), _p(pre_scale), _p(grad_scale), _p(dV), _p(dW),
+                                        _stream()), "nafae_sim_bwd_frames")
+    return dV, dW
 
 
 def loss_workspace(Na, Ns, Nb, Ne, D, device):

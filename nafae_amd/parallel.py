@@ -36,16 +36,124 @@ class GradAllReducer:
     def zero_grad(self):
         self.flat.zero_()
 
-    def allreduce(self):
-        """Average gradients over ranks (sum then divide, identical on every rank)."""
+    def allreduce(self, average=True):
+        """Sum the flat gradient buffer over ranks; `average` divides by the world size afterwards (replicated-model DP
+        with per-rank minibatches).  average=False is the frame-sharded exact mode, where every rank holds a PARTIAL
+        gradient of one global loss."""
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(self.world)
+            _all_reduce_sum(self.flat, self.group)
+            if average:
+                self.flat.div_(self.world)
         return self.flat
 
     @property
     def nbytes(self):
         return self.flat.numel() * 4
+
+
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def _host_staged(t, group):
+    """gloo moves CUDA tensors only for some collectives; stage through pinned host memory there (tests on one GPU)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t, group=None):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_rows(t, group=None):
+    """[n, ...] on every rank (same n) -> [world*n, ...] in rank order."""
+    world = _world(group)
+    if world == 1:
+        return t
+    src = t.cpu() if _host_staged(t, group) else t.contiguous()
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return torch.cat(parts, 0).to(t.device)
+
+
+def broadcast_rows(t, src=0, group=None):
+    if _world(group) == 1:
+        return t
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+class _FrameShardedDVSAFn(torch.autograd.Function):
+    """DVSA.forward (model.py:517-614) on a batch whose FRAMES are sharded over the ranks -- the "exact global batch"
+    mode of SURVEY.md section 8(e).  Every rank holds F/world whole frames (its rows of V) and all Q query rows (WordEbd is
+    replicated so its BatchNorm sees the full Q).  The region x query contraction and its per-frame max -- the only part
+    whose cost grows with the batch -- stay local; the exchange is ONE all-gather of S_max / arg-max ([F,Q] fp32 + i64:
+    4 MB + 8 MB at C4's 512 x 2048) plus a broadcast of the Nb rows of V that the clustering term gathers (always frame 0
+    of segment 0, model.py:562-569); the O(F*Q) loss tail then runs redundantly on every rank, so the loss value is
+    identical everywhere.  Backward is local: each rank turns its rows of dS into dV for its frames and a PARTIAL dW;
+    summing the parameter gradients over ranks (GradAllReducer.allreduce(average=False)) gives the gradient of the
+    global-batch loss."""
+
+    @staticmethod
+    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, group):
+        from . import ops
+        world, rank = _world(group), _rank(group)
+        F = Na * Ns
+        if F % world or V.shape[0] != (F // world) * Nb:
+            raise ValueError("frame-sharded DVSA: %d frames do not split over %d ranks as %d rows of V each"
+                             % (F, world, V.shape[0]))
+        Fl = F // world
+        S_loc, D_loc = ops.sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne)
+        S_max = all_gather_rows(S_loc, group)
+        D_ind = all_gather_rows(D_loc, group)
+        V0 = V[:Nb].detach().clone() if rank == 0 else torch.empty(Nb, V.shape[1], device=V.device, dtype=V.dtype)
+        if train:
+            broadcast_rows(V0, 0, group)
+        need = V.requires_grad or W.requires_grad
+        loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, V0, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=need)
+        if need:
+            ctx.save_for_backward(V, W, ent_len, D_loc, dS[rank * Fl:(rank + 1) * Fl].contiguous(), ws)
+        ctx.dims = (Na, Ns, Nb, Ne, bool(train) and rank == 0)
+        ctx.mark_non_differentiable(D_ind, S_max)
+        ctx.loss_parts = loss_out
+        return D_ind, S_max, loss_out[0]
+
+    @staticmethod
+    def backward(ctx, g_ind, g_sim, g_loss):
+        from . import ops
+        V, W, ent_len, D_loc, dS_loc, ws = ctx.saved_tensors
+        Na, Ns, Nb, Ne, cluster_rows = ctx.dims
+        gs = g_loss.detach().reshape(1).float().contiguous()
+        dV, dW = ops.sim_bwd_frames(dS_loc, D_loc, V, W, ent_len, Na, Ns, Nb, Ne, cluster_rows, ws, grad_scale=gs)
+        return dV, dW, None, None, None, None, None, None, None, None, None
+
+
+def dvsa_frame_sharded(dvsa, vis_feats_local, word_feats, entities_length, group=None):
+    """`dvsa(vis_feats, word_feats, entities_length)` for a DVSA module when `vis_feats_local` holds only this rank's
+    frames (rank r owns global frames [r*F/world, (r+1)*F/world)).  Returns the GLOBAL (D_ind, D_sim, margin_loss)."""
+    from .config import cfg
+    Na, Nb, Ne = dvsa.Na, cfg.TEST.RPN_POST_NMS_TOP_N, dvsa.args.max_ent_len
+    world = _world(group)
+    Ns = vis_feats_local.shape[0] * world // (Na * Nb)
+    if len(entities_length) != Na:
+        raise ValueError("entities_length has %d entries, Na = %d" % (len(entities_length), Na))
+    ent_len = torch.tensor([int(x) for x in entities_length], dtype=torch.int32, device=vis_feats_local.device)
+    return _FrameShardedDVSAFn.apply(vis_feats_local.contiguous(), word_feats.contiguous(), ent_len, Na, Ns, Nb, Ne,
+                                     float(dvsa.args.Delta), float(dvsa.args.vis_lam), dvsa.phase == 'train', group)
 
 
 def broadcast_parameters(model, src=0, group=None):

@@ -6,7 +6,7 @@ import torch
 from . import synthetic as syn
 from .config import cfg
 from .model import GroundModel, default_args
-from .parallel import FusedClipAdam, GradAllReducer, trainable_parameters
+from .parallel import FusedClipAdam, GradAllReducer, dvsa_frame_sharded, trainable_parameters
 
 
 class Batch:
@@ -69,6 +69,35 @@ def train_step(model, optimizer, criterion, batch, args, reducer=None):
     else:
         torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
         optimizer.step()
+    return loss.detach(), D, D_sim, rois
+
+
+def shard_frames(batch, rank, world):
+    """This rank's contiguous share of the frames of a GLOBAL batch; queries and lengths stay whole."""
+    F = batch.im_data.shape[0]
+    if F % world:
+        raise ValueError("%d frames do not split over %d ranks" % (F, world))
+    k = F // world
+    return Batch(batch.im_data[rank * k:(rank + 1) * k], batch.im_info[rank * k:(rank + 1) * k], batch.glove_feats,
+                 batch.entities_length)
+
+
+def train_step_exact(model, optimizer, criterion, local_batch, args, reducer, group=None):
+    """One training step on a GLOBAL batch whose frames are sharded over the ranks (exact mode): the
+    result equals a single-GPU train_step on the whole batch (same loss; gradients equal up to fp32 summation order),
+    unlike the default replicated-minibatch DP whose loss couples only the segments of one rank.  `local_batch` =
+    shard_frames(global_batch, rank, world).  Dropout must be off or seeded identically for the word side."""
+    with torch.no_grad():
+        rois, roi_scores, roi_feats, fc_feats = model.fasterRCNN(local_batch.im_data, local_batch.im_info,
+                                                                 local_batch.gt_boxes, local_batch.num_boxes)
+    vis_feats = model.vis_ebd(fc_feats)                       # this rank's rows only
+    word_feats = model.word_ebd(local_batch.glove_feats)      # replicated: BatchNorm sees all Q rows on every rank
+    reducer.zero_grad()
+    D, D_sim, margin_loss = dvsa_frame_sharded(model.DVSA, vis_feats, word_feats, local_batch.entities_length, group)
+    loss = criterion(margin_loss, torch.zeros_like(margin_loss))
+    loss.backward()
+    reducer.allreduce(average=False)                          # partial gradients of ONE loss: sum, do not average
+    optimizer.step()
     return loss.detach(), D, D_sim, rois
 
 

@@ -100,6 +100,53 @@ void oracle_roi_align_forward(const float *bottom_data, float spatial_scale, int
   }
 }
 
+/* ROIAlignBackward, roi_align_kernel.cu:93-141 (launcher :143-160, binding roi_align_cuda.c:42-79): every top element
+ * scatters its gradient to the four taps of its sample with the bilinear weights.  The reference adds with atomicAdd in
+ * an unspecified order; this restatement adds in index order.  Float/double mixing as written there: the two upper
+ * taps are evaluated in double (`1.` literals) and rounded once, the two lower taps entirely in float. */
+void oracle_roi_align_backward(const float *top_diff, float spatial_scale, int num_rois, int height,
+                               int width, int channels, int aligned_height, int aligned_width,
+                               const float *bottom_rois, float *bottom_diff) {
+  long nthreads = (long)num_rois * channels * aligned_height * aligned_width;
+  for (long index = 0; index < nthreads; index++) {
+    int pw = (int)(index % aligned_width);
+    int ph = (int)((index / aligned_width) % aligned_height);
+    int c = (int)((index / aligned_width / aligned_height) % channels);
+    int n = (int)(index / aligned_width / aligned_height / channels);
+
+    float roi_batch_ind = bottom_rois[n * 5 + 0];
+    float roi_start_w = bottom_rois[n * 5 + 1] * spatial_scale;
+    float roi_start_h = bottom_rois[n * 5 + 2] * spatial_scale;
+    float roi_end_w = bottom_rois[n * 5 + 3] * spatial_scale;
+    float roi_end_h = bottom_rois[n * 5 + 4] * spatial_scale;
+
+    float roi_width = fmaxf((float)((double)(roi_end_w - roi_start_w) + 1.), 0.f);  /* :115 */
+    float roi_height = fmaxf((float)((double)(roi_end_h - roi_start_h) + 1.), 0.f); /* :116 */
+    float bin_size_h = (float)((double)roi_height / ((double)aligned_height - 1.)); /* :117 */
+    float bin_size_w = (float)((double)roi_width / ((double)aligned_width - 1.));   /* :118 */
+
+    float h = (float)(ph)*bin_size_h + roi_start_h;
+    float w = (float)(pw)*bin_size_w + roi_start_w;
+    int hstart = (int)fminf(floorf(h), (float)(height - 2));
+    int wstart = (int)fminf(floorf(w), (float)(width - 2));
+    int img_start = (int)(roi_batch_ind * (float)channels * (float)height * (float)width);
+
+    if (!(h < 0 || h >= height || w < 0 || w >= width)) { /* :129 */
+      float h_ratio = h - (float)(hstart);
+      float w_ratio = w - (float)(wstart);
+      int upleft = img_start + (c * height + hstart) * width + wstart;
+      int upright = upleft + 1;
+      int downleft = upleft + width;
+      int downright = downleft + 1;
+      float td = top_diff[index];
+      bottom_diff[upleft] += (float)((double)td * (1. - (double)h_ratio) * (double)(1.f - w_ratio)); /* :137 */
+      bottom_diff[upright] += (float)((double)td * (1. - (double)h_ratio) * (double)w_ratio);        /* :138 */
+      bottom_diff[downleft] += (td * h_ratio) * (1.f - w_ratio);                                     /* :139 */
+      bottom_diff[downright] += (td * h_ratio) * w_ratio;                                            /* :140 */
+    }
+  }
+}
+
 /* lib/model/roi_align/modules/roi_align.py:26-29: align to (P+1)x(P+1), then avg_pool2d(k=2,s=1).
  * torch's CPU avg_pool2d sums the window in (kh, kw) row-major order in fp32 and divides by 4.
  * out: [N, C, P, P]. */

@@ -59,6 +59,18 @@ def roi_align_forward(features, rois, AH, AW, scale):
     return out
 
 
+def roi_align_backward(top_grad, rois, feature_shape, scale):
+    """top_grad [N,C,AH,AW], rois [N,5] -> bottom_grad [B,C,H,W] (roi_align_kernel.cu:93-141; index-order adds)."""
+    top_grad = np.ascontiguousarray(top_grad, dtype=np.float32)
+    rois = np.ascontiguousarray(rois, dtype=np.float32)
+    B, C, H, W = feature_shape
+    N, C2, AH, AW = top_grad.shape
+    assert C2 == C and rois.shape == (N, 5)
+    out = np.zeros((B, C, H, W), dtype=np.float32)
+    lib().oracle_roi_align_backward(_fp(top_grad), ctypes.c_float(scale), N, H, W, C, AH, AW, _fp(rois), _fp(out))
+    return out
+
+
 def roi_align_avg(features, rois, pooled, scale):
     """RoIAlignAvg (modules/roi_align.py:26-29): [N,C,pooled,pooled]."""
     features = np.ascontiguousarray(features, dtype=np.float32)

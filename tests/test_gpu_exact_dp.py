@@ -1,0 +1,108 @@
+"""Frame-sharded "exact global batch" data parallelism: N ranks, each with F/N frames of ONE global
+batch, must reproduce a single-process train_step on the whole batch."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg():
+    from nafae_amd.config import cfg_from_file, cfg_from_list, reset_cfg
+    reset_cfg()
+    cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
+    cfg_from_list(["TEST.RPN_POST_NMS_TOP_N", "32"])
+
+
+def test_frames_entries_are_slices_of_the_whole():
+    """nafae_sim_max_fwd_frames / nafae_sim_bwd_frames on a frame range == the rows of the whole-batch calls; partial dW
+    over a partition of the frames sums to the whole dW."""
+    from nafae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Na, Ns, Nb, Ne, D = 4, 4, 32, 8, 512
+    F, Q = Na * Ns, Na * Ne
+    V = torch.tanh(torch.randn(F * Nb, D, device="cuda", generator=g))
+    W = torch.tanh(torch.randn(Q, D, device="cuda", generator=g))
+    ent = torch.tensor([3, 0, 8, 5], dtype=torch.int32, device="cuda")
+    S, Di = ops.sim_max_fwd(V, W, ent, Na, Ns, Nb, Ne)
+    loss, dS, ws = ops.loss_fwd_bwd(S, Di, V, ent, Na, Ns, Nb, Ne, 10.0, 4.13, True)
+    dV, dW = ops.sim_bwd(dS, Di, V, W, ent, Na, Ns, Nb, Ne, True, ws)
+    dW_sum = torch.zeros_like(dW)
+    for (f0, f1) in ((0, 4), (4, 12), (12, 16)):           # uneven partition, whole frames
+        Vl = V[f0 * Nb:f1 * Nb].contiguous()
+        Sl, Dl = ops.sim_max_fwd_frames(Vl, W, ent, Nb, Na, Ne)
+        assert torch.equal(Sl, S[f0:f1]) and torch.equal(Dl, Di[f0:f1])
+        dVl, dWl = ops.sim_bwd_frames(dS[f0:f1].contiguous(), Dl, Vl, W, ent, Na, Ns, Nb, Ne, f0 == 0, ws)
+        assert torch.equal(dVl, dV[f0 * Nb:f1 * Nb])
+        dW_sum += dWl
+    assert float((dW_sum - dW).abs().max()) <= 1e-6 * float(dW.abs().max())
+    # the loss tail touches only the first Nb rows of V (frame-0 gather, model.py:562-569)
+    loss0, dS0, _ = ops.loss_fwd_bwd(S, Di, V[:Nb].contiguous(), ent, Na, Ns, Nb, Ne, 10.0, 4.13, True)
+    assert torch.equal(loss0, loss) and torch.equal(dS0, dS)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_exact_mode_equals_single_process(world):
+    from nafae_amd.model import default_args
+    from nafae_amd.train import make_batch, setup_training, train_step
+    steps = 2
+    Na, Ns, Ne = 4, 4, 8
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
+        procs = []
+        for r in range(world):
+            e = dict(env, RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exact_dp_worker.py"),
+                                           os.path.join(td, "r%d.pt" % r), str(steps)], env=e, cwd=ROOT,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        # the single-process run on the WHOLE batch, meanwhile
+        _cfg()
+        args = default_args(batch_size=Na, sample_num=Ns, max_ent_len=Ne, dropout_rate=0.0, Delta=10.0, vis_lam=4.13)
+        model, opt, crit, red = setup_training(args, seed=21)
+        ref_losses = []
+        for k in range(steps):
+            gb = make_batch(Na, Ns, Ne, seed=100 + k, lens=[3, 0, 8, 5])
+            loss, D, D_sim, rois = train_step(model, opt, crit, gb, args, red)
+            ref_losses.append(float(loss))
+            if k == 0:
+                ref_g0, ref_n0 = red.flat.clone().cpu(), float(opt.total_norm)
+        torch.cuda.synchronize()
+        outs = []
+        for r, p in enumerate(procs):
+            log, _ = p.communicate(timeout=600)
+            assert p.returncode == 0, "rank %d failed:\n%s" % (r, log.decode()[-3000:])
+            outs.append(torch.load(os.path.join(td, "r%d.pt" % r)))
+    ref_params = opt.flat_params.cpu()
+    for r, o in enumerate(outs):
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=2e-6)           # the SAME global loss on every rank
+        assert torch.equal(o["D"], D.cpu())                                      # grounding indices: exact
+        assert float((o["D_sim"] - D_sim.cpu()).abs().max()) <= 1e-5 * float(D_sim.abs().max())
+        # the gradient of the global-batch loss, summed from the ranks' partial gradients (fp32 summation order differs)
+        assert abs(o["norm0"] - ref_n0) <= 1e-5 * ref_n0
+        assert float((o["grads0"] - ref_g0).abs().max()) <= 1e-5 * float(ref_g0.abs().max()), r
+        # two Adam steps from identical starts.  Adam normalises each gradient element, so an element whose gradient is
+        # pure rounding noise may move by up to lr per step in either direction: bound the bulk tightly, the outliers by
+        # steps * 2 * lr
+        dp = (o["params"] - ref_params).abs()
+        assert float(dp.max()) <= steps * 2 * args.lr * 1.05 and float((dp > 1e-5).float().mean()) < 1e-3, (float(dp.max()), r)
+        # running statistics after step 2 see fc1 after one Adam step (the same +-lr outliers): loose bound
+        assert torch.allclose(o["bn_mean"], model.word_ebd.bn.running_mean.cpu(), rtol=0, atol=5e-4)
+        assert torch.equal(o["params"], outs[0]["params"])                       # replicas stay bit-identical
+    from nafae_amd.config import reset_cfg
+    reset_cfg()

@@ -226,6 +226,30 @@ def test_roi_align_forward_dropin(ops):
         np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-6)
 
 
+def test_roi_align_backward_dropin(ops):
+    """roi_align_backward_cuda (roi_align_cuda.c:42-79): vs the index-order oracle (summation order differs -> 1e-5),
+    and as the adjoint of the forward drop-in at the C2 feature-map size."""
+    from oracle import native as N
+    rs = np.random.RandomState(15)
+    Fr, C, H, W = 3, 10, 14, 14
+    rois = _rois(rs, 40, Fr)
+    for (AH, AW) in ((8, 8), (7, 7), (3, 5)):
+        g = rs.randn(40, C, AH, AW).astype(np.float32)
+        ref = N.roi_align_backward(g, rois, (Fr, C, H, W), 1 / 16.)
+        out = ops.roi_align_backward(dev(g), dev(rois), (Fr, C, H, W), 1 / 16.).cpu().numpy()
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    Fr, C, n = 8, 512, 256
+    rois = dev(_rois(rs, n, Fr))
+    x = torch.randn(Fr, C, H, W, device="cuda")
+    g = torch.randn(n, C, 8, 8, device="cuda")
+    y = ops.roi_align_forward(x, rois, 8, 8, 1 / 16.)
+    gx = ops.roi_align_backward(g, rois, (Fr, C, H, W), 1 / 16.)
+    lhs, rhs = float((y.double() * g.double()).sum()), float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+    with pytest.raises(ops.NafaeOpError):
+        ops.roi_align_backward(g, rois[:, :4].contiguous(), (Fr, C, H, W), 1 / 16.)
+
+
 def test_roi_align_avg_nhwc(ops):
     from oracle import native as N
     rs = np.random.RandomState(6)

@@ -101,3 +101,27 @@ def test_roi_align_avg_is_avgpool_of_8x8():
     b = N.roi_align_avg(f, rois, 7, 1 / 16.)
     t = torch.nn.functional.avg_pool2d(torch.from_numpy(a), kernel_size=2, stride=1).numpy()
     assert np.array_equal(t, b)           # modules/roi_align.py:26-29
+
+
+def test_roi_align_backward_is_adjoint_of_forward():
+    """<forward(x), g> == <x, backward(g)> for every x, g: the backward scatters with the weights the forward gathers
+    with (roi_align_kernel.cu:64-67 vs :137-140).  Includes out-of-range samples, a zero-padded and a degenerate ROI."""
+    rs = np.random.RandomState(3)
+    B, C, H, W = 2, 5, 14, 14
+    rois = np.array([[0, 3.3, 7.1, 150.2, 99.9], [1, 100, 100, 223, 223], [1, 0, 0, 0, 0], [0, 160, 0, 16, 15],
+                     [1, 0, 13.5 * 16, 0, 13.5 * 16]], np.float32)
+    for (AH, AW) in ((8, 8), (3, 5)):
+        x = rs.randn(B, C, H, W).astype(np.float32)
+        g = rs.randn(len(rois), C, AH, AW).astype(np.float32)
+        y = N.roi_align_forward(x, rois, AH, AW, 1 / 16.)
+        gx = N.roi_align_backward(g, rois, (B, C, H, W), 1 / 16.)
+        lhs, rhs = float((y.astype(np.float64) * g).sum()), float((x.astype(np.float64) * gx).sum())
+        assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    # a single top element lands on exactly its four taps with weights that sum to 1 (interior sample)
+    g = np.zeros((1, 1, 8, 8), np.float32); g[0, 0, 2, 3] = 1.0
+    gx = N.roi_align_backward(g, np.array([[0, 16, 16, 127, 127]], np.float32), (1, 1, 14, 14), 1 / 16.)
+    assert np.count_nonzero(gx) == 4 and abs(gx.sum() - 1.0) < 1e-6
+    # out-of-range sample (last row/column of a whole-map ROI) contributes nothing (:129)
+    g = np.zeros((1, 1, 8, 8), np.float32); g[0, 0, 7, 7] = 1.0
+    gx = N.roi_align_backward(g, np.array([[0, 0, 0, 223, 223]], np.float32), (1, 1, 14, 14), 1 / 16.)
+    assert not gx.any()
