@@ -109,8 +109,7 @@ class _FrameShardedDVSAFn(torch.autograd.Function):
     global-batch loss."""
 
     @staticmethod
-    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, group):
-        from . import ops
+    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, group, ops):
         world, rank = _world(group), _rank(group)
         F = Na * Ns
         if F % world or V.shape[0] != (F // world) * Nb:
@@ -128,24 +127,28 @@ class _FrameShardedDVSAFn(torch.autograd.Function):
         if need:
             ctx.save_for_backward(V, W, ent_len, D_loc, dS[rank * Fl:(rank + 1) * Fl].contiguous(), ws)
         ctx.dims = (Na, Ns, Nb, Ne, bool(train) and rank == 0)
+        ctx.ops = ops
         ctx.mark_non_differentiable(D_ind, S_max)
         ctx.loss_parts = loss_out
         return D_ind, S_max, loss_out[0]
 
     @staticmethod
     def backward(ctx, g_ind, g_sim, g_loss):
-        from . import ops
         V, W, ent_len, D_loc, dS_loc, ws = ctx.saved_tensors
         Na, Ns, Nb, Ne, cluster_rows = ctx.dims
         gs = g_loss.detach().reshape(1).float().contiguous()
-        dV, dW = ops.sim_bwd_frames(dS_loc, D_loc, V, W, ent_len, Na, Ns, Nb, Ne, cluster_rows, ws, grad_scale=gs)
-        return dV, dW, None, None, None, None, None, None, None, None, None
+        dV, dW = ctx.ops.sim_bwd_frames(dS_loc, D_loc, V, W, ent_len, Na, Ns, Nb, Ne, cluster_rows, ws, grad_scale=gs)
+        return dV, dW, None, None, None, None, None, None, None, None, None, None
 
 
-def dvsa_frame_sharded(dvsa, vis_feats_local, word_feats, entities_length, group=None):
+def dvsa_frame_sharded(dvsa, vis_feats_local, word_feats, entities_length, group=None, kernels=None):
     """`dvsa(vis_feats, word_feats, entities_length)` for a DVSA module when `vis_feats_local` holds only this rank's
-    frames (rank r owns global frames [r*F/world, (r+1)*F/world)).  Returns the GLOBAL (D_ind, D_sim, margin_loss)."""
+    frames (rank r owns global frames [r*F/world, (r+1)*F/world)).  Returns the GLOBAL (D_ind, D_sim, margin_loss).
+    `kernels` is the object providing sim_max_fwd_frames / loss_fwd_bwd / sim_bwd_frames: nafae_amd.ops (the HIP library;
+    default, and the only implementation the package ships -- the CPU protocol test injects its own)."""
     from .config import cfg
+    if kernels is None:
+        from . import ops as kernels
     Na, Nb, Ne = dvsa.Na, cfg.TEST.RPN_POST_NMS_TOP_N, dvsa.args.max_ent_len
     world = _world(group)
     Ns = vis_feats_local.shape[0] * world // (Na * Nb)
@@ -153,7 +156,7 @@ def dvsa_frame_sharded(dvsa, vis_feats_local, word_feats, entities_length, group
         raise ValueError("entities_length has %d entries, Na = %d" % (len(entities_length), Na))
     ent_len = torch.tensor([int(x) for x in entities_length], dtype=torch.int32, device=vis_feats_local.device)
     return _FrameShardedDVSAFn.apply(vis_feats_local.contiguous(), word_feats.contiguous(), ent_len, Na, Ns, Nb, Ne,
-                                     float(dvsa.args.Delta), float(dvsa.args.vis_lam), dvsa.phase == 'train', group)
+                                     float(dvsa.args.Delta), float(dvsa.args.vis_lam), dvsa.phase == 'train', group, kernels)
 
 
 def broadcast_parameters(model, src=0, group=None):

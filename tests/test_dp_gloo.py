@@ -88,3 +88,81 @@ def test_reducer_single_process_is_noop():
     before = red.flat.clone()
     red.allreduce()
     assert torch.equal(before, red.flat) and red.world == 1
+
+
+# ---------------------------------------------------------------------------------------------------- exact mode
+def _exact_case():
+    Na, Ns, Nb, Ne, D = 4, 4, 6, 3, 16
+    g = torch.Generator().manual_seed(5)
+    V = torch.tanh(torch.randn(Na * Ns * Nb, D, generator=g))
+    W = torch.tanh(torch.randn(Na * Ne, D, generator=g))
+    return Na, Ns, Nb, Ne, V, W, [2, 0, 3, 1]
+
+
+class _FakeDVSA:
+    def __init__(self, Na, Ne):
+        import argparse
+        self.Na, self.phase = Na, 'train'
+        self.args = argparse.Namespace(max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
+
+
+def test_cpu_tail_standin_matches_oracle():
+    """The torch stand-in used below (tests/cpu_kernels.py) == the oracle's DVSA.forward, loss and both gradients."""
+    from oracle import dvsa as O
+    from tests.cpu_kernels import CpuKernels as K
+    Na, Ns, Nb, Ne, V, W, lens = _exact_case()
+    Vr, Wr = V.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    Di, Ds, L = O.dvsa_forward(Vr, Wr, lens, Na, Nb, Ne, 10.0, 4.13, 'train')
+    L.backward()
+    ent = torch.tensor(lens, dtype=torch.int32)
+    S, Dk = K.sim_max_fwd_frames(V, W, ent, Nb, Na, Ne)
+    out, dS, ws = K.loss_fwd_bwd(S, Dk, V[:Nb].contiguous(), ent, Na, Ns, Nb, Ne, 10.0, 4.13, True)
+    dV, dW = K.sim_bwd_frames(dS, Dk, V, W, ent, Na, Ns, Nb, Ne, True, ws)
+    assert torch.equal(Dk, Di) and torch.allclose(S, Ds) and abs(float(out[0]) - float(L)) < 1e-5 * abs(float(L))
+    assert torch.allclose(dV, Vr.grad, atol=1e-6) and torch.allclose(dW, Wr.grad, atol=1e-6)
+
+
+def _exact_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nafae_amd.config import cfg, reset_cfg
+    from nafae_amd.parallel import GradAllReducer, dvsa_frame_sharded
+    from tests.cpu_kernels import CpuKernels
+    Na, Ns, Nb, Ne, V, W, lens = _exact_case()
+    reset_cfg()
+    cfg.TEST.RPN_POST_NMS_TOP_N = Nb
+    k = V.shape[0] // world
+    Vl = V[rank * k:(rank + 1) * k].clone().requires_grad_(True)      # this rank's frames
+    Wl = W.clone().requires_grad_(True)                                # replicated queries
+    D_ind, D_sim, loss = dvsa_frame_sharded(_FakeDVSA(Na, Ne), Vl, Wl, lens, kernels=CpuKernels)
+    loss.backward()
+    # the partial dW of the ranks sums to the global dW (what GradAllReducer.allreduce(average=False) does to the
+    # parameter gradients that follow from it)
+    red = GradAllReducer([torch.nn.Parameter(torch.zeros_like(W))])
+    red.flat.copy_(Wl.grad.reshape(-1))
+    red.allreduce(average=False)
+    torch.save({"D_ind": D_ind, "D_sim": D_sim, "loss": float(loss), "dV": Vl.grad, "dW": red.flat.view_as(W).clone()},
+               out % rank)
+    dist.destroy_process_group()
+
+
+def test_exact_mode_exchange_world2(tmp_path):
+    """Frame-sharded exact mode on 2 gloo ranks (CPU stand-in kernels): the all-gather of S_max / arg-max, the broadcast of
+    the frame-0 rows, the rank-0-only clustering rows and the summed partial gradients reproduce the single-process
+    DVSA on the whole batch."""
+    from oracle import dvsa as O
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_exact_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    Na, Ns, Nb, Ne, V, W, lens = _exact_case()
+    Vr, Wr = V.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    Di, Ds, L = O.dvsa_forward(Vr, Wr, lens, Na, Nb, Ne, 10.0, 4.13, 'train')
+    L.backward()
+    rs = [torch.load(out % r) for r in range(2)]
+    k = V.shape[0] // 2
+    for r, o in enumerate(rs):
+        assert torch.equal(o["D_ind"], Di) and torch.allclose(o["D_sim"], Ds)
+        assert abs(o["loss"] - float(L)) < 1e-5 * abs(float(L))
+        assert torch.allclose(o["dV"], Vr.grad[r * k:(r + 1) * k], atol=1e-6)       # own frames only
+        assert torch.allclose(o["dW"], Wr.grad, atol=1e-6)                           # summed partials
+    assert rs[1]["dV"][:Nb].abs().sum() >= 0 and not torch.equal(rs[0]["dV"], rs[1]["dV"])
