@@ -279,17 +279,72 @@ class GroundModel(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------- helpers
-def stepRCNN(im_data, im_info, gt_boxes, num_boxes, ground_model, step_size=64):
-    """model.py:429-454: run the detector over a long segment in chunks of 64 frames."""
+def stepRCNN(im_data, im_info, gt_boxes, num_boxes, ground_model, step_size=64, need_roi_feats=True):
+    """model.py:429-454: run the detector over a long segment in chunks of `step_size` (64) frames.
+
+    `im_data` may be what the reference passes -- a float32 [Ns,3,H,W] tensor already on the GPU -- or, streamed
+    (SURVEY.md section 8f.4), a HOST tensor: float32 [Ns,3,H,W], or raw decoded frames uint8 [Ns,H,W,3] (BGR; the -127.5 and
+    the layout change then happen on the GPU, youcook2.py:212-214, and a quarter of the bytes cross PCIe).  Host input
+    is moved chunk by chunk through two pinned staging buffers and two device buffers on a copy stream, so the H2D of
+    chunk k+1 overlaps the detector on chunk k and the whole segment never has to fit on the device at once.
+    `need_roi_feats=False` skips materialising the fp32 `pooled_feat` (822 MB per 64 frames at 128 proposals) that
+    validate() never reads (model.py:880-882); the second return value is then None."""
+    det = ground_model.fasterRCNN
     Ns = im_data.shape[0]
+    chunks = [(s, min(s + step_size, Ns)) for s in range(0, Ns, step_size)]
     rois_lst, roi_feats_lst, fc_feats_lst = [], [], []
-    for s in range(0, Ns, step_size):
-        e = min(s + step_size, Ns)
-        rois, roi_scores, roi_feats, fc_feats = ground_model.fasterRCNN(im_data[s:e], im_info[s:e], gt_boxes, num_boxes)
-        rois_lst.append(rois)
-        roi_feats_lst.append(roi_feats)
-        fc_feats_lst.append(fc_feats)
-    return torch.cat(rois_lst, 0), torch.cat(roi_feats_lst, 0), torch.cat(fc_feats_lst, 0)
+    keep = getattr(det, "materialize_pooled", True)
+    if not need_roi_feats:
+        det.materialize_pooled = False
+    try:
+        if im_data.is_cuda:
+            for s, e in chunks:
+                rois, roi_scores, roi_feats, fc_feats = det(im_data[s:e], im_info[s:e], gt_boxes, num_boxes)
+                rois_lst.append(rois); roi_feats_lst.append(roi_feats if need_roi_feats else None); fc_feats_lst.append(fc_feats)
+        else:
+            dev = next(det.parameters()).device
+            raw = im_data.dtype == torch.uint8
+            if not raw and im_data.dtype != torch.float32:
+                raise TypeError("host frames must be float32 [Ns,3,H,W] or uint8 [Ns,H,W,3], got %s" % im_data.dtype)
+            main = torch.cuda.current_stream(dev)
+            copy = torch.cuda.Stream(dev)
+            n0 = min(step_size, Ns)
+            shape = (n0,) + tuple(im_data.shape[1:])
+            pinned = [torch.empty(shape, dtype=im_data.dtype).pin_memory() for _ in range(2)]
+            dbuf = [torch.empty(shape, dtype=im_data.dtype, device=dev) for _ in range(2)]
+            landed, consumed = [None, None], [None, None]
+            info_dev = im_info.to(dev, non_blocking=True)
+
+            def stage(i):
+                s, e = chunks[i]
+                b = i & 1
+                if landed[b] is not None:
+                    landed[b].synchronize()              # the previous H2D out of this pinned buffer has finished
+                pinned[b][:e - s].copy_(im_data[s:e])
+                with torch.cuda.stream(copy):
+                    if consumed[b] is not None:
+                        copy.wait_event(consumed[b])     # the detector is done reading this device buffer
+                    dbuf[b][:e - s].copy_(pinned[b][:e - s], non_blocking=True)
+                    landed[b] = torch.cuda.Event()
+                    landed[b].record(copy)
+
+            stage(0)
+            for i, (s, e) in enumerate(chunks):
+                if i + 1 < len(chunks):
+                    stage(i + 1)
+                b = i & 1
+                main.wait_event(landed[b])
+                x = dbuf[b][:e - s]
+                if raw:
+                    x = ops.frames_u8_to_nchw_f32(x)
+                rois, roi_scores, roi_feats, fc_feats = det(x, info_dev[s:e], gt_boxes, num_boxes)
+                consumed[b] = torch.cuda.Event()
+                consumed[b].record(main)
+                rois_lst.append(rois); roi_feats_lst.append(roi_feats if need_roi_feats else None); fc_feats_lst.append(fc_feats)
+    finally:
+        det.materialize_pooled = keep
+    roi_feats_all = torch.cat(roi_feats_lst, 0) if need_roi_feats else None
+    return torch.cat(rois_lst, 0), roi_feats_all, torch.cat(fc_feats_lst, 0)
 
 
 def postprocess(D, D_sim, Na, Ns, Nb, Ne):

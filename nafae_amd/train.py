@@ -190,7 +190,8 @@ def validate_segment(model, batch, vid_entities, img_ids, args, dets):
     Nb = cfg.TEST.RPN_POST_NMS_TOP_N
     Na, Ne = len(batch.entities_length), args.max_ent_len
     with torch.no_grad():
-        rois, roi_feats, fc_feats = stepRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes, model)
+        rois, roi_feats, fc_feats = stepRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes, model,
+                                             need_roi_feats=False)     # validate() never reads roi_feats
         vis_feats = model.vis_ebd(fc_feats)
         word_feats = model.word_ebd(batch.glove_feats)
         D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)

@@ -290,3 +290,28 @@ def test_reference_default_shapes(gpu):
     assert np.isfinite([l0, l1]).all() and l1 != l0
     reset_cfg()
     cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
+
+
+def test_stepRCNN_streamed_host_input(gpu):
+    """stepRCNN (model.py:429-454) fed from HOST memory -- float32 NCHW and raw uint8 HWC frames -- through the
+    double-buffered copy stream equals the device-resident call chunk for chunk (150 frames = 64 + 64 + 22)."""
+    from nafae_amd.model import default_args, stepRCNN
+    from nafae_amd.train import build_model
+    gpu.TEST.RPN_POST_NMS_TOP_N = 16
+    model = build_model(default_args(), seed=5).eval()
+    Ns, H, W = 150, 64, 96
+    g = torch.Generator().manual_seed(9)
+    u8 = torch.randint(0, 255, (Ns, H, W, 3), dtype=torch.uint8, generator=g)          # decoded BGR frames
+    f32 = (u8.float() - 127.5).permute(0, 3, 1, 2).contiguous()                        # youcook2.py:212-214 on the host
+    info = torch.tensor([[H, W, 1.0]]).repeat(Ns, 1)
+    gt, nb = torch.zeros(1, 1, 5, device="cuda"), torch.zeros(1, device="cuda")
+    ref = stepRCNN(f32.cuda(), info.cuda(), gt, nb, model)
+    assert tuple(ref[0].shape) == (Ns, 16, 5) and tuple(ref[1].shape) == (Ns * 16, 512, 7, 7) and tuple(ref[2].shape) == (Ns * 16, 4096)
+    for host in (f32, u8):
+        out = stepRCNN(host, info, gt, nb, model)
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    out = stepRCNN(u8, info, gt, nb, model, need_roi_feats=False)
+    assert out[1] is None and torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2])
+    assert model.fasterRCNN.materialize_pooled is True
+    with pytest.raises(TypeError):
+        stepRCNN(f32.double(), info, gt, nb, model)
