@@ -175,6 +175,15 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
 int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
                        float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
                        void *stream);
+/* Same, with a caller-owned scratch buffer that enables the stream-K schedule for launches whose tile count would leave
+ * the last round of workgroups mostly empty (49*2^k-pixel layers: 784 / 392 tiles on 256 CUs).  Deterministic (fixed
+ * summation order); without a workspace, or when the schedule does not pay, identical to nafae_conv3x3_bf16.
+ * nafae_conv3x3_bf16_workspace_bytes: bytes this shape wants (0 = none needed), < 0 on invalid sizes.  The workspace
+ * needs no initialisation and must not be shared by launches that may run concurrently.  */
+int64_t nafae_conv3x3_bf16_workspace_bytes(int F, int H, int W, int Cin, int Cout);
+int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
+                          float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
+                          void *workspace, int64_t workspace_bytes, void *stream);
 /* First VGG layer from the reference's fp32 NCHW frames straight to NHWC planes.  */
 int nafae_conv1_3x3_relu_bf16(const float *in_nchw, const float *w, const float *bias, void *out_hi, void *out_lo,
                               int F, int H, int W, void *stream);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "nafae_merge_bf16": (c_int, [P, P, P, c_int64, P]),
     "nafae_gemm_nt_bf16": (c_int, [P, P, c_int, P, P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_float, c_int, P]),
     "nafae_conv3x3_bf16": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "nafae_conv3x3_bf16_ws": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, ctypes.c_int64, P]),
+    "nafae_conv3x3_bf16_workspace_bytes": (ctypes.c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "nafae_conv1_3x3_relu_bf16": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "nafae_maxpool2x2_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_roi_align_avg_nhwc_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, c_float, P, P, P, P]),

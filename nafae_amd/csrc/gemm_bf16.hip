@@ -356,118 +356,123 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
 // per-lane mask says which taps of that lane's output pixel fall inside the image; the others are zeroed in registers.
 // Weights stream per tap through their own LDS ring exactly as in bf16_dma_kernel.  Step order: channel chunk (32) ->
 // dy -> dx; one raw barrier and one counted vmcnt wait per step.
+struct ConvArgs {
+  const __bf16 *Xhi, *Xlo, *Whi, *Wlo;
+  int F, H, W, Cin, Cout;
+};
+
 template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16>
-__global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
-                                                           const float *__restrict__ bias, float *__restrict__ Cf,
-                                                           __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
-                                                           int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
+struct ConvRun {
   // run length: 256 + 2 pixels are needed; 320 (split) / 384 (plain) rows make the chunk count a multiple of 512 lanes
   // BX = 224 (7 x 32 pixels, run of 256 rows starting 16 pixels early) exists for tile-count quantisation: layers whose
   // pixel count is 49 * 2^k give 3.06 / 1.53 / 0.77 workgroups per CU with 256-pixel tiles but 3.5 / 1.75 / 0.875 with 224
   static_assert(BX == 256 || (BX == 224 && SPLIT), "tile of 256 pixels, or 224 for the split path");
-  constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384), ROFF = BX == 224 ? 16 : 32;
+  static constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384), ROFF = BX == 224 ? 16 : 32;
   using E = EngineH<BX, BW, WX, WW, SPLIT, IL, S16>;
   using L = typename E::L;
-  if (IL) {
-    Xlo = Xhi + BKH;
-    Wlo = Whi + BKH;
-  }
-  const int CinS = Cin * L::RS;  // elements per pixel row / per weight tap (both planes when interleaved)
-  constexpr int TX = E::TX, TW = E::TW, NI = E::NI, NJ = E::NJ, MS = E::MS;
-  constexpr int XRUN = RR * BKH * PL;   // bf16 elements per activation-run buffer
-  constexpr int WST = BW * BKH * PL;    // bf16 elements per weight stage
-  constexpr int NXC = RR * 4 * PL / NT16;
-  constexpr int NWC = BW * 4 * PL / NT16;
+  static constexpr int TX = E::TX, TW = E::TW, NI = E::NI, NJ = E::NJ, MS = E::MS;
+  static constexpr int XRUN = RR * BKH * PL;   // bf16 elements per activation-run buffer
+  static constexpr int WST = BW * BKH * PL;    // bf16 elements per weight stage
+  static constexpr int NXC = RR * 4 * PL / NT16;
+  static constexpr int NWC = BW * 4 * PL / NT16;
   static_assert(RR * 4 * PL % NT16 == 0 && BW * 4 * PL % NT16 == 0, "every lane active in every staging instruction");
-  constexpr int DIST = NSTW - 1;
+  static constexpr int DIST = NSTW - 1;
   static_assert(NSTW == 2 || NSTW == 3, "weight ring of 2 or 3 stages");
-  constexpr int NGRP = E::NGRP;
-  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
-  __bf16 *xbuf = smem16;
-  __bf16 *wbuf = smem16 + 2 * XRUN;
-  E e;
-  e.init();
-  int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int M = F * H * W;
-  const int m0 = tm * BX, n0 = tn * BW;
-  const int cpt = Cin / BKH;
-  const int nst = 9 * cpt, ngrp = 3 * cpt;
-  const int K9 = 9 * Cin;
-  const __bf16 *zero = reinterpret_cast<const __bf16 *>(nafae_zero_page);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  static constexpr int NGRP = E::NGRP;
+  static constexpr size_t LDS_BYTES = (size_t)(2 * XRUN + NSTW * WST) * sizeof(__bf16);
 
-  // activation-run chunks of this lane: run row -> pixel (p0 - ROFF + row) + dy*W
-  const __bf16 *xp[NXC];
+  // Per-lane state of one SEGMENT = steps [st0, st1) of output tile (m0, n0).  A step is (channel chunk cc, tap):
+  // st = 9*cc + tap; a row-offset group is 3 consecutive steps, so st0 and st1 are multiples of 3; the whole tile is
+  // [0, 9*Cin/32).  begin() points the lane at its staging chunks and issues the prologue loads; step() runs one
+  // barrier-to-barrier step and accumulates into e.acc.
+  const __bf16 *xp[NXC], *wp[NWC];
   int xpix[NXC];
-#pragma unroll
-  for (int i = 0; i < NXC; i++) {
-    int plane, row, slot;
-    L::template decode<RR>(threadIdx.x + NT16 * i, row, plane, slot);
-    xpix[i] = m0 - ROFF + row;
-    xp[i] = (plane ? Xlo : Xhi) + slot * 8;
-  }
-  const __bf16 *wp[NWC];
   bool wok[NWC];
-#pragma unroll
-  for (int i = 0; i < NWC; i++) {
-    int plane, row, slot;
-    L::template decode<BW>(threadIdx.x + NT16 * i, row, plane, slot);
-    const int n = n0 + row;
-    wok[i] = n < Cout;
-    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
-  }
-  // which taps of this lane's output pixels are inside the image
   unsigned tapmask[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int m = m0 + e.pm(j);
-    unsigned mk = 0;
-    if (m < M) {
-      const int x = m % W, y = (m / W) % H;
-#pragma unroll
-      for (int t = 0; t < 9; t++) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
-      }
-    }
-    tapmask[j] = mk;
-  }
+  int st0, st1, M, W, CinS;
+  __bf16 *xbuf, *wbuf;
 
-  auto issue_x = [&](int i, int grp) {  // chunk i of the run for group grp = (cc, dy)
+  __device__ __forceinline__ void issue_x(int i, int grp) const {  // chunk i of the run for group grp = (cc, dy)
     const int cc = grp / 3, dy = grp - cc * 3 - 1;
     const long pix = (long)xpix[i] + (long)dy * W;
-    const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * CinS + cc * L::KTS : zero;
-    char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
+    const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
+    char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + (threadIdx.x >> 6) * 64) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-  };
-  auto issue_w = [&](int i, int st) {  // chunk i of the weight tile for step st = (cc, tap)
+  }
+  __device__ __forceinline__ void issue_w(int i, int st) const {  // chunk i of the weight tile for step st = (cc, tap)
     const int cc = st / 9, tap = st - cc * 9;
-    const __bf16 *src = wok[i] ? wp[i] + tap * CinS + cc * L::KTS : zero;
-    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + wave * 64) * 16;
+    const __bf16 *src = wok[i] ? wp[i] + tap * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
+    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + (threadIdx.x >> 6) * 64) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-  };
+  }
 
-  // prologue: run 0, then the first DIST weight tiles
-#pragma unroll
-  for (int i = 0; i < NXC; i++) issue_x(i, 0);
-#pragma unroll
-  for (int d = 0; d < DIST; d++)
-    if (d < nst) {
-#pragma unroll
-      for (int i = 0; i < NWC; i++) issue_w(i, d);
+  __device__ __forceinline__ void begin(const E &e, __bf16 *smem16, const ConvArgs &a, int m0, int n0, int s0, int s1) {
+    const __bf16 *Xhi = a.Xhi, *Xlo = a.Xlo, *Whi = a.Whi, *Wlo = a.Wlo;
+    const int H = a.H, Cout = a.Cout;
+    if (IL) {
+      Xlo = Xhi + BKH;
+      Wlo = Whi + BKH;
     }
+    W = a.W;
+    CinS = a.Cin * L::RS;  // elements per pixel row / per weight tap (both planes when interleaved)
+    xbuf = smem16;
+    wbuf = smem16 + 2 * XRUN;
+    M = a.F * H * W;
+    st0 = s0;
+    st1 = s1;
+    const int K9 = 9 * a.Cin;
+    // activation-run chunks of this lane: run row -> pixel (p0 - ROFF + row) + dy*W
+#pragma unroll
+    for (int i = 0; i < NXC; i++) {
+      int plane, row, slot;
+      L::template decode<RR>(threadIdx.x + NT16 * i, row, plane, slot);
+      xpix[i] = m0 - ROFF + row;
+      xp[i] = (plane ? Xlo : Xhi) + slot * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NWC; i++) {
+      int plane, row, slot;
+      L::template decode<BW>(threadIdx.x + NT16 * i, row, plane, slot);
+      const int n = n0 + row;
+      wok[i] = n < Cout;
+      wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
+    }
+    // which taps of this lane's output pixels are inside the image
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int m = m0 + e.pm(j);
+      unsigned mk = 0;
+      if (m < M) {
+        const int x = m % W, y = (m / W) % H;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+          const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
+        }
+      }
+      tapmask[j] = mk;
+    }
+    // prologue: the first run, then the first DIST weight tiles
+#pragma unroll
+    for (int i = 0; i < NXC; i++) issue_x(i, st0 / 3);
+#pragma unroll
+    for (int d = 0; d < DIST; d++)
+      if (st0 + d < st1) {
+#pragma unroll
+        for (int i = 0; i < NWC; i++) issue_w(i, st0 + d);
+      }
+  }
 
-  const int fr = e.frow();
-  for (int st = 0; st < nst; st++) {
+  __device__ __forceinline__ void step(E &e, int st) {
+    const int g1 = st1 / 3;
     // everything issued after W(st) may stay in flight: that is what step st-1 issued (only when DIST == 2)
-    if (DIST == 1 || st + 1 >= nst) {
+    if (DIST == 1 || st + 1 >= st1) {
       wait_vmcnt<0>();
     } else {
       const int sp = st - 1;
-      const bool run_prev = sp >= 0 && (sp % 3 == 0) && (sp / 3 + 1 < ngrp);
+      const bool run_prev = sp >= st0 && (sp % 3 == 0) && (sp / 3 + 1 < g1);
       if (run_prev)
         wait_vmcnt<NWC + NXC>();
       else
@@ -477,8 +482,8 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
     const int grp = st / 3;
     const int tap = st - (st / 9) * 9;
     const int dx = tap - (tap / 3) * 3 - 1;
-    const bool do_x = (st % 3 == 0) && (grp + 1 < ngrp);
-    const bool do_w = st + DIST < nst;
+    const bool do_x = (st % 3 == 0) && (grp + 1 < g1);
+    const bool do_w = st + DIST < st1;
     // staging instructions of this step, handed out between MFMA groups: first the next run, then the next weight tile
     auto between = [&](int g) {
       if (g < NXC) {
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
     }
     const __bf16 *sX = xbuf + (size_t)(grp & 1) * XRUN;
     const __bf16 *sW = wbuf + (size_t)(st % NSTW) * WST;
+    const int fr = e.frow();
 #pragma unroll
     for (int s = 0; s < E::KSTEPS; s++) {
       const int sl = e.fslot(s);
@@ -523,7 +529,140 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
       }
     }
   }
-  epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+};
+
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16>
+__global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
+                                                           const float *__restrict__ bias, float *__restrict__ Cf,
+                                                           __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
+                                                           int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
+  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, S16>;
+  using E = typename R::E;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BX, n0 = tn * BW;
+  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout};
+  const int nst = 9 * (Cin / BKH);
+  R r;
+  r.begin(e, smem16, a, m0, n0, 0, nst);
+  for (int st = 0; st < nst; st++) r.step(e, st);
+  epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+}
+
+// ------------------------------------------------------------------------------------------------ run-reuse conv, stream-K
+// Tile-count quantisation: the layers whose pixel count is 49 * 2^k launch 784 / 392 tiles = 3.06 / 1.53 rounds on 256
+// CUs (one 140 KB-LDS workgroup per CU), and the time steps at whole rounds (measured: 62 frames 0.617 ms, 63-83
+// frames 0.755-0.80 ms, 84 frames 0.94 ms at 256->256 @56^2), so a quarter of the chip idles in the last round.  Here the
+// work of a launch is the list of (tile, row-offset group) units, tile-major; G = #CUs workgroups each take an equal
+// CONTIGUOUS share of it (stream-K).  A workgroup finishes the tiles that lie wholly inside its share exactly as the
+// kernel above does; for the tile(s) cut by a share boundary it writes the fp32 partial accumulators to `scratch` (slot
+// 2w for its first segment, 2w+1 for its last), and conv_sk_fixup_kernel -- the kernel boundary is the only
+// synchronisation -- adds the partials of each cut tile in workgroup order and runs the normal epilogue.  Deterministic:
+// the summation order is fixed by the share arithmetic.
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX>
+__global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi,
+                                                              const __bf16 *Wlo, const float *__restrict__ bias,
+                                                              float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                                                              __bf16 *__restrict__ Clo, int F, int H, int W, int Cin, int Cout,
+                                                              int relu, int tiles_m, int tiles_n, float *__restrict__ scratch) {
+  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false>;
+  using E = typename R::E;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  E e;
+  e.init();
+  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout};
+  const int ngrp = 3 * (Cin / BKH);
+  const long U = (long)tiles_m * tiles_n * ngrp;
+  const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
+  constexpr int NACC4 = E::NI * E::NJ * E::NG;   // float4 pieces of the accumulator per lane
+  if (u0 >= u1) return;
+  // ONE flat loop over the steps of this workgroup's share (the matrix body must appear once in the code: nested
+  // segment / step loops get unswitched into seven copies of it and spill); `st` is the step inside the current tile
+  R r;
+  long u = u0;          // first unit of the current segment
+  int st = 0, m0 = 0, n0 = 0;
+  bool fresh = true;    // the next iteration opens a segment
+  const long nsteps = 3 * (u1 - u0);
+  for (long it = 0; it < nsteps; it++) {
+    if (fresh) {
+      const int t = (int)(u / ngrp), ga = (int)(u - (long)t * ngrp);
+      const int gb = (u1 - u) < (long)(ngrp - ga) ? ga + (int)(u1 - u) : ngrp;
+      const int tm = t / tiles_n, tn = t - tm * tiles_n;   // the n-tiles of one pixel run back to back: its halo stays in L2
+      m0 = tm * BX;
+      n0 = tn * BW;
+      if (it) {
+        wait_vmcnt<0>();
+        __syncthreads();                                   // every wave is done with the previous segment's LDS buffers
+        e.zero_acc();
+      }
+      st = 3 * ga;
+      r.begin(e, smem16, a, m0, n0, 3 * ga, 3 * gb);
+      fresh = false;
+    }
+    r.step(e, st);
+    st++;
+    if (st == r.st1) {                                     // segment complete
+      const int ga = r.st0 / 3, gb = r.st1 / 3;
+      if (ga == 0 && gb == ngrp) {
+        epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+      } else {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < E::NI; i++)
+#pragma unroll
+          for (int j = 0; j < E::NJ; j++)
+#pragma unroll
+            for (int g = 0; g < E::NG; g++) {
+              f32x4 v;
+#pragma unroll
+              for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
+              dst[(size_t)((i * E::NJ + j) * E::NG + g) * NT16] = v;
+            }
+      }
+      u += gb - ga;
+      fresh = true;
+    }
+  }
+}
+
+// One workgroup per share boundary w (between workgroups w-1 and w of the kernel above).  The boundary that is the FIRST
+// one strictly inside a tile owns that tile: it adds the contributors' partials in workgroup order and writes the tile.
+template <int BW, int WX, int WW, bool SPLIT, bool IL, int BX>
+__global__ __launch_bounds__(NT16) void conv_sk_fixup_kernel(const float *__restrict__ scratch, const float *__restrict__ bias,
+                                                             float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                                                             __bf16 *__restrict__ Clo, int M, int Cout, int relu, int tiles_m,
+                                                             int tiles_n, int ngrp, int G) {
+  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, false>;
+  const int w = blockIdx.x + 1;
+  const long U = (long)tiles_m * tiles_n * ngrp;
+  const long b = U * w / G;
+  const int t = (int)(b / ngrp);
+  const long t0 = (long)t * ngrp, t1 = t0 + ngrp;
+  if (b == t0) return;                       // the boundary lies on a tile edge
+  if (U * (w - 1) / G > t0) return;          // an earlier boundary lies strictly inside this tile and owns it
+  E e;
+  e.init();
+  constexpr int NACC4 = E::NI * E::NJ * E::NG;
+  for (int c = w - 1; c < G; c++) {
+    const long c0 = U * c / G;
+    if (c0 >= t1) break;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < E::NI; i++)
+#pragma unroll
+      for (int j = 0; j < E::NJ; j++)
+#pragma unroll
+        for (int g = 0; g < E::NG; g++) {
+          const f32x4 v = src[(size_t)((i * E::NJ + j) * E::NG + g) * NT16];
+#pragma unroll
+          for (int q = 0; q < 4; q++) e.acc[i][j][4 * g + q] += v[q];
+        }
+  }
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  epilogue<E, SPLIT>(e, tm * BX, tn * BW, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv, 3 taps / barrier
@@ -890,6 +1029,48 @@ int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const voi
   return launched();
 }
 
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+
+// stream-K pays when the last round of a one-tile-per-workgroup launch is mostly empty
+inline bool sk_pays(long tiles, int G) {
+  // NAFAE_CONV_SK=0 disables it (A/B, and runs that must not depend on the batch size in the last bit: which tiles are
+  // cut -- hence the order their partial sums are added in -- depends on the tile count).  Read on every call.
+  const char *e = getenv("NAFAE_CONV_SK");
+  if ((e && e[0] == '0') || tiles <= G) return false;
+  const long rounds = (tiles + G - 1) / G;
+  return (double)(rounds * G - tiles) / (double)(rounds * G) > 0.10;
+}
+inline size_t sk_scratch_bytes(int BX, int BW, int G) { return (size_t)2 * G * BX * BW * sizeof(float); }
+
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX = 256>
+int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
+                       void *Clo, int F, int H, int W, int Cin, int Cout, int relu, float *scratch, int G, hipStream_t st) {
+  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false>;
+  const int M = F * H * W;
+  const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
+  auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX>;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES);
+    once = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
+                     (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch);
+  if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
+  hipLaunchKernelGGL((conv_sk_fixup_kernel<BW, WX, WW, SPLIT, IL, BX>), dim3(G - 1), dim3(NT16), 0, st, scratch, bias, Cf,
+                     (__bf16 *)Chi, (__bf16 *)Clo, M, Cout, relu, tiles_m, tiles_n, 3 * (Cin / BKH), G);
+  return launched();
+}
+
 template <int BW, int WX, int WW, bool IL = false>
 int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                      void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
@@ -993,9 +1174,25 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                                             alpha, act, S(stream));
 }
 
+int64_t nafae_conv3x3_bf16_workspace_bytes(int F, int H, int W, int Cin, int Cout) {
+  if (F <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (long)F * H * W >= (1L << 31)) return NAFAE_EINVAL;
+  if (Cout <= 64 || Cin % 32) return 0;
+  const int M = F * H * W, G = num_cus();
+  const int bw = (Cout >= 256 && M >= 256 * 128) ? 256 : 128;
+  const long tiles = (long)((M + 255) / 256) * ((Cout + bw - 1) / bw);
+  return sk_pays(tiles, G) ? (int64_t)sk_scratch_bytes(256, bw, G) : 0;
+}
+
 int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
                        float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
                        void *stream) {
+  return nafae_conv3x3_bf16_ws(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu, nullptr, 0,
+                               stream);
+}
+
+int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
+                          float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
+                          void *workspace, int64_t workspace_bytes, void *stream) {
   if (!in_hi || !w_hi || !bias || (!out_f32 && !out_hi) || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
   if (Cin % 32 || Cout % 4 || !al16(in_hi) || !al16(w_hi)) return NAFAE_EINVAL;
   if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
@@ -1039,12 +1236,20 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
         return launch_conv_run<256, 1, 8, 2, true, true, 224>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin,
                                                               Cout, relu, S(stream));
       if (Cout >= 256 && M >= 256 * 128) {
+        if (il && workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 255) / 256), num_cus()) &&
+            workspace_bytes >= (int64_t)sk_scratch_bytes(256, 256, num_cus()))
+          return launch_conv_run_sk<256, 2, 4, 2, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin,
+                                                              Cout, relu, (float *)workspace, num_cus(), S(stream));
         if (il)
           return launch_conv_run<256, 2, 4, 2, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout,
                                                            relu, S(stream));
         return launch_conv_run<256, 2, 4, 2, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                    S(stream));
       }
+      if (il && workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 127) / 128), num_cus()) &&
+          workspace_bytes >= (int64_t)sk_scratch_bytes(256, 128, num_cus()))
+        return launch_conv_run_sk<128, 4, 2, 3, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin,
+                                                            Cout, relu, (float *)workspace, num_cus(), S(stream));
       if (il)
         return launch_conv_run<128, 4, 2, 3, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout,
                                                          relu, S(stream));

@@ -270,8 +270,23 @@ def gemm_nt_bf16(X, Wt, bias=None, alpha=1.0, act=ACT_NONE, want_f32=False, want
     return cf, (C if want_planes else None)
 
 
-def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True):
-    """X Planes [F,H,W,Cin], Wt Planes [Cout,3,3,Cin] -> (f32 or None, Planes or None) of [F,H,W,Cout]."""
+_conv_ws = {}
+
+
+def _conv_workspace(nbytes, device):
+    """Scratch of the stream-K conv schedule, one buffer per (device, stream): launches on one stream are ordered, so they
+    can share it; concurrent streams (pipelined trainer, conv_streams) each get their own."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _conv_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        _conv_ws[key] = t
+    return t
+
+
+def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_workspace=True):
+    """X Planes [F,H,W,Cin], Wt Planes [Cout,3,3,Cin] -> (f32 or None, Planes or None) of [F,H,W,Cout].
+    use_workspace=False forces the one-tile-per-workgroup schedule (tests / A-B)."""
     _chk_planes(X, "X"); _chk_planes(Wt, "W"); _chk(bias)
     F, H, W, Cin = X.shape
     Cout = Wt.shape[0]
@@ -284,8 +299,10 @@ def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True):
     cf = torch.empty(F, H, W, Cout, device=X.hi.device, dtype=torch.float32) if want_f32 else None
     C = (_alloc_planes((F, H, W, Cout), X.hi.device, split, X.il and Cout % 32 == 0) if want_planes
          else Planes(None, None, False, (F, H, W, Cout)))
-    _rc(_lib.lib().nafae_conv3x3_bf16(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), _p(cf), _p(C.hi), _p(C.lo), F, H, W, Cin,
-                                      Cout, int(bool(relu)), _stream()), "nafae_conv3x3_bf16")
+    nws = int(_lib.lib().nafae_conv3x3_bf16_workspace_bytes(F, H, W, Cin, Cout)) if (split and X.il and use_workspace) else 0
+    ws = _conv_workspace(nws, X.hi.device) if nws > 0 else None
+    _rc(_lib.lib().nafae_conv3x3_bf16_ws(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), _p(cf), _p(C.hi), _p(C.lo), F, H, W,
+                                         Cin, Cout, int(bool(relu)), _p(ws), max(nws, 0), _stream()), "nafae_conv3x3_bf16_ws")
     return cf, (C if want_planes else None)
 
 

@@ -177,3 +177,33 @@ def test_detector_c1_in_bf16_modes(ops, precision, tol):
         # plain bf16 moves box coordinates by O(0.1 px): compare the head on the HIP path's own rois
         pooled_t = OD.roi_align_avg(base_o, rois.cpu().view(-1, 5))
         assert relerr(fc7.cpu(), OD.head_to_tail(pooled_t, sd)) < tol
+
+
+@pytest.mark.parametrize("F,H,Cin,Cout", [(64, 56, 64, 256), (64, 28, 256, 512), (24, 56, 64, 128), (5, 56, 32, 256), (33, 28, 64, 512)])
+def test_conv_stream_k_schedule(F, H, Cin, Cout):
+    """Stream-K schedule of the run-reuse conv (tile counts that leave the last round mostly empty: 784 / 392 / 294 / 62 / 204
+    tiles) against the one-tile-per-workgroup schedule: same values up to the fp32 order in which the partial sums of a
+    cut tile are added, deterministic, and within the bf16x3 bar of the fp32 conv."""
+    from nafae_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(F + H)
+    x = torch.randn(F, H, H, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    xp, wp = ops.split_bf16(x, True, True), ops.split_bf16(w, True, True)
+    nws = _lib.lib().nafae_conv3x3_bf16_workspace_bytes(F, H, H, Cin, Cout)
+    f0, p0 = ops.conv3x3_bf16(xp, wp, b, relu=False, want_f32=True, use_workspace=False)
+    f1, p1 = ops.conv3x3_bf16(xp, wp, b, relu=False, want_f32=True)
+    f2, p2 = ops.conv3x3_bf16(xp, wp, b, relu=False, want_f32=True)
+    assert torch.equal(f1, f2) and torch.equal(p1.hi, p2.hi)                       # deterministic
+    scale = float(f0.abs().max())
+    if nws > 0:
+        assert float((f1 - f0).abs().max()) <= 2e-6 * scale
+        # planes: hi + lo carries ~17 bits, so two fp32 values one ulp apart may merge 2^-17 apart
+        assert float((ops.merge_bf16(p1) - ops.merge_bf16(p0)).abs().max()) <= 2e-5 * scale
+    else:
+        assert torch.equal(f1, f0)                                                 # schedule not selected: same kernel
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    assert float((f1 - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
+    assert float((torch.relu(f1) - ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)[0]).abs().max()) == 0.0
+    if (F, H, Cin, Cout) == (64, 56, 64, 256):
+        assert nws > 0                                                             # 784 tiles on 256 CUs: selected

@@ -58,7 +58,11 @@ def test_frames_entries_are_slices_of_the_whole():
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_exact_mode_equals_single_process(world):
+def test_exact_mode_equals_single_process(world, monkeypatch):
+    # the stream-K conv schedule adds the partial sums of a cut tile in an order that depends on the tile count, i.e. on
+    # how many frames a rank holds; switch it off so that the detector is bit-identical for 4, 8 and 16 frames and the
+    # tolerances below measure the exchange alone
+    monkeypatch.setenv("NAFAE_CONV_SK", "0")
     from nafae_amd.model import default_args
     from nafae_amd.train import make_batch, setup_training, train_step
     steps = 2
