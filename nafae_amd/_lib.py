@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnafae_hip.so")
+# NAFAE_LIB points at another build of the same library (kernel A/B experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("NAFAE_LIB") or os.path.join(_HERE, "csrc", "libnafae_hip.so")
 _lib = None
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64

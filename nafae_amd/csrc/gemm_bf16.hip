@@ -10,6 +10,7 @@
 #include "bf16_tile.h"
 #include "mfma_tile.h"  // tile_coords
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/nafae_hip.h"
 
 using namespace nafae;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_bf16_kernel(const __bf16 *__rest
     if (kt + 1 < nk) store(nxt);
     __syncthreads();
   }
-  epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  epilogue<E, SPLIT>(e, m0, n0, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
 // ------------------------------------------------------------------------------------------------ LDS-DMA pipeline
@@ -325,24 +326,30 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
 
   issue(0, 0);
   if (DIST > 1 && nk > 1) issue(1, 1);
-  for (int kt = 0; kt < nk; kt++) {
+  // The loop is peeled into "a later tile exists" (staging unconditional) and the last DIST tiles (no staging): a
+  // per-instruction `if (more)` costs a branch around every staging instruction, which cuts the k-tile into a dozen
+  // scheduling regions and pins the LDS reads / MFMAs inside them.
+  auto tile = [&](int kt, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
     if (DIST > 1 && kt + 1 < nk)
       wait_vmcnt<(DIST - 1) * E::NCH>();  // tile kt has landed; the younger tile(s) may still be in flight
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // everyone's share of tile kt is in LDS, and everyone is done reading stage (kt-1)%NST
-    const bool more = kt + DIST < nk;
     const int nstage = (kt + DIST) % NST;
-    if (E::NCH > NGRP && more) {  // more staging instructions than MFMA groups: the surplus goes first
+    if (E::NCH > NGRP && MORE) {  // more staging instructions than MFMA groups: the surplus goes first
 #pragma unroll
       for (int i = NGRP; i < E::NCH; i++) issue_one(i, kt + DIST, nstage);
     }
     // (measured: handing the staging instructions out between MFMA groups beats issuing them all behind the barrier
     // even with only one tile in flight -- 4.23 vs 4.58 ms at the fc6 shape)
     e.compute(smem16 + (size_t)(kt % NST) * E::STAGE, [&](int g) {
-      if (g < E::NCH && g < NGRP && more) issue_one(g, kt + DIST, nstage);
+      if (MORE && g < E::NCH && g < NGRP) issue_one(g, kt + DIST, nstage);
     });
-  }
+  };
+  int kt = 0;
+  for (; kt + DIST < nk; kt++) tile(kt, std::true_type{});
+  for (; kt < nk; kt++) tile(kt, std::false_type{});
   epilogue<E, SPLIT>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
 }
 
@@ -359,6 +366,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
 struct ConvArgs {
   const __bf16 *Xhi, *Xlo, *Whi, *Wlo;
   int F, H, W, Cin, Cout;
+  int dbg;  // timing experiments only (relu bit 8 / bit 9): 1 = every staging load hits the zero page, 2 = only the weights do
 };
 
 template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16>
@@ -389,20 +397,20 @@ struct ConvRun {
   int xpix[NXC];
   bool wok[NWC];
   unsigned tapmask[NJ];
-  int st0, st1, M, W, CinS;
+  int st0, st1, M, W, CinS, dbg;
   __bf16 *xbuf, *wbuf;
 
   __device__ __forceinline__ void issue_x(int i, int grp) const {  // chunk i of the run for group grp = (cc, dy)
     const int cc = grp / 3, dy = grp - cc * 3 - 1;
     const long pix = (long)xpix[i] + (long)dy * W;
-    const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
+    const __bf16 *src = (pix >= 0 && pix < M && dbg != 1) ? xp[i] + pix * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
     char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + (threadIdx.x >> 6) * 64) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   }
   __device__ __forceinline__ void issue_w(int i, int st) const {  // chunk i of the weight tile for step st = (cc, tap)
     const int cc = st / 9, tap = st - cc * 9;
-    const __bf16 *src = wok[i] ? wp[i] + tap * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
+    const __bf16 *src = (wok[i] && dbg == 0) ? wp[i] + tap * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
     char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + (threadIdx.x >> 6) * 64) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -416,6 +424,7 @@ struct ConvRun {
       Wlo = Whi + BKH;
     }
     W = a.W;
+    dbg = a.dbg;
     CinS = a.Cin * L::RS;  // elements per pixel row / per weight tap (both planes when interleaved)
     xbuf = smem16;
     wbuf = smem16 + 2 * XRUN;
@@ -544,12 +553,12 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
   int tm, tn;
   tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BX, n0 = tn * BW;
-  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout};
+  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout, (relu >> 8) & 3};
   const int nst = 9 * (Cin / BKH);
   R r;
   r.begin(e, smem16, a, m0, n0, 0, nst);
   for (int st = 0; st < nst; st++) r.step(e, st);
-  epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv, stream-K
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi,
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   E e;
   e.init();
-  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout};
+  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout, (relu >> 8) & 3};
   const int ngrp = 3 * (Cin / BKH);
   const long U = (long)tiles_m * tiles_n * ngrp;
   const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi,
     if (st == r.st1) {                                     // segment complete
       const int ga = r.st0 / 3, gb = r.st1 / 3;
       if (ga == 0 && gb == ngrp) {
-        epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+        epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
       } else {
         f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
 #pragma unroll
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(NT16) void conv_sk_fixup_kernel(const float *__rest
         }
   }
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
-  epilogue<E, SPLIT>(e, tm * BX, tn * BW, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  epilogue<E, SPLIT>(e, tm * BX, tn * BW, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv, 3 taps / barrier
@@ -796,7 +805,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, c
       }
     }
   }
-  epilogue<E, true>(e, m0, n0, M, Cout, 1.0f, bias, relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  epilogue<E, true>(e, m0, n0, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
 // ------------------------------------------------------------------------------------------------ plane helpers

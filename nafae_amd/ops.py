@@ -284,7 +284,7 @@ def _conv_workspace(nbytes, device):
     return t
 
 
-def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_workspace=True):
+def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_workspace=True, _dbg=0):
     """X Planes [F,H,W,Cin], Wt Planes [Cout,3,3,Cin] -> (f32 or None, Planes or None) of [F,H,W,Cout].
     use_workspace=False forces the one-tile-per-workgroup schedule (tests / A-B)."""
     _chk_planes(X, "X"); _chk_planes(Wt, "W"); _chk(bias)
@@ -302,7 +302,8 @@ def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_w
     nws = int(_lib.lib().nafae_conv3x3_bf16_workspace_bytes(F, H, W, Cin, Cout)) if (split and X.il and use_workspace) else 0
     ws = _conv_workspace(nws, X.hi.device) if nws > 0 else None
     _rc(_lib.lib().nafae_conv3x3_bf16_ws(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), _p(cf), _p(C.hi), _p(C.lo), F, H, W,
-                                         Cin, Cout, int(bool(relu)), _p(ws), max(nws, 0), _stream()), "nafae_conv3x3_bf16_ws")
+                                         Cin, Cout, int(bool(relu)) | (int(_dbg) << 8), _p(ws), max(nws, 0), _stream()),
+        "nafae_conv3x3_bf16_ws")
     return cf, (C if want_planes else None)
 
 
