@@ -190,6 +190,10 @@ class _fasterRCNN(nn.Module):
                 outs.append(self._base_features_one(chunk, P))
         for st in self._streams:
             main.wait_stream(st)
+        for o in outs:      # allocated on a side stream, read by the concatenation on the main stream
+            for t in ((o.hi, o.lo) if isinstance(o, ops.Planes) else (o,)):
+                if t is not None:
+                    t.record_stream(main)
         if isinstance(outs[0], ops.Planes):
             hi = torch.cat([o.hi for o in outs], 0)
             shape = (F,) + tuple(outs[0].shape[1:])

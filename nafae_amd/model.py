@@ -314,6 +314,9 @@ def stepRCNN(im_data, im_info, gt_boxes, num_boxes, ground_model, step_size=64, 
             dbuf = [torch.empty(shape, dtype=im_data.dtype, device=dev) for _ in range(2)]
             landed, consumed = [None, None], [None, None]
             info_dev = im_info.to(dev, non_blocking=True)
+            # the device buffers come from the main stream's allocator pool: kernels enqueued earlier on the main stream
+            # may still be using the recycled memory, so the copy stream must not start writing before they are done
+            copy.wait_stream(main)
 
             def stage(i):
                 s, e = chunks[i]
