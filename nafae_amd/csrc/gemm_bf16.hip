@@ -847,58 +847,78 @@ __global__ __launch_bounds__(256) void merge_kernel(const __bf16 *hi, const __bf
   }
 }
 
-// First VGG layer (Cin = 3), fp32 NCHW frames in, bf16 planes out (NHWC, 64 channels).
+// First VGG layer (Cin = 3), fp32 NCHW frames in, bf16 planes out (NHWC, 64 channels).  K = 27 is too short for the matrix
+// cores; this is a vector-ALU kernel priced against the fp32 FMA rate (1728 FMAs per pixel, 5.5 G per C2 step) and the
+// 822 MB of planes it writes.  One lane = one pixel: its 27 taps live in registers, and every weight is a compile-time
+// position of a uniform array, so the compiler fetches it with scalar loads (16 KB scalar cache, 6.9 KB of weights) and
+// feeds it to v_fmac as the SGPR operand -- no LDS traffic in the inner loop (the previous version read the weights from
+// LDS, 4 ds_read_b128 per 16 FMAs, and ran at a third of the FMA rate).  Channels are produced in two halves of 32 (one
+// interleaved plane piece = hi 32 | lo 32 = one 128-B line per pixel), transposed through LDS so that every store
+// instruction writes 8 full lines.  Summation order per output: bias, then (ci, ky, kx) ascending, fused multiply-adds.
 __global__ __launch_bounds__(256) void conv1_bf16_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                          const float *__restrict__ bias, __bf16 *ohi, __bf16 *olo, int F,
                                                          int H, int W) {
-  __shared__ float sw[27 * 64];
-  __shared__ float sb[64];
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-    int co = i & 63, k = i >> 6;
-    sw[i] = w[co * 27 + k];
-  }
-  if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
-  __syncthreads();
+  constexpr int ROWB = 128 + 16;                      // LDS bytes per pixel: hi 32 | lo 32 (+16 B pad against bank conflicts)
+  __shared__ __attribute__((aligned(16))) char stage[256 * ROWB];
   const long total = (long)F * H * W;
-  const long p = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
-  if (p >= total) return;
-  const int cg = (threadIdx.x & 3) * 16;
-  const int x = p % W;
-  const int y = (p / W) % H;
-  const long n = p / ((long)W * H);
-  float acc[16];
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < total;
+  const long pc = live ? p : total - 1;
+  const int x = pc % W;
+  const int y = (pc / W) % H;
+  const long n = pc / ((long)W * H);
+  float v[27];
 #pragma unroll
-  for (int c = 0; c < 16; c++) acc[c] = sb[cg + c];
-#pragma unroll 1
-  for (int ci = 0; ci < 3; ci++)  // not unrolled: a fully unrolled body keeps all 27x16 weights live (256 VGPRs, 1 wave/SIMD)
-#pragma unroll 1
+  for (int ci = 0; ci < 3; ci++)
+#pragma unroll
     for (int ky = 0; ky < 3; ky++)
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const int yy = y + ky - 1, xx = x + kx - 1;
-        float v = 0.f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((n * 3 + ci) * H + yy) * W + xx];
-        const float *wk = &sw[(ci * 9 + ky * 3 + kx) * 64 + cg];
-#pragma unroll
-        for (int c = 0; c < 16; c++) acc[c] = fmaf(v, wk[c], acc[c]);
+        v[ci * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((n * 3 + ci) * H + yy) * W + xx] : 0.f;
       }
-  bf16x8 h[2], l[2];
+  const bool il = plane_il(ohi, olo);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long wave_p0 = (long)blockIdx.x * 256 + wave * 64;   // first pixel of this wave
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    float acc[32];
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    __bf16 a, b;
-    split_bf16(fmaxf(acc[c], 0.f), a, b);
-    h[c >> 3][c & 7] = a;
-    l[c >> 3][c & 7] = b;
-  }
-  // 16 channels cg..cg+15 sit inside one 32-channel piece in either layout
-  const long o = plane_il(ohi, olo) ? p * 128 + ((cg >> 5) << 6) + (cg & 31) : p * 64 + cg;
-  bf16x8 *oh = reinterpret_cast<bf16x8 *>(ohi + o);
-  oh[0] = h[0];
-  oh[1] = h[1];
-  if (olo) {
-    bf16x8 *ol = reinterpret_cast<bf16x8 *>(olo + o);
-    ol[0] = l[0];
-    ol[1] = l[1];
+    for (int c = 0; c < 32; c++) {
+      const int co = half * 32 + c;
+      float a = bias[co];
+#pragma unroll
+      for (int k = 0; k < 27; k++) a = fmaf(v[k], w[co * 27 + k], a);
+      acc[c] = a;
+    }
+    char *row = stage + threadIdx.x * ROWB;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; c8++) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        __bf16 a, b;
+        split_bf16(fmaxf(acc[c8 * 8 + c], 0.f), a, b);
+        h[c] = a;
+        l[c] = b;
+      }
+      *reinterpret_cast<bf16x8 *>(row + c8 * 16) = h;
+      *reinterpret_cast<bf16x8 *>(row + 64 + c8 * 16) = l;
+    }
+    __syncthreads();
+    // 64 pixels x 8 pieces of 16 B per wave: piece j = plane*4 + part of pixel q>>3
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int q = it * 64 + lane, px = q >> 3, j = q & 7, plane = j >> 2, part = j & 3;
+      const long pg = wave_p0 + px;
+      if (pg < total && (plane == 0 || olo)) {
+        const bf16x8 d = *reinterpret_cast<const bf16x8 *>(stage + (wave * 64 + px) * ROWB + j * 16);
+        __bf16 *dst = il ? ohi + pg * 128 + half * 64 + plane * 32 + part * 8
+                         : (plane ? olo : ohi) + pg * 64 + half * 32 + part * 8;
+        *reinterpret_cast<bf16x8 *>(dst) = d;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1309,8 +1329,8 @@ int nafae_conv1_3x3_relu_bf16(const float *in_nchw, const float *w, const float 
                               int H, int W, void *stream) {
   if (!in_nchw || !w || !bias || !out_hi || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
   long total = (long)F * H * W;
-  if ((total + 63) / 64 > 0x7fffffffL) return NAFAE_ELIMIT;
-  hipLaunchKernelGGL(conv1_bf16_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, S(stream), in_nchw, w, bias,
+  if ((total + 255) / 256 > 0x7fffffffL) return NAFAE_ELIMIT;
+  hipLaunchKernelGGL(conv1_bf16_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, S(stream), in_nchw, w, bias,
                      (__bf16 *)out_hi, (__bf16 *)out_lo, F, H, W);
   return launched();
 }
