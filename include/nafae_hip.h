@@ -195,6 +195,14 @@ int nafae_roi_align_avg_nhwc_bf16(const void *feat_hi, const void *feat_lo, int 
                                   const float *rois, int N, float spatial_scale, void *out_hi, void *out_lo,
                                   float *out_f32, void *stream);
 
+/* The same fused RoIAlignAvg from an fp32 NHWC feature map (e.g. nafae_merge_bf16 of the conv5_3 planes, once per
+ * step) to the planes fc6 consumes: the bilinear weights of a sample are formed once (in double, as
+ * roi_align_kernel.cu:64-67 writes them, then rounded) and applied with fp32 FMAs.  Agrees with
+ * nafae_roi_align_avg_nhwc to ~1e-7, well inside the 2^-17 the planes hold.  out_lo NULL: plain bf16 output. */
+int nafae_roi_align_avg_nhwc_to_planes(const float *feat, int F, int H, int W, int C, const float *rois, int N,
+                                       float spatial_scale, void *out_hi, void *out_lo, float *out_f32,
+                                       void *stream);
+
 /* ---- similarity + loss (DVSA.forward, model.py:517-614) ---------------------------------------- */
 
 /* S_ = V W^T with masked query slots, reduced on the fly to per-frame max / arg-max over the Nb proposals

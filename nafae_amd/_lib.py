@@ -45,6 +45,7 @@ SIGNATURES = {
     "nafae_conv1_3x3_relu_bf16": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "nafae_maxpool2x2_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_roi_align_avg_nhwc_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, c_float, P, P, P, P]),
+    "nafae_roi_align_avg_nhwc_to_planes": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, P, P, P, P]),
     "nafae_sim_max_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "nafae_loss_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "nafae_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, P, P, P]),

@@ -418,6 +418,78 @@ __global__ __launch_bounds__(128) void roi_align_avg_nhwc_bf16_kernel(const __bf
   }
 }
 
+// RoIAlignAvg from an fp32 NHWC feature map straight to the bf16 planes fc6 consumes (and, optionally, the fp32
+// `pooled_feat`).  The detector merges the conv5_3 planes to fp32 once per step (25.7 MB at C2) instead of once per tap
+// here (4.3 G tap reads), and the bilinear weights of a sample -- the reference's double-precision products
+// (roi_align_kernel.cu:64-67), rounded once -- are shared by all channels, so a sample costs 4 fp32 FMAs per channel.
+// The result differs from the exact-fp32 kernel above by the rounding of the weights (~1e-7), far inside the 2^-17 of
+// the planes it is stored in; the exact kernel stays the one behind precision = 'f32'.
+__global__ __launch_bounds__(128) void roi_align_avg_to_planes_kernel(const float *__restrict__ feat, int H, int W, int C,
+                                                                      const float *__restrict__ rois, float scale, __bf16 *ohi,
+                                                                      __bf16 *olo, float *__restrict__ of32) {
+  const int n = blockIdx.x;
+  const bool il = olo != nullptr && reinterpret_cast<const char *>(olo) == reinterpret_cast<const char *>(ohi) + 64;
+  const int CS = il ? 2 * C : C;  // elements per output pixel row behind one plane pointer
+  const RoiGeom g = roi_geom(rois + (long)n * 5, scale, AS, AS);
+  __shared__ int s_off[AS * AS];           // element offset of the up-left tap, or -1: sample outside the map
+  __shared__ f32x4 s_wt[AS * AS];          // (1-hr)(1-wr), (1-hr)wr, hr(1-wr), hr wr
+  if (threadIdx.x < AS * AS) {
+    const int ph = threadIdx.x / AS, pw = threadIdx.x - ph * AS;
+    const float h = (float)ph * g.bin_h + g.start_h;
+    const float w = (float)pw * g.bin_w + g.start_w;
+    const int hs = (int)fminf(floorf(h), (float)(H - 2));
+    const int ws = (int)fminf(floorf(w), (float)(W - 2));
+    const bool ok = !(h < 0 || h >= H) && !(w < 0 || w >= W);
+    const double hr = (double)(h - (float)hs), wr = (double)(w - (float)ws);
+    s_off[threadIdx.x] = ok ? (hs * W + ws) * C : -1;
+    s_wt[threadIdx.x] = f32x4{(float)((1. - hr) * (1. - wr)), (float)((1. - hr) * wr), (float)(hr * (1. - wr)), (float)(hr * wr)};
+  }
+  __syncthreads();
+  const float *img = feat + (long)g.img * H * W * C;
+  const long ob = (long)n * PS * PS * CS;
+  const long rs = (long)W * C;
+  for (int c = threadIdx.x * 4; c < C; c += 512) {
+    f32x4 prev[AS], cur[AS];
+#pragma unroll
+    for (int ph = 0; ph < AS; ph++) {
+#pragma unroll
+      for (int pw = 0; pw < AS; pw++) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int off = s_off[ph * AS + pw];
+        if (off >= 0) {
+          const float *p = img + off + c;
+          const f32x4 wt = s_wt[ph * AS + pw];
+          const f32x4 ul = *reinterpret_cast<const f32x4 *>(p), ur = *reinterpret_cast<const f32x4 *>(p + C);
+          const f32x4 dl = *reinterpret_cast<const f32x4 *>(p + rs), dr = *reinterpret_cast<const f32x4 *>(p + rs + C);
+          v = ul * wt[0] + ur * wt[1] + dl * wt[2] + dr * wt[3];
+        }
+        cur[pw] = v;
+      }
+      if (ph > 0) {
+#pragma unroll
+        for (int pw = 0; pw < PS; pw++) {
+          bf16x4_t hv, lv;
+          f32x4 fv;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float sv = (((prev[pw][q] + prev[pw + 1][q]) + cur[pw][q]) + cur[pw + 1][q]) / 4.0f;
+            const __bf16 hq = (__bf16)sv;
+            hv[q] = hq;
+            lv[q] = (__bf16)(sv - (float)hq);
+            fv[q] = olo ? (float)hq + (float)lv[q] : (float)hq;   // exactly what merging the planes would give
+          }
+          if (of32) *reinterpret_cast<f32x4 *>(of32 + (long)n * PS * PS * C + ((ph - 1) * PS + pw) * (long)C + c) = fv;
+          const long o = ob + ((ph - 1) * PS + pw) * (long)CS + (il ? ((c >> 5) << 6) + (c & 31) : c);
+          *reinterpret_cast<bf16x4_t *>(ohi + o) = hv;
+          if (olo) *reinterpret_cast<bf16x4_t *>(olo + o) = lv;
+        }
+      }
+#pragma unroll
+      for (int pw = 0; pw < AS; pw++) prev[pw] = cur[pw];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -518,6 +590,16 @@ int nafae_roi_align_avg_nhwc_bf16(const void *feat_hi, const void *feat_lo, int 
   if ((feat_lo == nullptr) != (out_lo == nullptr)) return NAFAE_EINVAL;
   hipLaunchKernelGGL(roi_align_avg_nhwc_bf16_kernel, dim3(N), dim3(128), 0, S(stream), (const __bf16 *)feat_hi,
                      (const __bf16 *)feat_lo, H, W, C, rois, spatial_scale, (__bf16 *)out_hi, (__bf16 *)out_lo, out_f32);
+  return launched();
+}
+
+int nafae_roi_align_avg_nhwc_to_planes(const float *feat, int F, int H, int W, int C, const float *rois, int N,
+                                       float spatial_scale, void *out_hi, void *out_lo, float *out_f32, void *stream) {
+  if (!feat || !rois || !out_hi || F <= 0 || H < 2 || W < 2 || C <= 0 || N <= 0) return NAFAE_EINVAL;
+  if (C & 3) return NAFAE_EINVAL;
+  if ((long)H * W * C >= (1L << 31)) return NAFAE_ELIMIT;
+  hipLaunchKernelGGL(roi_align_avg_to_planes_kernel, dim3(N), dim3(128), 0, S(stream), feat, H, W, C, rois, spatial_scale,
+                     (__bf16 *)out_hi, (__bf16 *)out_lo, out_f32);
   return launched();
 }
 

@@ -238,10 +238,14 @@ class _fasterRCNN(nn.Module):
             R = rois.shape[0] * rois.shape[1]
             if self.precision != 'f32':
                 with ops.timed("roi_align"):   # planes for fc6 and (API parity) the fp32 pooled_feat in one pass
+                    sp = self.precision == 'bf16x3'
+                    feat32 = ops.merge_bf16(base_feat)          # conv5_3 as fp32 once (25.7 MB), not once per bilinear tap
                     if self.materialize_pooled:
-                        pooled_pl, pooled = ops.roi_align_avg_nhwc_bf16(base_feat, rois.view(R, 5), 1.0 / 16.0, want_f32=True)
+                        pooled_pl, pooled = ops.roi_align_avg_nhwc_to_planes(feat32, rois.view(R, 5), 1.0 / 16.0, split=sp, il=sp,
+                                                                             want_f32=True)
                     else:
-                        pooled_pl, pooled = ops.roi_align_avg_nhwc_bf16(base_feat, rois.view(R, 5), 1.0 / 16.0), None
+                        pooled_pl, pooled = ops.roi_align_avg_nhwc_to_planes(feat32, rois.view(R, 5), 1.0 / 16.0, split=sp,
+                                                                             il=sp), None
                 with ops.timed("fc6"):
                     _, fc6 = ops.gemm_nt_bf16(pooled_pl.view(R, -1), P['fc6_w_h'], P['fc6_b'], act=ops.ACT_RELU)
                 with ops.timed("fc7"):

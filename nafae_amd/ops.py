@@ -338,6 +338,18 @@ def roi_align_avg_nhwc_bf16(X, rois, spatial_scale, want_f32=False):
     return (P, f32) if want_f32 else P
 
 
+def roi_align_avg_nhwc_to_planes(feat_nhwc, rois, spatial_scale, split=True, il=True, want_f32=False):
+    """fp32 feat [F,H,W,C] -> Planes [N,7,7,C] (and, with want_f32, the same values as an fp32 tensor)."""
+    _chk(feat_nhwc); _chk(rois)
+    F, H, W, C = feat_nhwc.shape
+    N = rois.shape[0]
+    P = _alloc_planes((N, 7, 7, C), rois.device, split, il and split and C % 32 == 0)
+    f32 = torch.empty(N, 7, 7, C, device=rois.device, dtype=torch.float32) if want_f32 else None
+    _rc(_lib.lib().nafae_roi_align_avg_nhwc_to_planes(_p(feat_nhwc), F, H, W, C, _p(rois), N, float(spatial_scale), _p(P.hi), _p(P.lo),
+                                                      _p(f32), _stream()), "nafae_roi_align_avg_nhwc_to_planes")
+    return (P, f32) if want_f32 else P
+
+
 # ------------------------------------------------------------------------------------------------ proposals
 def rpn_decode(head, anchors, im_info, F, H, W, A, feat_stride):
     _chk(head); _chk(anchors); _chk(im_info)

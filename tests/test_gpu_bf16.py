@@ -136,6 +136,13 @@ def test_conv1_maxpool_roialign_planes(ops):
     assert np.array_equal(outi, out)
     pl, f32 = ops.roi_align_avg_nhwc_bf16(fi, dev(rois), 1 / 16., want_f32=True)
     assert torch.equal(f32, ops.merge_bf16(pl))       # the fused fp32 copy == merging the planes
+    # the detector's variant: fp32 feature map in (planes merged once), planes out, fp32 FMAs with pre-formed weights
+    for (split, il) in ((True, True), (True, False), (False, False)):
+        pl2, f322 = ops.roi_align_avg_nhwc_to_planes(dev(torch.from_numpy(fm).permute(0, 2, 3, 1).contiguous()), dev(rois), 1 / 16.,
+                                                     split=split, il=il, want_f32=True)
+        assert pl2.il == (split and il) and torch.equal(f322, ops.merge_bf16(pl2))
+        o2 = f322.cpu().permute(0, 3, 1, 2).numpy()
+        assert relerr(o2, ref) < (2e-5 if split else 5e-3)
 
 
 def _detector(seed, precision):
