@@ -322,6 +322,42 @@ def test_dvsa_against_oracle_larger(ops, Na, Ns, Nb, Ne):
             assert relerr(dW, w.grad) < 5 * TOL
 
 
+def test_dvsa_degenerate_shapes(ops):
+    """The degenerate shapes SURVEY.md section 8a records as probed on the reference: Ns = 2 makes the clustering term
+    identically 1 with zero gradient; Na = 1 makes the ranking term 2*Delta (loss 200 at Delta = 10); Ns = 1 and an
+    all-empty batch make vis_loss 0/0 -- NaN in the reference (model.py:576-577) and here.  Each against the oracle."""
+    from nafae_amd import synthetic as syn
+    from oracle import dvsa as O
+    D = 512
+
+    def both(Na, Ns, Nb, Ne, lens, train=True):
+        V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, D, seed=7 * Na + Ns)
+        v, w = V.clone().requires_grad_(), W.clone().requires_grad_()
+        Di, Ds, L, parts = O.dvsa_forward(v, w, lens, Na, Nb, Ne, 10.0, 4.13, "train" if train else "eval", return_parts=True)
+        L.backward()
+        return (V, W, Di, Ds, L.detach(), v.grad, w.grad, parts), _run_dvsa(ops, V, W, lens, Na, Ns, Nb, Ne, 10.0, 4.13, train)
+
+    # Ns = 2: vis_loss == 1 (up to rounding), its gradient vanishes; everything still matches
+    (V, W, Di, Ds, L, gV, gW, parts), (S_max, D_ind, loss, dV, dW) = both(3, 2, 32, 8, [3, 5, 1])
+    assert abs(float(parts["vis_loss"]) - 1.0) < 1e-5 and abs(float(loss[2]) - 1.0) < 1e-5
+    assert torch.equal(D_ind, Di) and abs(float(loss[0]) - float(L)) < TOL * abs(float(L))
+    assert relerr(dV, gV) < 5 * TOL and relerr(dW, gW) < 5 * TOL
+    # Na = 1: ranking term == 2*Delta exactly, whatever the similarities are
+    (V, W, Di, Ds, L, gV, gW, parts), (S_max, D_ind, loss, dV, dW) = both(1, 4, 32, 8, [3], train=False)
+    assert float(L) == 200.0 and float(loss[0]) == 200.0 and torch.equal(D_ind, Di)
+    assert float(dV.abs().max()) == 0.0 and float(gV.abs().max()) == 0.0
+    # Ns = 1: one frame per segment -> the clustering matrix is all diagonal -> 0/0
+    (V, W, Di, Ds, L, gV, gW, parts), (S_max, D_ind, loss, dV, dW) = both(3, 1, 32, 8, [3, 5, 1])
+    assert torch.isnan(L) and torch.isnan(loss[0]) and torch.isnan(loss[2]) and float(loss[3]) == 0.0
+    assert torch.equal(D_ind, Di) and relerr(S_max, Ds.detach()) < TOL          # the grounding output is still defined
+    # every segment without entities: all query columns masked -> S_max == 0, D_ind == 0, clustering 0/0
+    (V, W, Di, Ds, L, gV, gW, parts), (S_max, D_ind, loss, dV, dW) = both(2, 4, 32, 8, [0, 0])
+    assert torch.isnan(L) and torch.isnan(loss[0]) and float(S_max.abs().max()) == 0.0 and torch.equal(D_ind, Di)
+    # ... and in eval mode (no clustering term) the same batch is finite: relu(Delta) twice
+    (V, W, Di, Ds, L, gV, gW, parts), (S_max, D_ind, loss, dV, dW) = both(2, 4, 32, 8, [0, 0], train=False)
+    assert float(L) == 200.0 and float(loss[0]) == 200.0
+
+
 def test_sim_max_full_size_properties(ops):
     """BASELINE config C5 per-GPU shape (19200 x 512): size-independent checks -- max >= every sampled entry,
     arg-max points at the max, masked slots are (0, 0), linearity in W."""
