@@ -212,5 +212,5 @@ def test_conv_stream_k_schedule(F, H, Cin, Cout):
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
     assert float((f1 - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
     assert float((torch.relu(f1) - ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)[0]).abs().max()) == 0.0
-    if (F, H, Cin, Cout) == (64, 56, 64, 256):
+    if (F, H, Cin, Cout) == (64, 56, 64, 256) and os.environ.get("NAFAE_CONV_SK", "1") != "0":
         assert nws > 0                                                             # 784 tiles on 256 CUs: selected
