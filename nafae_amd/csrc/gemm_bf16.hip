@@ -808,6 +808,185 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, c
   epilogue<E, true>(e, m0, n0, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
+// ------------------------------------------------------------------------------------------------ 2-D patch conv (narrow layers)
+// 3x3 conv for the layers where a 256-pixel x 64-channel tile holds only ~6 us of matrix work (conv1_2: 64 -> 64 at
+// 224^2) and the raster-run kernels above spend twice that on everything else: 387 KB of L2 -> LDS staging per tile (the run
+// is re-staged for each of the 3 row offsets), a cold prologue and an epilogue per tile, border masks on every fragment.
+// Here a tile is a 16 x 16 pixel SQUARE and the activation side is its 18 x 18 input PATCH, staged ONCE per 32-channel
+// chunk (41.5 KB) with the conv padding zero-filled at staging time -- a third of the activation traffic, no masks; all
+// nine taps read the same LDS image at a uniform row offset (dy*18 + dx).  The kernel is PERSISTENT (#CUs workgroups,
+// tiles round-robin), so the patch of the next (tile, chunk) and the weight taps of the next group stream in under the
+// current group's MFMAs and the epilogue's stores drain under the next tile's first group (counted vmcnt: stores are
+// younger than the loads that group needs).  One barrier per row-offset group (3 taps x 2 k-steps = 36 MFMAs per wave).
+// Interleaved split planes only; H, W multiples of 16; Cout in tiles of 64.
+constexpr int PT = 16, PP = PT + 2, PROWS = 384;   // tile side, patch side, patch rows in LDS (324 used; 6 chunks per lane)
+
+__global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, const __bf16 *Wt, const float *__restrict__ bias,
+                                                             __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
+                                                             int W, int Cin, int Cout, int relu, int tiles_y, int tiles_x,
+                                                             int tiles_n) {
+  using E = EngineH<256, 64, 8, 1, true, true, false>;   // 8 waves x (32 pixels x 64 channels)
+  constexpr int XB = PROWS * 64, WS = 64 * 64;           // bf16 elements per patch buffer / per weight tap stage
+  constexpr int NPC = PROWS * 8 / NT16;                  // patch staging chunks per lane (6)
+  constexpr int NSTORE = 8;                              // 16-byte stores per lane in the epilogue
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  __bf16 *xbuf = smem16, *wbuf = smem16 + 2 * XB;
+  E e;
+  e.init();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cpt = Cin / BKH, ngrp = 3 * cpt, CinS = 2 * Cin, K9S = 18 * Cin;
+  const __bf16 *zero = reinterpret_cast<const __bf16 *>(nafae_zero_page);
+  // staging: chunk c = tid + 512 i sits in LDS row (tid >> 3) + 64 i; its (plane, k-slot) does not depend on i
+  const int row0 = threadIdx.x >> 3;
+  const int lsw = (threadIdx.x & 7) ^ ((row0 >> 1) & 7);
+  const int soff = (lsw >> 2) * BKH + (lsw & 3) * 8;      // element offset inside a pixel's 64-element (hi 32 | lo 32) piece
+  // MFMA side: this lane's output pixel and the patch row of its (dy, dx) = (0, 0) tap
+  const int mloc = wave * 32 + (lane & 31), ty = mloc >> 4, tx = mloc & 15, h = lane >> 5;
+  const int prow0 = ty * PP + tx;
+  const int T = F * tiles_y * tiles_x * tiles_n;       // (< 2^31: checked by the launcher)
+  const int nmine = (int)blockIdx.x < T ? (T - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  if (nmine == 0) return;
+
+  struct Tile {
+    int f, y0, x0, n0;
+  };
+  auto tile_of = [&](int k) {                 // k-th tile of this workgroup (32-bit divisions, once per tile)
+    int t = (int)blockIdx.x + k * (int)gridDim.x;
+    Tile r;
+    r.n0 = (t % tiles_n) * 64;
+    t /= tiles_n;
+    r.x0 = (t % tiles_x) * PT;
+    t /= tiles_x;
+    r.y0 = (t % tiles_y) * PT;
+    r.f = t / tiles_y;
+    return r;
+  };
+  // staging instructions are handed out ONE AT A TIME between the MFMA clusters of a group (issued in a burst behind the
+  // barrier they keep both waves of a SIMD off the matrix pipe for ~80 cycles each): slots 0-2 = the three weight taps of
+  // the next group, slots 3-8 = the six chunks of the next patch
+  auto issue_patch_one = [&](const Tile &tl, int cc, int buf, int i) {   // chunk i of an 18 x 18 x 32-channel patch -> xbuf[buf]
+    char *dst = reinterpret_cast<char *>(xbuf + (size_t)buf * XB) + (wave * 64) * 16;
+    const int pr = row0 + 64 * i;
+    const int py = pr / PP, px = pr - py * PP;
+    const int y = tl.y0 - 1 + py, x = tl.x0 - 1 + px;
+    const bool ok = pr < PP * PP && y >= 0 && y < H && x >= 0 && x < W && !(relu & 512);   // (bit 9: timing experiment)
+    const __bf16 *src = ok ? X + (((long)tl.f * H + y) * W + x) * CinS + cc * 2 * BKH + soff : zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(dst + NT16 * i * 16), 16, 0, 0);
+  };
+  auto issue_w_one = [&](const Tile &tl, int cc, int dy, int half, int t) {   // tap t of a group -> ring stage half * 3 + t
+    const __bf16 *wsrc = (relu & 512) ? zero - (dy * 3 + t) * CinS : Wt + (long)(tl.n0 + row0) * K9S + cc * 2 * BKH + soff;
+    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(half * 3 + t) * WS) + (wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (dy * 3 + t) * CinS),
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  };
+
+  Tile cur = tile_of(0);
+#pragma unroll
+  for (int i = 0; i < NPC; i++) issue_patch_one(cur, 0, 0, i);
+#pragma unroll
+  for (int t = 0; t < 3; t++) issue_w_one(cur, 0, 0, 0, t);
+  int younger = 0;   // vector-memory ops issued after the loads the next group needs (they may stay in flight)
+  int gpar = 0;      // parity of the running group count (weight ring half)
+  int ppar = 0;      // parity of the running patch count (patch buffer)
+  constexpr int TROW = 128 + 16;                       // epilogue transpose: LDS bytes per pixel (32 ch x (hi, lo) + pad)
+  static_assert(8 * 32 * TROW <= XB * 2, "the transposition fits one patch buffer");
+  for (int k = 0; k < nmine; k++) {
+    const bool last_tile = k + 1 == nmine;
+    const Tile nxt = last_tile ? cur : tile_of(k + 1);
+    for (int cc = 0; cc < cpt; cc++) {
+      const bool last_cc = cc + 1 == cpt;
+      for (int dy = 0; dy < 3; dy++) {
+        if (younger == NPC)
+          wait_vmcnt<NPC>();
+        else if (younger == NSTORE)
+          wait_vmcnt<NSTORE>();
+        else
+          wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // this group's taps and patch are in LDS for everyone; everyone is done with the previous group
+        // what this group stages: the next group's taps (they are what the next wait is for: issued first), and -- at the
+        // first group of a patch, when the other patch buffer has just become free -- the next patch (3 groups to land)
+        const bool w_next_tile = dy == 2 && last_cc;
+        const bool do_w = !(w_next_tile && last_tile);
+        const Tile &wt = w_next_tile ? nxt : cur;
+        const int wcc = dy < 2 ? cc : (last_cc ? 0 : cc + 1), wdy = dy < 2 ? dy + 1 : 0;
+        const bool do_p = dy == 0 && !(last_cc && last_tile);
+        const Tile &pt = last_cc ? nxt : cur;
+        const int pcc = last_cc ? 0 : cc + 1;
+        younger = do_p ? NPC : 0;
+        const __bf16 *xb = xbuf + (size_t)ppar * XB;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const __bf16 *wb = wbuf + (size_t)(gpar * 3 + t) * WS;
+          const int pr = prow0 + dy * PP + t;
+#pragma unroll
+          for (int s = 0; s < 2; s++) {
+            const int sl = 2 * s + h;
+            bf16x8 xa[2], wa[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) xa[p] = *reinterpret_cast<const bf16x8 *>(&xb[E::L::template frag<PROWS>(pr, p, sl)]);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+#pragma unroll
+              for (int p = 0; p < 2; p++)
+                wa[p] = *reinterpret_cast<const bf16x8 *>(&wb[E::L::template frag<64>(i * 32 + (lane & 31), p, sl)]);
+              e.mma(i, 0, wa, xa);
+              const int slot = (t * 2 + s) * 2 + i;      // 12 clusters per group, 9 staging slots
+              if (slot < 3) {
+                if (do_w) issue_w_one(wt, wcc, wdy, gpar ^ 1, slot);
+              } else if (slot - 3 < NPC) {
+                if (do_p) issue_patch_one(pt, pcc, ppar ^ 1, slot - 3);
+              }
+            }
+          }
+        }
+        gpar ^= 1;
+      }
+      ppar ^= 1;
+    }
+    // ---- tile complete: bias, ReLU, split; transposed through the patch buffer just consumed, so that every store instruction
+    // writes full 128-B lines (a lane's own 4 channels would be 8-byte pieces of 32 different lines); the next tile's loads
+    // are already in flight and its first group waits only for them (the stores are younger)
+    {
+      __builtin_amdgcn_s_barrier();                      // every wave is done reading the consumed patch buffer
+      char *tb = reinterpret_cast<char *>(xbuf + (size_t)(ppar ^ 1) * XB) + wave * (32 * TROW);   // (ppar was flipped above)
+      char *trow = tb + (lane & 31) * TROW;
+      const long rowb = (long)2 * Cout * sizeof(__bf16);             // bytes per output pixel (interleaved planes)
+#pragma unroll
+      for (int i = 0; i < 2; i++) {                      // one 32-channel piece (= one 128-B line per pixel) at a time
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+          const int nl = 8 * gq + 4 * h;                 // channel inside the piece
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float v = e.acc[i][0][4 * gq + q] + bias[cur.n0 + i * 32 + nl + q];
+            if (relu & 1) v = v > 0.f ? v : 0.f;
+            __bf16 a, b;
+            split_bf16(v, a, b);
+            hi[q] = a;
+            lo[q] = b;
+          }
+          *reinterpret_cast<bf16x4 *>(trow + nl * 2) = hi;
+          *reinterpret_cast<bf16x4 *>(trow + 64 + nl * 2) = lo;
+        }
+        char *obase = reinterpret_cast<char *>(Chi) + ((cur.n0 >> 5) + i) * 128;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+          const int qd = it * 64 + lane, px = qd >> 3, part = qd & 7;   // 8 pieces of 16 B per pixel
+          const int m = wave * 32 + px;
+          const long mg = ((long)cur.f * H + cur.y0 + (m >> 4)) * W + cur.x0 + (m & 15);
+          const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
+          if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + mg * rowb + part * 16) = d;   // (bit 8: timing experiment)
+        }
+      }
+      e.zero_acc();
+      younger = (relu & 256) ? 0 : NSTORE;
+    }
+    cur = nxt;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ plane helpers
 // element e of a dense tensor whose last dimension is a multiple of 32 -> offset of its hi part in the I32 layout
 __device__ __forceinline__ long il_off(long e) { return ((e >> 5) << 6) + (e & 31); }
@@ -1118,6 +1297,33 @@ int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const vo
   return launched();
 }
 
+inline int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void *Chi, void *Clo, int F, int H, int W,
+                             int Cin, int Cout, int relu, hipStream_t st) {
+  const int tiles_y = H / PT, tiles_x = W / PT, tiles_n = Cout / 64;
+  const long T = (long)F * tiles_y * tiles_x * tiles_n;
+  if (T >= (1L << 31)) return NAFAE_ELIMIT;
+  const size_t lds = (size_t)(2 * PROWS * 64 + 6 * 64 * 64) * sizeof(__bf16);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    once = true;
+  }
+  // a few workgroups per CU rather than exactly one: each still runs several tiles back to back (the prologue is paid once
+  // per workgroup), but workgroups retire every few tiles, which lets the small kernels of another stream (the training
+  // tail that the pipelined trainer overlaps with the next detector) onto the CUs instead of waiting for the whole launch
+  static int per_cu = 0;
+  if (!per_cu) {
+    const char *e = getenv("NAFAE_PATCH_WG_PER_CU");
+    per_cu = e && atoi(e) > 0 ? atoi(e) : 4;
+  }
+  const long want = (long)per_cu * num_cus();
+  const int G = (int)(T < want ? T : want);
+  hipLaunchKernelGGL(conv3x3_patch_kernel, dim3(G), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Whi, bias,
+                     (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_y, tiles_x, tiles_n);
+  return launched();
+}
+
 // A/B switches: NAFAE_BF16_PIPE=reg selects the register-staged kernels; NAFAE_CONV_RUN=0 disables the run-reuse conv
 inline bool use_run() {
   static int v = -1;
@@ -1233,6 +1439,15 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
     if (split) {
       const bool il = host_il(in_hi, in_lo);
       if (il != host_il(w_hi, w_lo)) return NAFAE_EINVAL;   // both operands in the same plane layout
+      {   // narrow layers: 2-D patch kernel (NAFAE_CONV_PATCH=0 disables it, =all widens it to every eligible layer).
+          // Measured at C2: 64->64@224^2 1.04 -> 0.80 ms, 64->128@112^2 0.48 -> 0.37, 128->128@112^2 0.83 -> 0.66; wider
+          // layers re-read the patch once per 64 output channels and stay on the run-reuse kernels.
+        const char *pe = getenv("NAFAE_CONV_PATCH");
+        const bool off = pe && pe[0] == '0', all = pe && pe[0] == 'a';
+        if (il && !off && !out_f32 && out_hi && out_lo && host_il(out_hi, out_lo) && H % PT == 0 && W % PT == 0 && Cout % 64 == 0 &&
+            (all || (Cin <= 128 && Cout <= 128)) && (long)F * (H / PT) * (W / PT) * (Cout / 64) >= num_cus())
+          return launch_conv_patch(in_hi, w_hi, bias, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+      }
       if (Cout <= 64) {
         static int g3 = -1;  // NAFAE_CONV_RUN3=0: one barrier per tap instead of per 3-tap group (A/B)
         if (g3 < 0) {

@@ -214,3 +214,29 @@ def test_conv_stream_k_schedule(F, H, Cin, Cout):
     assert float((torch.relu(f1) - ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)[0]).abs().max()) == 0.0
     if (F, H, Cin, Cout) == (64, 56, 64, 256) and os.environ.get("NAFAE_CONV_SK", "1") != "0":
         assert nws > 0                                                             # 784 tiles on 256 CUs: selected
+
+
+@pytest.mark.parametrize("F,H,W,Cin,Cout,widen", [(8, 64, 128, 64, 64, False), (3, 112, 112, 64, 64, False), (5, 48, 160, 64, 64, False),
+                                                  (4, 64, 64, 128, 128, True), (2, 112, 112, 64, 128, True), (9, 32, 32, 256, 64, True)])
+def test_conv_patch_kernel(F, H, W, Cin, Cout, widen, monkeypatch):
+    """2-D patch conv (conv3x3_patch_kernel; layers up to 128 channels by default, any eligible layer with NAFAE_CONV_PATCH=all)
+    against the raster-run kernels (same products, different summation order over the taps -> fp32 noise) and the fp32
+    conv; borders, image seams between frames, several tiles per workgroup, more workgroups than tiles."""
+    from nafae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(F * H + W)
+    x = torch.randn(F, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    xp, wp = ops.split_bf16(x, True, True), ops.split_bf16(w, True, True)
+    monkeypatch.setenv("NAFAE_CONV_PATCH", "0")
+    _, p0 = ops.conv3x3_bf16(xp, wp, b, relu=True)
+    monkeypatch.setenv("NAFAE_CONV_PATCH", "all" if widen else "1")
+    _, p1 = ops.conv3x3_bf16(xp, wp, b, relu=True)
+    _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True)
+    assert torch.equal(p1.hi, p2.hi)                                               # deterministic (hi | lo interleaved)
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    o0, o1 = ops.merge_bf16(p0), ops.merge_bf16(p1)
+    assert float((o1 - ref).abs().max()) <= 5e-5 * scale
+    assert float((o1 - o0).abs().max()) <= 2e-5 * scale
+    assert not torch.equal(o1, torch.zeros_like(o1))
