@@ -1383,7 +1383,10 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     const bool il = split && host_il(X_hi, X_lo) && host_il(W_hi, W_lo);  // interleaved I32 operands (K % 32 == 0)
     if (split && (host_il(X_hi, X_lo) != host_il(W_hi, W_lo))) return NAFAE_EINVAL;
     if (il && (K & 31)) return NAFAE_EINVAL;
-    if (split && big && M >= 256 && N >= 256) {  // 256x256 tile, 2-stage ring: 21 B/clk/CU of staging instead of 31
+    // 256x256 tile, 2-stage ring: 21 B/clk/CU of staging instead of 31 -- when it still gives at least half a chip of
+    // workgroups (VisEbd's 8192 x 512 output would be 64 of them: the 256x128 tile below makes 128)
+    const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    if (split && big && M >= 256 && N >= 256 && 2 * big_tiles >= num_cus()) {
       if (il)
         return launch_dma<256, 256, 2, 4, true, false, 2, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N,
                                                                 K, alpha, act, 0, 0, 0, S(stream));

@@ -249,8 +249,11 @@ class _fasterRCNN(nn.Module):
                 with ops.timed("fc6"):
                     _, fc6 = ops.gemm_nt_bf16(pooled_pl.view(R, -1), P['fc6_w_h'], P['fc6_b'], act=ops.ACT_RELU)
                 with ops.timed("fc7"):
-                    fc7, _ = ops.gemm_nt_bf16(fc6, P['fc7_w_h'], P['fc7_b'], act=ops.ACT_RELU, want_f32=True,
-                                              want_planes=False)
+                    sp = self.precision == 'bf16x3'
+                    fc7, fc7_pl = ops.gemm_nt_bf16(fc6, P['fc7_w_h'], P['fc7_b'], act=ops.ACT_RELU, want_f32=True,
+                                                   want_planes=sp)
+                    if sp:      # VisEbd (model.py:624-629) continues on the same arithmetic without re-splitting fc7
+                        fc7._nafae_planes = fc7_pl
             else:
                 with ops.timed("roi_align"):
                     pooled = ops.roi_align_avg_nhwc(base_feat, rois.view(R, 5), 1.0 / 16.0)  # [R,7,7,512]

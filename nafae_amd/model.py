@@ -98,9 +98,15 @@ class _VisEbdFn(torch.autograd.Function):
     """tanh(drop(fc1(x / 100)))  -- model.py:624-629."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, mask, scale):
+    def forward(ctx, feats, weight, bias, mask, scale, planes=None):
         with ops.timed("vis_ebd"):
-            pre = ops.gemm_nt(feats, weight, bias, alpha=0.01)      # (x/100) W^T + b  ==  0.01 (x W^T) + b
+            if planes is not None:
+                # fc7 arrived with its split-bf16 planes (detector in 'bf16x3' mode): the same 3-MFMA arithmetic as fc6 / fc7
+                # (~1e-5, inside the 1e-4 bar) instead of fp32 MFMA at 1/16 of the rate.  The backward below stays fp32.
+                wp = ops.split_bf16(weight.detach(), True, planes.il)
+                pre, _ = ops.gemm_nt_bf16(planes, wp, bias, alpha=0.01, want_f32=True, want_planes=False)
+            else:
+                pre = ops.gemm_nt(feats, weight, bias, alpha=0.01)  # (x/100) W^T + b  ==  0.01 (x W^T) + b
             y = ops.dropout_tanh(pre, mask, scale)
         ctx.save_for_backward(feats, y, mask)
         ctx.scale = scale
@@ -115,7 +121,7 @@ class _VisEbdFn(torch.autograd.Function):
             rows, count = ops.nonzero_rows(gpre)
             gw = ops.gemm_tn_rows(gpre, feats, rows, count, alpha=0.01)   # [D, 4096]
             gb = ops.colsum(gpre)
-        return None, gw, gb, None, None
+        return None, gw, gb, None, None, None
 
 
 class _WordEbdFn(torch.autograd.Function):
@@ -244,7 +250,11 @@ class VisEbd(nn.Module):
         mask, scale = (None, 1.0)
         if self.training and p > 0:
             mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device), 1.0 / (1.0 - p)
-        return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, mask, scale)
+        # the detector hands fc7 over together with its split-bf16 planes (an attribute on the very tensor it returned)
+        planes = getattr(feats, "_nafae_planes", None)
+        if planes is not None and (tuple(planes.shape) != tuple(feats.shape) or not feats.is_contiguous()):
+            planes = None
+        return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, mask, scale, planes)
 
 
 class WordEbd(nn.Module):
