@@ -209,14 +209,15 @@ def main():
             # MFMA flops actually issued per algorithmic flop, and the dense peak of the pipe they run on
             nprod, peak, kname = {"f32": (1, FP32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel<128,128,2,2> (fc6, fp32 MFMA)"),
                                   "bf16x3": (3, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,split,gemm,2> (fc6, 3 bf16 MFMAs per product)"),
-                                  "bf16": (1, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,128,4,2,plain,gemm,3> (fc6, bf16 MFMA)")}[a.precision]
+                                  "bf16": (1, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,plain,gemm,3> (fc6, bf16 MFMA)")}[a.precision]
             ach = nprod * fl / (fc6["avg_ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),
                                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "algorithmic_tflops": round(fl / (fc6["avg_ms"] * 1e-3) / 1e12, 2),
-                               "traffic": (pmc_traffic({"f32": "gemm_nt_fc6", "bf16x3": "gemm_bf16x3_fc6_256x256_il"}.get(a.precision, ""))
+                               "traffic": (pmc_traffic({"f32": "gemm_nt_fc6", "bf16x3": "gemm_bf16x3_fc6_256x256_il",
+                                                        "bf16": "gemm_bf16_plain_fc6_256x256"}.get(a.precision, ""))
                                            if a.workload == "c2" else None),
-                               "algorithmic": 4.0 * (R * 25088 + 4096 * 25088 + R * 4096),
+                               "algorithmic": (2.0 if a.precision == "bf16" else 4.0) * (R * 25088 + 4096 * 25088 + R * 4096),
                                "avg_ms": round(fc6["avg_ms"], 4), "launches": fc6["n"]}
         sim = prof.get("sim_max")
         if sim:
