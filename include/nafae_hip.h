@@ -171,7 +171,10 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                        float *C_f32, void *C_hi, void *C_lo, int ldc, const float *bias, int M, int N, int K,
                        float alpha, int act, void *stream);
 
-/* 3x3 conv + bias (+ReLU), NHWC planes in, fp32 and/or planes out; w planes are [Cout,3,3,Cin].  */
+/* 3x3 conv + bias (+ReLU), NHWC planes in, fp32 and/or planes out; w planes are [Cout,3,3,Cin].
+ * `relu`: bit 0 = apply ReLU.  Bits 8 and 9 are timing experiments used by scripts/layer_times.py (staging loads served
+ * from one cached zero line / stores skipped -- the results are then meaningless); production callers pass 0 or 1.
+ * Likewise `act` = -1 / -2 of nafae_gemm_nt_bf16.  */
 int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
                        float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
                        void *stream);
