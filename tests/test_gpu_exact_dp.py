@@ -94,7 +94,10 @@ def test_exact_mode_equals_single_process(world, monkeypatch):
             outs.append(torch.load(os.path.join(td, "r%d.pt" % r)))
     ref_params = opt.flat_params.cpu()
     for r, o in enumerate(outs):
-        np.testing.assert_allclose(o["losses"], ref_losses, rtol=2e-6)           # the SAME global loss on every rank
+        # the SAME global loss on every rank: the first step to fp32 summation order, later steps through parameters that
+        # took an Adam step on gradients differing in their last bits (see the bounds on `params` below)
+        np.testing.assert_allclose(o["losses"][:1], ref_losses[:1], rtol=2e-6)
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=2e-5)
         assert torch.equal(o["D"], D.cpu())                                      # grounding indices: exact
         assert float((o["D_sim"] - D_sim.cpu()).abs().max()) <= 1e-5 * float(D_sim.abs().max())
         # the gradient of the global-batch loss, summed from the ranks' partial gradients (fp32 summation order differs)
