@@ -226,14 +226,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST, bool IL, bool S16>
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST, bool IL, bool S16, bool PAIR = false>
 __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const __bf16 *Xlo, int ldx, const __bf16 *Whi,
                                                         const __bf16 *Wlo, int ldw,
                                                         float *__restrict__ Cf, __bf16 *__restrict__ Chi,
                                                         __bf16 *__restrict__ Clo, int ldc, const float *__restrict__ bias,
                                                         int M, int N, int K, float alpha, int act, int tiles_m, int tiles_n,
                                                         int H, int W, int Cin) {
-  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, S16>;
+  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, S16, PAIR>;
   using L = typename E::L;
   static_assert(E::CHUNKS % NT16 == 0, "LDS-DMA path needs every lane active in every staging instruction");
   static_assert(NST == 2 || NST == 3, "ring of 2 or 3 LDS stages");
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
   int kt = 0;
   for (; kt + DIST < nk; kt++) tile(kt, std::true_type{});
   for (; kt < nk; kt++) tile(kt, std::false_type{});
-  epilogue<E, SPLIT>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
+  epilogue<E, SPLIT && !PAIR>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);   // PAIR: plain bf16 / fp32 output
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv
@@ -369,14 +369,14 @@ struct ConvArgs {
   int dbg;  // timing experiments only (relu bit 8 / bit 9): 1 = every staging load hits the zero page, 2 = only the weights do
 };
 
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16, bool PAIR = false>
 struct ConvRun {
   // run length: 256 + 2 pixels are needed; 320 (split) / 384 (plain) rows make the chunk count a multiple of 512 lanes
   // BX = 224 (7 x 32 pixels, run of 256 rows starting 16 pixels early) exists for tile-count quantisation: layers whose
   // pixel count is 49 * 2^k give 3.06 / 1.53 / 0.77 workgroups per CU with 256-pixel tiles but 3.5 / 1.75 / 0.875 with 224
   static_assert(BX == 256 || (BX == 224 && SPLIT), "tile of 256 pixels, or 224 for the split path");
   static constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384), ROFF = BX == 224 ? 16 : 32;
-  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, S16>;
+  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, S16, PAIR>;
   using L = typename E::L;
   static constexpr int TX = E::TX, TW = E::TW, NI = E::NI, NJ = E::NJ, MS = E::MS;
   static constexpr int XRUN = RR * BKH * PL;   // bf16 elements per activation-run buffer
@@ -540,12 +540,12 @@ struct ConvRun {
   }
 };
 
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16, bool PAIR = false>
 __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
                                                            const float *__restrict__ bias, float *__restrict__ Cf,
                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                            int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
-  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, S16>;
+  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, S16, PAIR>;
   using E = typename R::E;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   E e;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
   R r;
   r.begin(e, smem16, a, m0, n0, 0, nst);
   for (int st = 0; st < nst; st++) r.step(e, st);
-  epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  epilogue<E, SPLIT && !PAIR>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv, stream-K
@@ -571,13 +571,13 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
 // 2w for its first segment, 2w+1 for its last), and conv_sk_fixup_kernel -- the kernel boundary is the only
 // synchronisation -- adds the partials of each cut tile in workgroup order and runs the normal epilogue.  Deterministic:
 // the summation order is fixed by the share arithmetic.
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool PAIR = false>
 __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi,
                                                               const __bf16 *Wlo, const float *__restrict__ bias,
                                                               float *__restrict__ Cf, __bf16 *__restrict__ Chi,
                                                               __bf16 *__restrict__ Clo, int F, int H, int W, int Cin, int Cout,
                                                               int relu, int tiles_m, int tiles_n, float *__restrict__ scratch) {
-  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false>;
+  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false, PAIR>;
   using E = typename R::E;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   E e;
@@ -616,7 +616,8 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi,
     if (st == r.st1) {                                     // segment complete
       const int ga = r.st0 / 3, gb = r.st1 / 3;
       if (ga == 0 && gb == ngrp) {
-        epilogue<E, SPLIT>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+        epilogue<E, SPLIT && !PAIR>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo,
+                                    Cout);
       } else {
         f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
 #pragma unroll
@@ -821,14 +822,15 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, c
 // Interleaved split planes only; H, W multiples of 16; Cout in tiles of 64.
 constexpr int PT = 16, PP = PT + 2, PROWS = 384;   // tile side, patch side, patch rows in LDS (324 used; 6 chunks per lane)
 
+template <bool PAIR>   // PAIR: plain bf16 tensors read as the two-piece layout over Cin/2 pairs (bf16_tile.h); plain output
 __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, const __bf16 *Wt, const float *__restrict__ bias,
                                                              __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                              int W, int Cin, int Cout, int relu, int tiles_y, int tiles_x,
                                                              int tiles_n) {
-  using E = EngineH<256, 64, 8, 1, true, true, false>;   // 8 waves x (32 pixels x 64 channels)
+  using E = EngineH<256, 64, 8, 1, true, true, false, PAIR>;   // 8 waves x (32 pixels x 64 channels)
   constexpr int XB = PROWS * 64, WS = 64 * 64;           // bf16 elements per patch buffer / per weight tap stage
   constexpr int NPC = PROWS * 8 / NT16;                  // patch staging chunks per lane (6)
-  constexpr int NSTORE = 8;                              // 16-byte stores per lane in the epilogue
+  constexpr int NSTORE = PAIR ? 4 : 8;                   // 16-byte stores per lane in the epilogue
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   __bf16 *xbuf = smem16, *wbuf = smem16 + 2 * XB;
   E e;
@@ -951,6 +953,33 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
       __builtin_amdgcn_s_barrier();                      // every wave is done reading the consumed patch buffer
       char *tb = reinterpret_cast<char *>(xbuf + (size_t)(ppar ^ 1) * XB) + wave * (32 * TROW);   // (ppar was flipped above)
       char *trow = tb + (lane & 31) * TROW;
+      if constexpr (PAIR) {
+        // plain bf16 output: the tile's 64 channels of a pixel are one 128-B line
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int gq = 0; gq < 4; gq++) {
+            const int nl = i * 32 + 8 * gq + 4 * h;
+            bf16x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              float v = e.acc[i][0][4 * gq + q] + bias[cur.n0 + nl + q];
+              if (relu & 1) v = v > 0.f ? v : 0.f;
+              o[q] = (__bf16)v;
+            }
+            *reinterpret_cast<bf16x4 *>(trow + nl * 2) = o;
+          }
+        char *obase = reinterpret_cast<char *>(Chi) + cur.n0 * 2;
+        const long rowp = (long)Cout * sizeof(__bf16);
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+          const int qd = it * 64 + lane, px = qd >> 3, part = qd & 7;
+          const int m = wave * 32 + px;
+          const long mg = ((long)cur.f * H + cur.y0 + (m >> 4)) * W + cur.x0 + (m & 15);
+          const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
+          if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + mg * rowp + part * 16) = d;
+        }
+      } else {
       const long rowb = (long)2 * Cout * sizeof(__bf16);             // bytes per output pixel (interleaved planes)
 #pragma unroll
       for (int i = 0; i < 2; i++) {                      // one 32-channel piece (= one 128-B line per pixel) at a time
@@ -979,6 +1008,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
           const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
           if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + mg * rowb + part * 16) = d;   // (bit 8: timing experiment)
         }
+      }
       }
       e.zero_acc();
       younger = (relu & 256) ? 0 : NSTORE;
@@ -1197,15 +1227,15 @@ inline bool use_s16() {
   return v == 1;
 }
 
-template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST = 3, bool IL = false>
+template <int BX, int BW, int WX, int WW, bool SPLIT, bool CONV, int NST = 3, bool IL = false, bool PAIR = false>
 int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const void *Wlo, int ldw, float *Cf, void *Chi,
                void *Clo, int ldc, const float *bias, int M, int N, int K, float alpha, int act, int H, int W, int Cin,
                hipStream_t st) {
   using E = EngineH<BX, BW, WX, WW, SPLIT>;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
   const size_t lds = NST * E::STAGE * sizeof(__bf16);
-  auto kern = use_s16() ? bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, true>
-                         : bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, false>;
+  auto kern = (use_s16() && !PAIR) ? bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, true>
+                                    : bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, false, PAIR>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1217,15 +1247,15 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   return launched();
 }
 
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL = false, int BX = 256>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL = false, int BX = 256, bool PAIR = false>
 int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                     void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
   const int M = F * H * W;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
   constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384);
   const size_t lds = (size_t)(2 * RR * BKH * PL + NSTW * BW * BKH * PL) * sizeof(__bf16);
-  auto kern = use_s16() ? conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, true>
-                         : conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, false>;
+  auto kern = (use_s16() && !PAIR) ? conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, true>
+                                    : conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, false, PAIR>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1259,13 +1289,13 @@ inline bool sk_pays(long tiles, int G) {
 }
 inline size_t sk_scratch_bytes(int BX, int BW, int G) { return (size_t)2 * G * BX * BW * sizeof(float); }
 
-template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX = 256>
+template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX = 256, bool PAIR = false>
 int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                        void *Clo, int F, int H, int W, int Cin, int Cout, int relu, float *scratch, int G, hipStream_t st) {
-  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false>;
+  using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false, PAIR>;
   const int M = F * H * W;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
-  auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX>;
+  auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES);
@@ -1274,7 +1304,8 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
                      (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch);
   if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
-  hipLaunchKernelGGL((conv_sk_fixup_kernel<BW, WX, WW, SPLIT, IL, BX>), dim3(G - 1), dim3(NT16), 0, st, scratch, bias, Cf,
+  // (PAIR: plain output -- the fix-up only needs the accumulator geometry, so the plain-epilogue instantiation serves)
+  hipLaunchKernelGGL((conv_sk_fixup_kernel<BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, BX>), dim3(G - 1), dim3(NT16), 0, st, scratch, bias, Cf,
                      (__bf16 *)Chi, (__bf16 *)Clo, M, Cout, relu, tiles_m, tiles_n, 3 * (Cin / BKH), G);
   return launched();
 }
@@ -1297,15 +1328,16 @@ int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const vo
   return launched();
 }
 
-inline int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void *Chi, void *Clo, int F, int H, int W,
-                             int Cin, int Cout, int relu, hipStream_t st) {
+template <bool PAIR>
+int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void *Chi, void *Clo, int F, int H, int W,
+                      int Cin, int Cout, int relu, hipStream_t st) {
   const int tiles_y = H / PT, tiles_x = W / PT, tiles_n = Cout / 64;
   const long T = (long)F * tiles_y * tiles_x * tiles_n;
   if (T >= (1L << 31)) return NAFAE_ELIMIT;
   const size_t lds = (size_t)(2 * PROWS * 64 + 6 * 64 * 64) * sizeof(__bf16);
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel<PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     once = true;
   }
@@ -1319,7 +1351,7 @@ inline int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias
   }
   const long want = (long)per_cu * num_cus();
   const int G = (int)(T < want ? T : want);
-  hipLaunchKernelGGL(conv3x3_patch_kernel, dim3(G), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Whi, bias,
+  hipLaunchKernelGGL(conv3x3_patch_kernel<PAIR>, dim3(G), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Whi, bias,
                      (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_y, tiles_x, tiles_n);
   return launched();
 }
@@ -1399,6 +1431,22 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     if (split)
       return launch_dma<256, 128, 4, 2, true, false>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha,
                                                      act, 0, 0, 0, S(stream));
+    // plain bf16 with 64-deep k-tiles: a plain row-major operand IS the interleaved two-piece layout over K/2 "pairs"
+    // (piece 0 = k 0..31, piece 1 = k 32..63 of each 64), so the split kernels run it with piece0*piece0 + piece1*piece1:
+    // 32 instead of 16 MFMAs per wave between barriers (NAFAE_BF16_PAIR=0 falls back to the 32-deep k-tile kernels)
+    static int pair = -1;
+    if (pair < 0) {
+      const char *e = getenv("NAFAE_BF16_PAIR");
+      pair = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (pair && !split && (K % 64) == 0 && (ldx % 64) == 0 && (ldw % 64) == 0 && M >= 256 && N >= 128) {
+      const void *xl = static_cast<const char *>(X_hi) + 64, *wl = static_cast<const char *>(W_hi) + 64;
+      if (big && N >= 256 && 2 * big_tiles >= num_cus())
+        return launch_dma<256, 256, 2, 4, true, false, 2, true, true>(X_hi, xl, ldx / 2, W_hi, wl, ldw / 2, C_f32, C_hi, nullptr, ldc,
+                                                                      bias, M, N, K / 2, alpha, act, 0, 0, 0, S(stream));
+      return launch_dma<256, 128, 4, 2, true, false, 3, true, true>(X_hi, xl, ldx / 2, W_hi, wl, ldw / 2, C_f32, C_hi, nullptr, ldc, bias,
+                                                                    M, N, K / 2, alpha, act, 0, 0, 0, S(stream));
+    }
     if (big && M >= 256 && N >= 256)
       return launch_dma<256, 256, 2, 4, false, false, 3>(X_hi, nullptr, ldx, W_hi, nullptr, ldw, C_f32, C_hi, nullptr, ldc, bias, M, N,
                                                          K, alpha, act, 0, 0, 0, S(stream));
@@ -1449,7 +1497,7 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
         const bool off = pe && pe[0] == '0', all = pe && pe[0] == 'a';
         if (il && !off && !out_f32 && out_hi && out_lo && host_il(out_hi, out_lo) && H % PT == 0 && W % PT == 0 && Cout % 64 == 0 &&
             (all || (Cin <= 128 && Cout <= 128)) && (long)F * (H / PT) * (W / PT) * (Cout / 64) >= num_cus())
-          return launch_conv_patch(in_hi, w_hi, bias, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+          return launch_conv_patch<false>(in_hi, w_hi, bias, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
       }
       if (Cout <= 64) {
         static int g3 = -1;  // NAFAE_CONV_RUN3=0: one barrier per tap instead of per 3-tap group (A/B)
@@ -1503,7 +1551,39 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
       return launch_conv_run<128, 4, 2, 3, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
                                                  S(stream));
     }
-    // plain bf16 (BASELINE config C3): weight tiles of 128 / 256 rows fill the 512 lanes evenly; 64-row tiles do not,
+    // plain bf16 (BASELINE config C3).  With Cin % 64 == 0 a plain NHWC tensor is the interleaved two-piece layout over
+    // Cin/2 "pairs" (bf16_tile.h, PAIR): the split kernels run it with 64-channel k-tiles -- twice the MFMAs per barrier of
+    // the 32-channel plain kernels below -- including the stream-K schedule.  NAFAE_BF16_PAIR=0 disables it.
+    {
+      const char *pe = getenv("NAFAE_BF16_PAIR");
+      const bool pair = !(pe && pe[0] == '0');
+      if (pair && !split && Cin % 64 == 0 && !host_il(out_hi, out_lo)) {
+        const int Ce = Cin / 2, G = num_cus();
+        const char *pp = getenv("NAFAE_CONV_PATCH");
+        if (!(pp && pp[0] == '0') && !out_f32 && out_hi && H % PT == 0 && W % PT == 0 && Cout % 64 == 0 &&
+            ((pp && pp[0] == 'a') || (Cin <= 128 && Cout <= 128)) && (long)F * (H / PT) * (W / PT) * (Cout / 64) >= G)
+          return launch_conv_patch<true>(in_hi, w_hi, bias, out_hi, nullptr, F, H, W, Ce, Cout, relu, S(stream));
+        if (Cout >= 256 && M >= 256 * 128) {
+          if (workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 255) / 256), G) &&
+              workspace_bytes >= (int64_t)sk_scratch_bytes(256, 256, G))
+            return launch_conv_run_sk<256, 2, 4, 2, true, true, 256, true>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr,
+                                                                           F, H, W, Ce, Cout, relu, (float *)workspace, G, S(stream));
+          return launch_conv_run<256, 2, 4, 2, true, true, 256, true>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F,
+                                                                      H, W, Ce, Cout, relu, S(stream));
+        }
+        if (Cout > 64) {
+          if (workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 127) / 128), G) &&
+              workspace_bytes >= (int64_t)sk_scratch_bytes(256, 128, G))
+            return launch_conv_run_sk<128, 4, 2, 3, true, true, 256, true>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr,
+                                                                           F, H, W, Ce, Cout, relu, (float *)workspace, G, S(stream));
+          return launch_conv_run<128, 4, 2, 3, true, true, 256, true>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F,
+                                                                      H, W, Ce, Cout, relu, S(stream));
+        }
+        return launch_conv_run<64, 8, 1, 3, true, true, 256, true>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H,
+                                                                   W, Ce, Cout, relu, S(stream));
+      }
+    }
+    // 32-channel k-tiles: weight tiles of 128 / 256 rows fill the 512 lanes evenly; 64-row tiles do not,
     // so the Cout <= 64 layer stays on the per-tap kernels below
     if (Cout >= 256 && M >= 256 * 128)
       return launch_conv_run<256, 2, 4, 3, false>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H, W, Cin, Cout,

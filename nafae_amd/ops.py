@@ -299,7 +299,7 @@ def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_w
     cf = torch.empty(F, H, W, Cout, device=X.hi.device, dtype=torch.float32) if want_f32 else None
     C = (_alloc_planes((F, H, W, Cout), X.hi.device, split, X.il and Cout % 32 == 0) if want_planes
          else Planes(None, None, False, (F, H, W, Cout)))
-    nws = int(_lib.lib().nafae_conv3x3_bf16_workspace_bytes(F, H, W, Cin, Cout)) if (split and X.il and use_workspace) else 0
+    nws = int(_lib.lib().nafae_conv3x3_bf16_workspace_bytes(F, H, W, Cin, Cout)) if (use_workspace and (X.il or not split)) else 0
     ws = _conv_workspace(nws, X.hi.device) if nws > 0 else None
     _rc(_lib.lib().nafae_conv3x3_bf16_ws(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), _p(cf), _p(C.hi), _p(C.lo), F, H, W,
                                          Cin, Cout, int(bool(relu)) | (int(_dbg) << 8), _p(ws), max(nws, 0), _stream()),

@@ -240,3 +240,29 @@ def test_conv_patch_kernel(F, H, W, Cin, Cout, widen, monkeypatch):
     assert float((o1 - ref).abs().max()) <= 5e-5 * scale
     assert float((o1 - o0).abs().max()) <= 2e-5 * scale
     assert not torch.equal(o1, torch.zeros_like(o1))
+
+
+@pytest.mark.parametrize("F,H,W,Cin,Cout", [(8, 64, 128, 64, 64), (3, 112, 112, 64, 128), (4, 64, 64, 128, 128), (40, 56, 56, 128, 256),
+                                            (64, 28, 28, 256, 512), (6, 14, 14, 512, 512), (2, 20, 36, 64, 64)])
+def test_conv_plain_bf16_pair_mode(F, H, W, Cin, Cout, monkeypatch):
+    """Plain bf16 (BASELINE config C3) through the 64-channel k-tile ("PAIR") form of the split kernels -- patch kernel,
+    run-reuse kernels and their stream-K schedule -- against the 32-channel plain kernels (same bf16 products, other
+    summation order) and the fp32 conv at bf16 tolerance."""
+    from nafae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(F + H + Cin)
+    x = torch.randn(F, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    xp, wp = ops.split_bf16(x, False), ops.split_bf16(w, False)
+    monkeypatch.setenv("NAFAE_BF16_PAIR", "0")
+    f0, p0 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)
+    monkeypatch.setenv("NAFAE_BF16_PAIR", "1")
+    f1, p1 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)      # fp32 + plane output: run kernels
+    _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True)                      # planes only: the patch kernel where eligible
+    xr, wr = ops.merge_bf16(xp), ops.merge_bf16(wp)                     # the bf16-rounded operands, exactly
+    ref = torch.relu(torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((f1 - ref).abs().max()) <= 2e-5 * scale               # fp32 accumulation of exact bf16 products
+    assert float((f1 - f0).abs().max()) <= 2e-5 * scale
+    for p in (p1, p2):
+        assert p.lo is None and float((ops.merge_bf16(p) - ref).abs().max()) <= 5e-3 * scale   # one bf16 rounding of the output
