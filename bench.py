@@ -92,6 +92,49 @@ def cpu_baseline(Na, Ns, Nb, Ne, seconds_budget=25.0):
             "pairs_per_s": round(Na * Ns * Nb * Na * Ne / t_sim, 1)}
 
 
+def sim_loss_only(Na, Ns, Nb, Ne, dev, iters=50):
+    """The similarity + loss part alone (SURVEY.md section 8d, C5 note): synthetic V, W = tanh(N(0,1)) of the workload's shape,
+    sim+max forward, loss tail forward+backward, similarity backward; HIP-event time over `iters` back-to-back passes."""
+    import torch
+    from nafae_amd import ops
+    from nafae_amd import synthetic as syn
+    F, Q, R, D = Na * Ns, Na * Ne, Na * Ns * Nb, 512
+    V, W = syn.embeddings(R, Q, D, seed=1)
+    V, W = V.to(dev), W.to(dev)
+    lens = torch.tensor(syn.entity_lengths(Na, Ne, seed=1234), dtype=torch.int32, device=dev)
+    ws = ops.loss_workspace(Na, Ns, Nb, Ne, D, V.device)
+
+    def fwd():
+        return ops.sim_max_fwd(V, W, lens, Na, Ns, Nb, Ne)
+
+    def full():
+        S_max, D_ind = fwd()
+        loss, dS, _ = ops.loss_fwd_bwd(S_max, D_ind, V, lens, Na, Ns, Nb, Ne, 10.0, 4.13, True, workspace=ws)
+        return ops.sim_bwd(dS, D_ind, V, W, lens, Na, Ns, Nb, Ne, True, ws)
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    t_f, t_fb = timeit(fwd), timeit(full)
+    by_f = 4.0 * D * (R + Q) + 12.0 * F * Q                       # SURVEY 8d: forward algorithmic bytes
+    by_fb = by_f + 4.0 * D * (R + Q) + 4.0 * D * F * Q            # + dense dV, dW and the arg-max row re-reads
+    return {"R": R, "Q": Q, "pairs": R * Q,
+            "fwd_ms": round(t_f, 4), "fwd_pairs_per_s": round(R * Q / (t_f * 1e-3), 1),
+            "fwd_hbm_frac": round(by_f / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "fwd_fp32_mfma_frac": round(2.0 * R * Q * D / (t_f * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "fwd_bwd_ms": round(t_fb, 4), "fwd_bwd_pairs_per_s": round(R * Q / (t_fb * 1e-3), 1),
+            "fwd_bwd_hbm_frac": round(by_fb / (t_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +276,8 @@ def main():
         if det_ms > 0:
             out["detector_algorithmic_tflops"] = round(F * flops_per_frame(Nb) / (det_ms * 1e-3) / 1e12, 2)
             out["detector_fp32_mfma_frac"] = round(F * flops_per_frame(Nb) / (det_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if world == 1:
+            out["sim_loss_only"] = sim_loss_only(Na, Ns, Nb, Ne, dev)
         if world == 1 and not a.no_other_precisions:
             # the same step in the other arithmetic modes, a few steps each (reported, never the headline)
             other = {}
