@@ -25,6 +25,53 @@ def make_batch(Na, Ns, Ne, H=224, W=224, glove_dim=200, seed=1234, device='cuda'
     return Batch(im.to(device), im_info.to(device), g.to(device), lens)
 
 
+def get_word(glove, word):
+    """model.py:426-427: `glove` is anything with torchtext's GloVe interface (`.stoi` dict, `.vectors` [V, dim])."""
+    return glove.vectors[glove.stoi[word]]
+
+
+def prepare_batch(loader_batch, glove, args, device='cuda', raw_frames=False):
+    """The host-side preparation train() does on every loader tuple (model.py:684-747), returning a Batch, or None
+    when the reference skips the iteration (`max(entities_length) == 0`, model.py:685-686).
+
+    loader_batch = (im_blobs [F,H,W,3] float32 BGR-127.5 -- or, with raw_frames=True, the decoded uint8 frames, in which
+    case the -127.5 and the HWC -> CHW re-layout run on the GPU (nafae_frames_u8_to_nchw_f32) and a quarter of the
+    bytes cross PCIe --, entities, entities_length, frm_length, rl_seg_inds, seg_nums, im_paths, img_ids), i.e. what
+    MPrpDataSet.combine_batches returns (lib/datasets/youcook2.py:254-308).  Bug-compatible with the reference's GloVe
+    loop: an EMPTY entity string is skipped WITHOUT advancing the entity pointer (model.py:736-737), and a word missing
+    from the vocabulary raises (model.py:740-742)."""
+    import numpy as np
+    im_blobs, entities, entities_length = loader_batch[0], loader_batch[1], loader_batch[2]
+    if max(entities_length) == 0:
+        return None
+    im_blobs = np.asarray(im_blobs)
+    F, H, W = im_blobs.shape[0], im_blobs.shape[1], im_blobs.shape[2]
+    im_info = torch.tensor([[H, W, 1.0]] * F, dtype=torch.float32)          # (h, w, im_scale = 1)  model.py:688-691
+    if raw_frames:
+        from . import ops
+        if im_blobs.dtype != np.uint8:
+            raise TypeError("raw_frames=True expects the decoded uint8 frames, got %s" % im_blobs.dtype)
+        im_data = ops.frames_u8_to_nchw_f32(torch.from_numpy(np.ascontiguousarray(im_blobs)).to(device))
+    else:
+        im_data = torch.from_numpy(im_blobs.astype(np.float32, copy=True)).permute(0, 3, 1, 2).to(device)   # :692-698
+    Na, Ne = len(entities_length), args.max_ent_len
+    glove_feats = torch.zeros(Na, Ne, args.glove_dim)
+    ent_p = 0
+    for act_ind, entity_length in enumerate(entities_length):
+        for ent_ind in range(entity_length):
+            entity = entities[ent_p]
+            if not entity:
+                continue
+            elif entity in glove.stoi.keys():
+                glove_feats[act_ind, ent_ind] = get_word(glove, entity)
+            else:
+                raise Exception('{} is not in glove vocabulary'.format(entity))
+            ent_p += 1
+    b = Batch(im_data, im_info.to(device), glove_feats.view(-1, args.glove_dim).to(device), list(entities_length))
+    b.loader_batch = loader_batch                                             # frm_length, img_ids ... for validate()
+    return b
+
+
 def build_model(args=None, device='cuda', seed=1234, heads=False):
     """GroundModel with the seeded synthetic detector (random-init weights of the reference's architecture)."""
     args = args or default_args()

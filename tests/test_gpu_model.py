@@ -315,3 +315,23 @@ def test_stepRCNN_streamed_host_input(gpu):
     assert model.fasterRCNN.materialize_pooled is True
     with pytest.raises(TypeError):
         stepRCNN(f32.double(), info, gt, nb, model)
+
+
+def test_prepare_batch_raw_frames_equals_host_preprocessing(gpu):
+    """prepare_batch (model.py:684-747): uint8 frames normalised on the GPU == the reference's host-side float path, and the
+    resulting Batch drives a training step."""
+    import argparse
+    from nafae_amd.model import default_args
+    from nafae_amd.train import combine_batches_synthetic, prepare_batch, setup_training, train_step
+    args = default_args(batch_size=2, sample_num=2, max_ent_len=8, dropout_rate=0.0)
+    gpu.TEST.RPN_POST_NMS_TOP_N = 32
+    lb = list(combine_batches_synthetic(2, 2, 8, seed=5))
+    vocab = sorted(set(lb[1]))
+    glove = argparse.Namespace(stoi={w: i for i, w in enumerate(vocab)}, vectors=torch.randn(len(vocab), 200) * 0.4)
+    bf = prepare_batch(tuple(lb), glove, args)
+    u8 = (lb[0] + 127.5).astype(np.uint8)
+    br = prepare_batch((u8,) + tuple(lb[1:]), glove, args, raw_frames=True)
+    assert torch.equal(bf.im_data, br.im_data) and torch.equal(bf.glove_feats, br.glove_feats)
+    model, opt, crit, red = setup_training(args, seed=3)
+    loss = train_step(model, opt, crit, br, args, red)[0]
+    assert np.isfinite(float(loss))

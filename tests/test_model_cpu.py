@@ -135,3 +135,37 @@ def test_checkpoint_round_trip(tmp_path):
     assert torch.equal(m3.fasterRCNN.weight, m1.fasterRCNN.weight)
     assert abs(C.adjust_learning_rate(opt, 1e-3, 25, 0.1, 20) - 1e-4) < 1e-12 and opt.param_groups[0]['lr'] == 1e-4
     reset_cfg()
+
+
+def test_prepare_batch_mirrors_train_loop():
+    """train.prepare_batch == the per-iteration host preparation of model.py:684-747 (CPU tensors here): im_info rows
+    (h, w, 1), NCHW permute, zero-padded GloVe rows at [a*Ne + e], the empty-entity quirk, the skip and raise rules."""
+    import argparse
+    import numpy as np
+    import pytest
+    from nafae_amd.train import combine_batches_synthetic, prepare_batch
+    vocab = ['bowl', 'egg', 'pan', 'oil', 'salt', 'water']
+    glove = argparse.Namespace(stoi={w: i for i, w in enumerate(vocab)}, vectors=torch.arange(6 * 200, dtype=torch.float32).view(6, 200))
+    args = argparse.Namespace(max_ent_len=5, glove_dim=200)
+    lb = list(combine_batches_synthetic(3, 2, 5, H=32, W=48, seed=3))
+    lb[2] = [2, 0, 3]
+    lb[1] = ['egg', 'pan', 'oil', 'salt', 'bowl']
+    b = prepare_batch(tuple(lb), glove, args, device='cpu')
+    assert tuple(b.im_data.shape) == (6, 3, 32, 48) and b.im_data.dtype == torch.float32
+    assert torch.equal(b.im_data, torch.from_numpy(lb[0]).permute(0, 3, 1, 2))
+    assert torch.equal(b.im_info, torch.tensor([[32., 48., 1.]] * 6))
+    g = b.glove_feats.view(3, 5, 200)
+    assert torch.equal(g[0, 0], glove.vectors[1]) and torch.equal(g[0, 1], glove.vectors[2])
+    assert torch.equal(g[2, 0], glove.vectors[3]) and torch.equal(g[2, 2], glove.vectors[0])
+    assert not g[1].any() and not g[0, 2:].any() and not g[2, 3:].any()        # padded slots stay zero rows
+    assert b.entities_length == [2, 0, 3] and tuple(b.gt_boxes.shape) == (1, 1, 5)
+    # an empty entity string is skipped WITHOUT advancing the pointer: the next slot re-reads the same (empty) entry
+    lb2 = list(lb); lb2[1] = ['egg', '', 'oil', 'salt', 'bowl']
+    g2 = prepare_batch(tuple(lb2), glove, args, device='cpu').glove_feats.view(3, 5, 200)
+    assert torch.equal(g2[0, 0], glove.vectors[1]) and not g2[0, 1].any() and not g2[2].any()
+    # nothing to ground -> the reference skips the iteration
+    lb3 = list(lb); lb3[2] = [0, 0, 0]
+    assert prepare_batch(tuple(lb3), glove, args, device='cpu') is None
+    lb4 = list(lb); lb4[1] = ['egg', 'spatula', 'oil', 'salt', 'bowl']
+    with pytest.raises(Exception, match="spatula is not in glove vocabulary"):
+        prepare_batch(tuple(lb4), glove, args, device='cpu')
