@@ -202,6 +202,42 @@ class PipelinedTrainer:
         return loss.detach(), D, D_sim, rois
 
 
+def train_epoch(train_loader, model, glove, criterion, optimizer, reducer, args, device='cuda', raw_frames=False,
+                pipelined=True, on_step=None):
+    """One pass of the reference's train() (model.py:676-795) over any iterable of loader tuples: per tuple the host
+    preparation (prepare_batch), one training step, and the running mean loss that train() prints and logs.  Tuples with
+    no entity at all are skipped, as there (model.py:685-686).  With `pipelined` the detector of the next usable tuple is in
+    flight while the tail of the current one runs (PipelinedTrainer).  `on_step(batch_ind, loss, D, D_sim, rois, batch)`
+    is the hook for the reference's periodic visualisation (model.py:783-793); it receives device tensors, so leaving it
+    out keeps the loop free of host synchronisation except for the loss read-back at the very end.
+    Returns (mean loss over the steps taken, number of steps)."""
+    batches = (b for b in (prepare_batch(lb, glove, args, device=device, raw_frames=raw_frames) for lb in train_loader)
+               if b is not None)
+    losses = []
+    if not pipelined:
+        for i, b in enumerate(batches):
+            out = train_step(model, optimizer, criterion, b, args, reducer)
+            losses.append(out[0])
+            if on_step:
+                on_step(i, *out, b)
+    else:
+        pipe = PipelinedTrainer(model, optimizer, criterion, args, reducer)
+        cur = next(batches, None)
+        if cur is not None:
+            pipe.submit(cur)
+        i = 0
+        while cur is not None:
+            nxt = next(batches, None)
+            out = pipe.step(nxt)
+            losses.append(out[0])
+            if on_step:
+                on_step(i, *out, cur)
+            cur, i = nxt, i + 1
+    if not losses:
+        return float('nan'), 0
+    return float(torch.stack([l.reshape(()) for l in losses]).mean()), len(losses)
+
+
 def eval_step(model, batch):
     """Forward of validate() (model.py:875-947) for one segment batch."""
     with torch.no_grad():

@@ -335,3 +335,28 @@ def test_prepare_batch_raw_frames_equals_host_preprocessing(gpu):
     model, opt, crit, red = setup_training(args, seed=3)
     loss = train_step(model, opt, crit, br, args, red)[0]
     assert np.isfinite(float(loss))
+
+
+def test_train_epoch_pipelined_equals_sequential(gpu):
+    """train_epoch (the body of model.py:676-795) over a list of loader tuples, one of them without entities (skipped like
+    the reference): pipelined and sequential runs take the same steps and end with identical parameters."""
+    import argparse
+    from nafae_amd.model import default_args
+    from nafae_amd.train import combine_batches_synthetic, setup_training, train_epoch
+    args = default_args(batch_size=2, sample_num=2, max_ent_len=8, dropout_rate=0.0)
+    gpu.TEST.RPN_POST_NMS_TOP_N = 32
+    loader = [list(combine_batches_synthetic(2, 2, 8, seed=40 + i)) for i in range(4)]
+    loader[2][1], loader[2][2] = [], [0, 0]                                        # nothing to ground in this batch
+    vocab = sorted({w for lb in loader for w in lb[1]})
+    glove = argparse.Namespace(stoi={w: i for i, w in enumerate(vocab)},
+                               vectors=torch.randn(len(vocab), 200, generator=torch.Generator().manual_seed(1)) * 0.4)
+    res = []
+    for pipelined in (False, True):
+        model, opt, crit, red = setup_training(args, seed=9)
+        seen = []
+        mean_loss, n = train_epoch([tuple(lb) for lb in loader], model, glove, crit, opt, red, args, pipelined=pipelined,
+                                   on_step=lambda i, loss, D, D_sim, rois, b: seen.append((i, float(loss))))
+        assert n == 3 and [i for i, _ in seen] == [0, 1, 2]
+        assert abs(mean_loss - np.mean([l for _, l in seen])) < 1e-4 * abs(mean_loss)
+        res.append((mean_loss, opt.flat_params.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
