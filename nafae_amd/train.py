@@ -285,6 +285,39 @@ def validate_segment(model, batch, vid_entities, img_ids, args, dets):
     return float(margin_loss)
 
 
+def validate_epoch(val_loader, model, glove, args, recs=None, class_list=None, device='cuda', raw_frames=False,
+                   result_path=None, max_frames=800):
+    """The reference's validate() (model.py:800-991) over any iterable of loader tuples: eval mode, per video the 800-frame
+    cap (model.py:850-853), host preparation, chunked detector + embeddings + DVSA(eval) + postprocess + record_det
+    (validate_segment); then the detection list [img_inds, obj_labels, obj_bboxes, obj_confs] is optionally pickled under
+    the reference's file format (model.py:972-981) and scored with evaluate_box when ground-truth `recs` / `class_list`
+    (youcook_eval.parse_gt) are given.  Returns (accuracy or None, mean validation loss, dets)."""
+    import pickle
+    model.eval()
+    model.DVSA.init_eval()
+    dets = [[], [], [], []]
+    losses = []
+    for lb in val_loader:
+        im_blobs, entities, entities_length, frm_length, rl_seg_inds, seg_nums, im_paths, img_ids = lb
+        if max(entities_length) == 0:
+            continue
+        if len(im_blobs) > max_frames:
+            im_blobs, im_paths, img_ids = im_blobs[:max_frames], im_paths[:max_frames], img_ids[:max_frames]
+        batch = prepare_batch((im_blobs, entities, entities_length, frm_length, rl_seg_inds, seg_nums, im_paths, img_ids), glove,
+                              args, device=device, raw_frames=raw_frames)
+        ents = list(entities)
+        vid_entities = [[ents.pop(0) for _ in range(l)] for l in entities_length]      # model.py:906-909
+        losses.append(validate_segment(model, batch, vid_entities, list(img_ids), args, dets))
+    if result_path:
+        with open(result_path, 'wb') as f:
+            pickle.dump(dets, f)
+    accuracy = None
+    if recs is not None and class_list is not None:
+        from .evaluate import evaluate_box
+        accuracy = evaluate_box(recs, dets, class_list)
+    return accuracy, (sum(losses) / len(losses) if losses else float('nan')), dets
+
+
 def combine_batches_synthetic(Na, Ns, Ne, H=224, W=224, seed=1234, vocab=('bowl', 'egg', 'pan', 'oil', 'salt', 'water')):
     """The 8-tuple the reference's DataLoader hands to train()/validate() (lib/datasets/youcook2.py:254-308,
     unpacked at model.py:684), filled with synthetic content of the right shapes and types:

@@ -360,3 +360,34 @@ def test_train_epoch_pipelined_equals_sequential(gpu):
         assert abs(mean_loss - np.mean([l for _, l in seen])) < 1e-4 * abs(mean_loss)
         res.append((mean_loss, opt.flat_params.clone()))
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+def test_validate_epoch_over_loader_tuples(gpu, tmp_path):
+    """validate_epoch = validate() (model.py:800-991) over loader tuples: skip rule, 800-frame cap, detection pickle in the
+    reference's format, accuracy 1.0 against ground truth planted on the grounded boxes."""
+    import argparse, pickle
+    from nafae_amd.model import default_args
+    from nafae_amd.train import combine_batches_synthetic, setup_training, validate_epoch
+    Na, Ns, Ne, Nb = 1, 5, 4, 8
+    gpu.TEST.RPN_POST_NMS_TOP_N = Nb
+    args = default_args(batch_size=2, batch_size_val=Na, sample_num=Ns, max_ent_len=Ne)
+    model, _, _, _ = setup_training(args, seed=5)
+    vids = []
+    for v in range(3):
+        lb = list(combine_batches_synthetic(Na, Ns, Ne, H=64, W=64, seed=60 + v))
+        lb[2] = [2]; lb[1] = ['bowl', 'egg']; lb[7] = list(range(Ns * v, Ns * v + Ns))
+        vids.append(lb)
+    vids[1][1], vids[1][2] = [], [0]                                               # a video without entities: skipped
+    glove = argparse.Namespace(stoi={'bowl': 0, 'egg': 1}, vectors=torch.randn(2, 200, generator=torch.Generator().manual_seed(2)) * 0.4)
+    path = str(tmp_path / "ground_res.pkl")
+    acc, loss, dets = validate_epoch([tuple(v) for v in vids], model, glove, args, result_path=path, max_frames=3)
+    assert acc is None and np.isfinite(loss)
+    assert len(dets[0]) == 2 * 3 * 2 and sorted(set(dets[0])) == [0, 1, 2, 10, 11, 12]      # 2 videos x 3 capped frames x 2 entities
+    assert pickle.load(open(path, 'rb'))[1] == dets[1]
+    classes = ['bowl', 'egg']
+    recs = [{'label': [], 'bbox': [], 'thr': [], 'img_ids': []} for _ in range(3 * Ns)]      # indexed by image id
+    for i, l, b in zip(dets[0], dets[1], dets[2]):
+        recs[i]['label'].append(l); recs[i]['bbox'].append(b); recs[i]['thr'].append(0.5); recs[i]['img_ids'].append(i)
+    acc2, _, dets2 = validate_epoch([tuple(v) for v in vids], model, glove, args, recs=recs, class_list=classes, max_frames=3)
+    assert dets2[1] == dets[1]
+    assert abs(acc2 - 1.0) < 1e-5                                                  # gt planted on the grounded boxes
