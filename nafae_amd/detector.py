@@ -254,6 +254,7 @@ class _fasterRCNN(nn.Module):
                                                    want_planes=sp)
                     if sp:      # VisEbd (model.py:624-629) continues on the same arithmetic without re-splitting fc7
                         fc7._nafae_planes = fc7_pl
+                        fc7._nafae_planes_version = fc7._version       # an in-place edit of fc7 invalidates the planes
             else:
                 with ops.timed("roi_align"):
                     pooled = ops.roi_align_avg_nhwc(base_feat, rois.view(R, 5), 1.0 / 16.0)  # [R,7,7,512]

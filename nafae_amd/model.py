@@ -252,7 +252,8 @@ class VisEbd(nn.Module):
             mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device), 1.0 / (1.0 - p)
         # the detector hands fc7 over together with its split-bf16 planes (an attribute on the very tensor it returned)
         planes = getattr(feats, "_nafae_planes", None)
-        if planes is not None and (tuple(planes.shape) != tuple(feats.shape) or not feats.is_contiguous()):
+        if planes is not None and (tuple(planes.shape) != tuple(feats.shape) or not feats.is_contiguous()
+                                   or getattr(feats, "_nafae_planes_version", None) != feats._version):
             planes = None
         return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, mask, scale, planes)
 

@@ -391,3 +391,22 @@ def test_validate_epoch_over_loader_tuples(gpu, tmp_path):
     acc2, _, dets2 = validate_epoch([tuple(v) for v in vids], model, glove, args, recs=recs, class_list=classes, max_frames=3)
     assert dets2[1] == dets[1]
     assert abs(acc2 - 1.0) < 1e-5                                                  # gt planted on the grounded boxes
+
+
+def test_visebd_uses_planes_only_while_fc7_is_untouched(gpu):
+    """VisEbd continues on the detector's split-bf16 planes of fc7 (same values to ~1e-5); an in-place edit of fc7 or a
+    derived tensor falls back to the exact fp32 GEMM on the tensor's actual contents."""
+    from nafae_amd.model import default_args
+    from nafae_amd.train import make_batch, setup_training
+    gpu.TEST.RPN_POST_NMS_TOP_N = 32
+    args = default_args(batch_size=2, sample_num=2, max_ent_len=8, dropout_rate=0.0)
+    model, _, _, _ = setup_training(args, seed=4)
+    batch = make_batch(2, 2, 8, seed=4)
+    with torch.no_grad():
+        _, _, _, fc7 = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+        assert getattr(fc7, "_nafae_planes", None) is not None
+        v_planes = model.vis_ebd(fc7)
+        v_exact = model.vis_ebd(fc7.clone())                       # a copy carries no planes: fp32 GEMM
+        assert relerr(v_planes.cpu(), v_exact.cpu()) < 5e-5 and not torch.equal(v_planes, v_exact)
+        fc7.mul_(0.5)                                              # in-place edit: the planes are stale and must be ignored
+        assert torch.equal(model.vis_ebd(fc7), model.vis_ebd(fc7.clone()))
