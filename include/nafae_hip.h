@@ -172,7 +172,9 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                        float alpha, int act, void *stream);
 
 /* 3x3 conv + bias (+ReLU), NHWC planes in, fp32 and/or planes out; w planes are [Cout,3,3,Cin].
- * `relu`: bit 0 = apply ReLU.  Bits 8 and 9 are timing experiments used by scripts/layer_times.py (staging loads served
+ * `relu`: bit 0 = apply ReLU; bit 4 = also apply the 2x2/2 max-pool that follows the layer (outputs are then
+ * [F, H/2, W/2, Cout]; available where the 2-D patch kernel runs -- otherwise NAFAE_ELIMIT is returned and the caller
+ * pools separately with nafae_maxpool2x2_bf16).  Bits 8 and 9 are timing experiments used by scripts/layer_times.py (staging loads served
  * from one cached zero line / stores skipped -- the results are then meaningless); production callers pass 0 or 1.
  * Likewise `act` = -1 / -2 of nafae_gemm_nt_bf16.  */
 int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,

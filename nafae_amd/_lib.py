@@ -10,6 +10,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NAFAE_LIB points at another build of the same library (kernel A/B experiments); the default is the in-tree build
+NAFAE_OK, NAFAE_EINVAL, NAFAE_ELIMIT, NAFAE_ELAUNCH = 0, -1, -2, -3     # include/nafae_hip.h
 LIB_PATH = os.environ.get("NAFAE_LIB") or os.path.join(_HERE, "csrc", "libnafae_hip.so")
 _lib = None
 

@@ -822,7 +822,11 @@ __global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, c
 // Interleaved split planes only; H, W multiples of 16; Cout in tiles of 64.
 constexpr int PT = 16, PP = PT + 2, PROWS = 384;   // tile side, patch side, patch rows in LDS (324 used; 6 chunks per lane)
 
-template <bool PAIR>   // PAIR: plain bf16 tensors read as the two-piece layout over Cin/2 pairs (bf16_tile.h); plain output
+// PAIR: plain bf16 tensors read as the two-piece layout over Cin/2 pairs (bf16_tile.h); plain output.
+// POOL: the 2x2/2 max-pool that follows the layer is applied in the epilogue (a 16 x 16 tile holds whole pooling windows, and a
+// wave's 32 pixels are two adjacent rows of the tile, so a window is four lanes of one wave): only the pooled map is written
+// -- a quarter of the stores -- and the separate pooling pass with its read of the full map disappears.
+template <bool PAIR, bool POOL>
 __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, const __bf16 *Wt, const float *__restrict__ bias,
                                                              __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
                                                              int W, int Cin, int Cout, int relu, int tiles_y, int tiles_x,
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
   using E = EngineH<256, 64, 8, 1, true, true, false, PAIR>;   // 8 waves x (32 pixels x 64 channels)
   constexpr int XB = PROWS * 64, WS = 64 * 64;           // bf16 elements per patch buffer / per weight tap stage
   constexpr int NPC = PROWS * 8 / NT16;                  // patch staging chunks per lane (6)
-  constexpr int NSTORE = PAIR ? 4 : 8;                   // 16-byte stores per lane in the epilogue
+  constexpr int NSTORE = POOL ? (PAIR ? 1 : 2) : (PAIR ? 4 : 8);   // 16-byte stores per lane in the epilogue
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   __bf16 *xbuf = smem16, *wbuf = smem16 + 2 * XB;
   E e;
@@ -953,6 +957,28 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
       __builtin_amdgcn_s_barrier();                      // every wave is done reading the consumed patch buffer
       char *tb = reinterpret_cast<char *>(xbuf + (size_t)(ppar ^ 1) * XB) + wave * (32 * TROW);   // (ppar was flipped above)
       char *trow = tb + (lane & 31) * TROW;
+      // value of accumulator element (i, gq, q) after bias and ReLU -- and, with POOL, after the max over the lane's 2 x 2
+      // window: lanes r ^ 1 (x neighbour) and r ^ 16 (y neighbour) of the same 32-lane half
+      auto outv = [&](int i, int gq, int q) {
+        float v = e.acc[i][0][4 * gq + q] + bias[cur.n0 + i * 32 + 8 * gq + 4 * h + q];
+        if (relu & 1) v = v > 0.f ? v : 0.f;
+        if (POOL) {
+          v = fmaxf(v, __shfl_xor(v, 1));
+          v = fmaxf(v, __shfl_xor(v, 16));
+        }
+        return v;
+      };
+      // POOL: the lanes with even x in the upper row own the window; their pooled pixel is (lane & 15) >> 1 of the wave's 8
+      const bool owner = !POOL || ((lane & 17) == 0);
+      char *prow = POOL ? tb + ((lane & 15) >> 1) * TROW : trow;
+      const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+      // output pixel of piece index px of this wave
+      auto out_pix = [&](int px) {
+        if (POOL) return ((long)cur.f * Ho + cur.y0 / 2 + wave) * Wo + cur.x0 / 2 + px;
+        const int m = wave * 32 + px;
+        return ((long)cur.f * H + cur.y0 + (m >> 4)) * W + cur.x0 + (m & 15);
+      };
+      constexpr int NIT = POOL ? 1 : 4;                  // 64 pieces of 16 B per pass: 8 pixels x 8 pieces
       if constexpr (PAIR) {
         // plain bf16 output: the tile's 64 channels of a pixel are one 128-B line
 #pragma unroll
@@ -962,53 +988,45 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
             const int nl = i * 32 + 8 * gq + 4 * h;
             bf16x4 o;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-              float v = e.acc[i][0][4 * gq + q] + bias[cur.n0 + nl + q];
-              if (relu & 1) v = v > 0.f ? v : 0.f;
-              o[q] = (__bf16)v;
-            }
-            *reinterpret_cast<bf16x4 *>(trow + nl * 2) = o;
+            for (int q = 0; q < 4; q++) o[q] = (__bf16)outv(i, gq, q);
+            if (owner) *reinterpret_cast<bf16x4 *>(prow + nl * 2) = o;
           }
         char *obase = reinterpret_cast<char *>(Chi) + cur.n0 * 2;
         const long rowp = (long)Cout * sizeof(__bf16);
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < NIT; it++) {
           const int qd = it * 64 + lane, px = qd >> 3, part = qd & 7;
-          const int m = wave * 32 + px;
-          const long mg = ((long)cur.f * H + cur.y0 + (m >> 4)) * W + cur.x0 + (m & 15);
           const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
-          if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + mg * rowp + part * 16) = d;
+          if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + out_pix(px) * rowp + part * 16) = d;
         }
       } else {
-      const long rowb = (long)2 * Cout * sizeof(__bf16);             // bytes per output pixel (interleaved planes)
+        const long rowb = (long)2 * Cout * sizeof(__bf16);           // bytes per output pixel (interleaved planes)
 #pragma unroll
-      for (int i = 0; i < 2; i++) {                      // one 32-channel piece (= one 128-B line per pixel) at a time
+        for (int i = 0; i < 2; i++) {                    // one 32-channel piece (= one 128-B line per pixel) at a time
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-          const int nl = 8 * gq + 4 * h;                 // channel inside the piece
-          bf16x4 hi, lo;
+          for (int gq = 0; gq < 4; gq++) {
+            const int nl = 8 * gq + 4 * h;               // channel inside the piece
+            bf16x4 hi, lo;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            float v = e.acc[i][0][4 * gq + q] + bias[cur.n0 + i * 32 + nl + q];
-            if (relu & 1) v = v > 0.f ? v : 0.f;
-            __bf16 a, b;
-            split_bf16(v, a, b);
-            hi[q] = a;
-            lo[q] = b;
+            for (int q = 0; q < 4; q++) {
+              __bf16 a, b;
+              split_bf16(outv(i, gq, q), a, b);
+              hi[q] = a;
+              lo[q] = b;
+            }
+            if (owner) {
+              *reinterpret_cast<bf16x4 *>(prow + nl * 2) = hi;
+              *reinterpret_cast<bf16x4 *>(prow + 64 + nl * 2) = lo;
+            }
           }
-          *reinterpret_cast<bf16x4 *>(trow + nl * 2) = hi;
-          *reinterpret_cast<bf16x4 *>(trow + 64 + nl * 2) = lo;
-        }
-        char *obase = reinterpret_cast<char *>(Chi) + ((cur.n0 >> 5) + i) * 128;
+          char *obase = reinterpret_cast<char *>(Chi) + ((cur.n0 >> 5) + i) * 128;
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-          const int qd = it * 64 + lane, px = qd >> 3, part = qd & 7;   // 8 pieces of 16 B per pixel
-          const int m = wave * 32 + px;
-          const long mg = ((long)cur.f * H + cur.y0 + (m >> 4)) * W + cur.x0 + (m & 15);
-          const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
-          if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + mg * rowb + part * 16) = d;   // (bit 8: timing experiment)
+          for (int it = 0; it < NIT; it++) {
+            const int qd = it * 64 + lane, px = qd >> 3, part = qd & 7;   // 8 pieces of 16 B per pixel
+            const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
+            if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + out_pix(px) * rowb + part * 16) = d;   // (bit 8: timing experiment)
+          }
         }
-      }
       }
       e.zero_acc();
       younger = (relu & 256) ? 0 : NSTORE;
@@ -1328,7 +1346,7 @@ int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const vo
   return launched();
 }
 
-template <bool PAIR>
+template <bool PAIR, bool POOL = false>
 int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void *Chi, void *Clo, int F, int H, int W,
                       int Cin, int Cout, int relu, hipStream_t st) {
   const int tiles_y = H / PT, tiles_x = W / PT, tiles_n = Cout / 64;
@@ -1337,7 +1355,7 @@ int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void 
   const size_t lds = (size_t)(2 * PROWS * 64 + 6 * 64 * 64) * sizeof(__bf16);
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel<PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel<PAIR, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     once = true;
   }
@@ -1351,7 +1369,7 @@ int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void 
   }
   const long want = (long)per_cu * num_cus();
   const int G = (int)(T < want ? T : want);
-  hipLaunchKernelGGL(conv3x3_patch_kernel<PAIR>, dim3(G), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Whi, bias,
+  hipLaunchKernelGGL((conv3x3_patch_kernel<PAIR, POOL>), dim3(G), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Whi, bias,
                      (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_y, tiles_x, tiles_n);
   return launched();
 }
@@ -1485,6 +1503,7 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
   const bool split = in_lo && w_lo;
   if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
   if (host_il(in_hi, in_lo) && !(use_dma() && use_run())) return NAFAE_EINVAL;  // I32 operands: run-reuse kernels only
+  if ((relu & 16) && (!(use_dma() && use_run()) || (H & 1) || (W & 1))) return NAFAE_ELIMIT;
   if (use_dma() && use_run()) {
     const int M = F * H * W;
     if (split) {
@@ -1497,7 +1516,9 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
         const bool off = pe && pe[0] == '0', all = pe && pe[0] == 'a';
         if (il && !off && !out_f32 && out_hi && out_lo && host_il(out_hi, out_lo) && H % PT == 0 && W % PT == 0 && Cout % 64 == 0 &&
             (all || (Cin <= 128 && Cout <= 128)) && (long)F * (H / PT) * (W / PT) * (Cout / 64) >= num_cus())
-          return launch_conv_patch<false>(in_hi, w_hi, bias, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+          return (relu & 16) ? launch_conv_patch<false, true>(in_hi, w_hi, bias, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream))
+                             : launch_conv_patch<false>(in_hi, w_hi, bias, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
+        if (relu & 16) return NAFAE_ELIMIT;   // fused max-pool exists in the patch kernel only: the caller pools separately
       }
       if (Cout <= 64) {
         static int g3 = -1;  // NAFAE_CONV_RUN3=0: one barrier per tap instead of per 3-tap group (A/B)
@@ -1562,7 +1583,9 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
         const char *pp = getenv("NAFAE_CONV_PATCH");
         if (!(pp && pp[0] == '0') && !out_f32 && out_hi && H % PT == 0 && W % PT == 0 && Cout % 64 == 0 &&
             ((pp && pp[0] == 'a') || (Cin <= 128 && Cout <= 128)) && (long)F * (H / PT) * (W / PT) * (Cout / 64) >= G)
-          return launch_conv_patch<true>(in_hi, w_hi, bias, out_hi, nullptr, F, H, W, Ce, Cout, relu, S(stream));
+          return (relu & 16) ? launch_conv_patch<true, true>(in_hi, w_hi, bias, out_hi, nullptr, F, H, W, Ce, Cout, relu, S(stream))
+                             : launch_conv_patch<true>(in_hi, w_hi, bias, out_hi, nullptr, F, H, W, Ce, Cout, relu, S(stream));
+        if (relu & 16) return NAFAE_ELIMIT;
         if (Cout >= 256 && M >= 256 * 128) {
           if (workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 255) / 256), G) &&
               workspace_bytes >= (int64_t)sk_scratch_bytes(256, 256, G))
@@ -1583,6 +1606,7 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
                                                                    W, Ce, Cout, relu, S(stream));
       }
     }
+    if (relu & 16) return NAFAE_ELIMIT;
     // 32-channel k-tiles: weight tiles of 128 / 256 rows fill the 512 lanes evenly; 64-row tiles do not,
     // so the Cout <= 64 layer stays on the per-tap kernels below
     if (Cout >= 256 && M >= 256 * 128)

@@ -146,13 +146,21 @@ class _fasterRCNN(nn.Module):
             sp = self.precision == 'bf16x3'
             x = ops.conv1_3x3_relu_bf16(im_data.contiguous(), P['conv1_w'], P['conv1_b'], split=sp, il=sp)
             li = 0
-            for v in VGG_CFG_D[1:]:
-                if v == 'M':
+            seq = VGG_CFG_D[1:]
+            k = 0
+            while k < len(seq):
+                if seq[k] == 'M':
                     x = ops.maxpool2x2_bf16(x)
+                    k += 1
+                    continue
+                w, b = P['convs_h'][li]
+                li += 1
+                if k + 1 < len(seq) and seq[k + 1] == 'M':       # conv + ReLU + max-pool: fused where the library can
+                    _, x = ops.conv3x3_bf16(x, w, b, relu=True, pool=True)
+                    k += 2
                 else:
-                    w, b = P['convs_h'][li]
                     _, x = ops.conv3x3_bf16(x, w, b, relu=True)
-                    li += 1
+                    k += 1
             return x
         x = ops.conv1_3x3_relu(im_data.contiguous(), P['conv1_w'], P['conv1_b'])
         li = 0

@@ -284,9 +284,27 @@ def _conv_workspace(nbytes, device):
     return t
 
 
-def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_workspace=True, _dbg=0):
+def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_workspace=True, _dbg=0, pool=False):
     """X Planes [F,H,W,Cin], Wt Planes [Cout,3,3,Cin] -> (f32 or None, Planes or None) of [F,H,W,Cout].
-    use_workspace=False forces the one-tile-per-workgroup schedule (tests / A-B)."""
+    use_workspace=False forces the one-tile-per-workgroup schedule (tests / A-B).
+    pool=True: conv + ReLU + the 2x2/2 max-pool that follows, fused where the library can (planes of [F,H/2,W/2,Cout]), as two
+    launches otherwise -- same result up to which of two nearly equal window elements wins (<= 2^-17 relative)."""
+    if pool:
+        if want_f32 or not want_planes:
+            raise NafaeOpError("conv3x3_bf16(pool=True) returns planes only")
+        F, H, W, Cin = X.shape
+        Cout = Wt.shape[0]
+        split = X.lo is not None
+        if H % 2 == 0 and W % 2 == 0:
+            C = _alloc_planes((F, H // 2, W // 2, Cout), X.hi.device, split, X.il and Cout % 32 == 0)
+            rc = _lib.lib().nafae_conv3x3_bf16_ws(_p(X.hi), _p(X.lo), _p(Wt.hi), _p(Wt.lo), _p(bias), None, _p(C.hi), _p(C.lo), F, H,
+                                                  W, Cin, Cout, int(bool(relu)) | 16 | (int(_dbg) << 8), None, 0, _stream())
+            if rc == 0:
+                return None, C
+            if rc != _lib.NAFAE_ELIMIT:
+                _rc(rc, "nafae_conv3x3_bf16_ws")
+        _, Y = conv3x3_bf16(X, Wt, bias, relu=relu, use_workspace=use_workspace, _dbg=_dbg)
+        return None, maxpool2x2_bf16(Y)
     _chk_planes(X, "X"); _chk_planes(Wt, "W"); _chk(bias)
     F, H, W, Cin = X.shape
     Cout = Wt.shape[0]

@@ -36,8 +36,10 @@ for (name, H, Cin, Cout, pool) in (("conv1_2", 224, 64, 64, True), ("conv2_1", 1
                                                                  timeit(lambda: ops.conv3x3_bf16(xp, wp, cb, _dbg=2)))
     if pool:
         _, y = ops.conv3x3_bf16(xp, wp, cb)
-        mp = timeit(lambda: ops.maxpool2x2_bf16(y)); tot += mp
-        line += "   + pool %.3f ms" % mp
+        mp = timeit(lambda: ops.maxpool2x2_bf16(y))
+        fused = timeit(lambda: ops.conv3x3_bf16(xp, wp, cb, pool=True))
+        tot += fused - ms
+        line += "   + pool %.3f ms (conv+pool in one call: %.3f ms)" % (mp, fused)
     print(line)
     del x, w, xp, wp
 print("sum %.3f ms" % tot)

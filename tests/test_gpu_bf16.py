@@ -266,3 +266,28 @@ def test_conv_plain_bf16_pair_mode(F, H, W, Cin, Cout, monkeypatch):
     assert float((f1 - f0).abs().max()) <= 2e-5 * scale
     for p in (p1, p2):
         assert p.lo is None and float((ops.merge_bf16(p) - ref).abs().max()) <= 5e-3 * scale   # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize("F,H,W,Cin,Cout,split", [(8, 64, 128, 64, 64, True), (3, 112, 112, 64, 128, True), (4, 64, 64, 128, 128, True),
+                                                   (8, 64, 128, 64, 64, False), (4, 64, 64, 128, 128, False), (2, 56, 56, 128, 256, True)])
+def test_conv_fused_maxpool(F, H, W, Cin, Cout, split):
+    """conv + ReLU + 2x2/2 max-pool in one launch (patch kernel epilogue; falls back to two launches where that kernel does
+    not run, e.g. the 56^2 case) == max-pool of the separately computed conv output, up to which of two nearly equal window
+    elements wins (<= 2^-17 relative for split planes, one bf16 ulp for plain)."""
+    from nafae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(H + Cin + Cout)
+    x = torch.randn(F, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    xp, wp = ops.split_bf16(x, split, split), ops.split_bf16(w, split, split)
+    _, y = ops.conv3x3_bf16(xp, wp, b, relu=True)
+    ref = ops.merge_bf16(ops.maxpool2x2_bf16(y))
+    _, p = ops.conv3x3_bf16(xp, wp, b, relu=True, pool=True)
+    _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True, pool=True)
+    out = ops.merge_bf16(p)
+    assert tuple(out.shape) == (F, H // 2, W // 2, Cout) and torch.equal(p.hi, p2.hi)
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= (2e-5 if split else 8e-3) * scale
+    full = torch.relu(torch.nn.functional.conv2d(ops.merge_bf16(xp).permute(0, 3, 1, 2), ops.merge_bf16(wp).permute(0, 3, 1, 2), b, padding=1))
+    pooled = torch.nn.functional.max_pool2d(full, 2, 2).permute(0, 2, 3, 1)
+    assert float((out - pooled).abs().max()) <= (5e-5 if split else 8e-3) * float(pooled.abs().max())
