@@ -101,6 +101,7 @@ struct EngineH {
   static constexpr int TW = BW / WW / 32;
   static_assert(TX >= 1 && TW >= 1, "tile too small");
   static constexpr int MS = S16 ? 16 : 32;
+  static constexpr int BXT = BX, BWT = BW;          // tile extents (rows of the activation side, of the weight side)
   static constexpr int NJ = BX / WX / MS, NI = BW / WW / MS, NG = S16 ? 1 : 4;
   static constexpr int NGRP = 4 * TW * TX / (S16 ? 1 : 2);  // `between` call sites per k-tile
   static constexpr int PL = SPLIT ? 2 : 1;

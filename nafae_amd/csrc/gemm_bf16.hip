@@ -36,6 +36,36 @@ __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, flo
                                          int act, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
                                          __bf16 *__restrict__ Clo, int ldc) {
   const bool oil = SPLIT && plane_il(Chi, Clo);
+  // Common case of the conv / fc layers -- interleaved planes only, bias present, tile entirely inside the matrix: one straight
+  // block without the per-piece bounds / output-kind branches of the general path below (which costs ~3300 instructions per
+  // wave for a 256x256 tile; the short conv tiles feel that).
+  if (SPLIT && oil && !Cf && bias && m0 + E::BXT <= M && n0 + E::BWT <= N && act >= 0) {
+#pragma unroll
+    for (int i = 0; i < E::NI; i++)
+#pragma unroll
+      for (int g = 0; g < E::NG; g++) {
+        const int n = n0 + e.pn(i, g);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n);
+        const size_t co = ((size_t)(n >> 5) << 6) + (n & 31);
+#pragma unroll
+        for (int j = 0; j < E::NJ; j++) {
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float t = alpha * e.acc[i][j][4 * g + q] + bv[q];
+            if (act == NAFAE_ACT_RELU) t = fmaxf(t, 0.f);
+            __bf16 a, b;
+            split_bf16(t, a, b);
+            hi[q] = a;
+            lo[q] = b;
+          }
+          __bf16 *row = Chi + (size_t)(m0 + e.pm(j)) * (2 * ldc) + co;
+          *reinterpret_cast<bf16x4 *>(row) = hi;
+          *reinterpret_cast<bf16x4 *>(row + 32) = lo;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < E::NJ; j++) {
     const int m = m0 + e.pm(j);
