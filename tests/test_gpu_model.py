@@ -401,6 +401,7 @@ def test_visebd_uses_planes_only_while_fc7_is_untouched(gpu):
     gpu.TEST.RPN_POST_NMS_TOP_N = 32
     args = default_args(batch_size=2, sample_num=2, max_ent_len=8, dropout_rate=0.0)
     model, _, _, _ = setup_training(args, seed=4)
+    model.fasterRCNN.precision = 'bf16x3'                          # (whatever NAFAE_PRECISION says)
     batch = make_batch(2, 2, 8, seed=4)
     with torch.no_grad():
         _, _, _, fc7 = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
