@@ -261,7 +261,9 @@ def test_pipelined_trainer_equals_sequential(gpu):
     torch.cuda.synchronize()
     assert np.allclose(seq, par, rtol=1e-5), (seq, par)
     assert len(set(seq)) > 1                                        # the trajectory actually moves
-    assert relerr(m2.vis_ebd.fc1.weight.detach().cpu(), m1.vis_ebd.fc1.weight.detach().cpu()) < 1e-5
+    # (the weight-gradient GEMM accumulates its K-splits with atomic adds: run-to-run differences in the last bit, which Adam's
+    # normalisation passes on to the weights)
+    assert relerr(m2.vis_ebd.fc1.weight.detach().cpu(), m1.vis_ebd.fc1.weight.detach().cpu()) < 5e-5
 
 
 def test_reference_default_shapes(gpu):
