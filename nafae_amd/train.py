@@ -186,6 +186,11 @@ class PipelinedTrainer:
         main.wait_event(ev)
         for t in (rois, fc_feats):                 # produced on the detector stream, consumed here
             t.record_stream(main)
+        planes = getattr(fc_feats, "_nafae_planes", None)   # fc7's split-bf16 planes travel with it (VisEbd reads them)
+        if planes is not None:
+            for t in (planes.hi, planes.lo):
+                if t is not None:
+                    t.record_stream(main)
         model, args = self.model, self.args
         vis_feats = model.vis_ebd(fc_feats)
         word_feats = model.word_ebd(batch.glove_feats)
