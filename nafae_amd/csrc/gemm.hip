@@ -7,6 +7,7 @@
 //
 // Reference call sites are cited next to each extern "C" entry point (declared in include/nafae_hip.h).
 #include "mfma_tile.h"
+#include <stdlib.h>
 #include "../../include/nafae_hip.h"
 
 using namespace nafae;
@@ -430,6 +431,49 @@ void launch_conv(const float *in, const float *w, const float *bias, float *out,
 
 }  // namespace
 
+// Weight gradients must not depend on thread timing: no split-K (its atomic accumulation made the last bit of a gradient
+// vary from run to run).  Parallelism comes from the tile size instead -- the largest of 128x128 / 64x128 / 64x64 that still
+// gives about one workgroup per CU (VisEbd's 512 x 4096 gradient: 256 tiles of 64x128).  NAFAE_GEMM_TN_SPLITK=1 restores the
+// split-K schedule (A/B).
+template <int BM, int BN>
+static int launch_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K, float alpha,
+                          int accumulate, const int32_t *rows, const int32_t *count, bool splitk, hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+  const size_t lds = 2 * (BM + BN) * BK * sizeof(float);
+  int splits = 1, k_chunk = ((K + BK - 1) / BK) * BK;
+  if (splitk && !accumulate) {
+    const int nk_total = (K + BK - 1) / BK;
+    if (rows) {
+      while (tiles * splits < 512 && splits < 8) splits *= 2;   // the k range is only known on the device: fixed split count
+    } else {
+      while (tiles * splits < 512 && nk_total / (splits * 2) >= 8) splits *= 2;
+      k_chunk = ((nk_total + splits - 1) / splits) * BK;
+      splits = (K + k_chunk - 1) / k_chunk;
+    }
+    if (splits > 1 && hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st) != hipSuccess)
+      return NAFAE_EINVAL;
+  }
+  // (gridDim.x > tiles selects the atomic epilogue; with a single slice plain stores are used)
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tiles * splits), dim3(NTHREADS), lds, st, A, lda, B, ldb, C, ldc, M, N, K, alpha,
+                     accumulate, tiles_m, tiles_n, k_chunk, rows, count);
+  return launched();
+}
+
+static int gemm_tn_dispatch(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K, float alpha,
+                            int accumulate, const int32_t *rows, const int32_t *count, hipStream_t st) {
+  const char *e = getenv("NAFAE_GEMM_TN_SPLITK");
+  const bool splitk = e && e[0] == '1';
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long)((M + 63) / 64) * ((N + 127) / 128);
+  static int pref = -1;   // NAFAE_GEMM_TN_MIN_TILES: workgroups wanted before a larger tile is accepted (default 384)
+  if (pref < 0) {
+    const char *t = getenv("NAFAE_GEMM_TN_MIN_TILES");
+    pref = t && atoi(t) > 0 ? atoi(t) : 384;
+  }
+  if (splitk || t128 >= pref) return launch_gemm_tn<128, 128>(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, rows, count, splitk, st);
+  if (t64 >= pref) return launch_gemm_tn<64, 128>(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, rows, count, false, st);
+  return launch_gemm_tn<64, 64>(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, rows, count, false, st);
+}
+
 extern "C" {
 
 int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M,
@@ -448,43 +492,14 @@ int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, in
                   float alpha, int accumulate, void *stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
-  constexpr int BM = 128, BN = 128;
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const size_t lds = 2 * (BM + BN) * BK * sizeof(float);
-  // split K so that ~2 workgroups per CU exist; slices accumulate with fp32 atomics into a zeroed C
-  int tiles = tiles_m * tiles_n;
-  int splits = 1;
-  const int nk_total = (K + BK - 1) / BK;
-  if (!accumulate) {
-    while (tiles * splits < 512 && nk_total / (splits * 2) >= 8) splits *= 2;
-  }
-  int k_chunk = ((nk_total + splits - 1) / splits) * BK;
-  splits = (K + k_chunk - 1) / k_chunk;
-  if (splits > 1) {
-    hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, S(stream));
-    if (e != hipSuccess) return NAFAE_EINVAL;
-  }
-  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tiles * splits), dim3(NTHREADS), lds, S(stream), A, lda, B, ldb, C,
-                     ldc, M, N, K, alpha, accumulate, tiles_m, tiles_n, k_chunk, nullptr, nullptr);
-  return launched();
+  return gemm_tn_dispatch(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, nullptr, nullptr, S(stream));
 }
 
 int nafae_gemm_tn_rows(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, const int32_t *rows,
                        const int32_t *count, int max_rows, float alpha, void *stream) {
   if (!A || !B || !C || !rows || !count || M <= 0 || N <= 0 || max_rows <= 0) return NAFAE_EINVAL;
   if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
-  constexpr int BM = 128, BN = 128;
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const size_t lds = 2 * (BM + BN) * BK * sizeof(float);
-  const int tiles = tiles_m * tiles_n;
-  int splits = 1;
-  while (tiles * splits < 512 && splits < 8) splits *= 2;   // the k range is only known on the device: fixed split count
-  hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, S(stream));
-  if (e != hipSuccess) return NAFAE_EINVAL;
-  // (gridDim.x > tiles selects the atomic epilogue; with a single slice plain stores are used)
-  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tiles * splits), dim3(NTHREADS), lds, S(stream), A, lda, B, ldb, C, ldc, M,
-                     N, max_rows, alpha, 0, tiles_m, tiles_n, 0, rows, count);
-  return launched();
+  return gemm_tn_dispatch(A, lda, B, ldb, C, ldc, M, N, max_rows, alpha, 0, rows, count, S(stream));
 }
 
 int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias, float *out_nhwc, int F, int H,
