@@ -1,27 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: training steps of the NAFAE grounding hot path on synthetic data (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--precision f32|bf16x3|bf16]
 
 One "step" = one pass of the hot path over one segment batch, exactly the body of the reference's train loop
 (model.py:684-775): frozen detector forward (VGG16 conv -> RPN/NMS -> ROI-Align -> fc6/fc7), VisEbd / WordEbd,
 similarity + contextual-similarity + clustering loss, backward, gradient all-reduce (N > 1), clip, Adam.
-Inputs (frames, GloVe rows) are resident in HBM before the timed region.  At N = 1 the workload is BASELINE
-config C2 (64 frames 224x224, 128 proposals/frame, 16 query slots, fp32 parity); each additional GPU processes its
-own 64 frames (weak scaling, no data-path collective; one RCCL all-reduce of 8.8 MB of gradients per step).
+Inputs (frames, GloVe rows) are resident in HBM before the timed region.
 
-Arithmetic (`dtype`, --precision): the default `bf16x3` evaluates every detector contraction as three bf16 MFMAs on
-split-bf16 operands with fp32 accumulation -- it meets the fp32 parity bar of BASELINE.json (1e-4; measured ~1e-5,
-tests/test_gpu_bf16.py) and is what SURVEY.md section 7(iv) names as the alternative to fp32 MFMA.  `f32` (exact fp32
-MFMA) and `bf16` (BASELINE config C3) are timed in the same invocation and reported under `other_precisions`.
+Workload and arithmetic.  N = 1: BASELINE config C2 -- 64 frames 224x224, 128 proposals/frame, 16 query slots, **fp32**:
+the headline (`value`, `dtype` = "f32") is the exact-fp32 MFMA path, because that is the arithmetic C2 names.  The same step in
+the two faster arithmetic modes is timed in the same invocation, each over the same K steps with its own roofline block, and
+reported under `modes`: "bf16x3" (split-bf16, three bf16 MFMAs per product; meets the 1e-4 fp32 parity bar) and "bf16"
+(BASELINE config C3).  N > 1: BASELINE config C4 per GPU (64 frames, 256 proposals/frame, 32 query slots), weak scaling, one
+RCCL all-reduce of the 8.8 MB flat gradient buffer per step.
 
-Prints ONE JSON line on rank 0.  `value` = frames/s over all GPUs; pairs/s through sim+loss is reported next to
-it.  `roofline` prices the dominant kernel (the fc6 fp32-MFMA GEMM) from HIP-event timings taken inside the timed
-region on the launch stream; `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
+Launch.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent
+only counts devices (never initialises the GPU), spawns one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+relays rank 0's JSON line and exits non-zero if fewer than N devices are visible or a rank fails.  Under
+`python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE already set) it runs as one rank.
+
+Prints ONE JSON line on rank 0.  `value` = frames/s over all GPUs.  `roofline` prices the dominant kernel (the fc6 GEMM) with
+its ALGORITHMIC flops / the kernel's average duration (HIP events on the launch stream inside the timed region) / the dense
+MFMA peak of the dtype; `mfma_issue_util` is the separate figure for issued MFMA work (3x in bf16x3).  `roofline_sim` and
+`sim_loss_c5` time the similarity kernel stand-alone (a hipGraph of back-to-back launches, so the figure is kernel time and not
+Python launch time) against the HBM roofline.  `cpu_baseline` times the CPU oracle on the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,6 +47,14 @@ WORKLOADS = {
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense (the 5 PF headline includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0
+MODE_INFO = {
+    # precision: (MFMAs issued per algorithmic product, dense peak of the pipe, fc6 kernel, bytes per operand element)
+    "f32": (1, FP32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel<128,128,2,2> (fc6, exact fp32 MFMA)", 4.0, "gemm_nt_fc6"),
+    "bf16x3": (3, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,split,gemm,2> (fc6, 3 bf16 MFMAs per product)", 4.0,
+               "gemm_bf16x3_fc6_256x256_il"),
+    "bf16": (1, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,plain,gemm,3> (fc6, bf16 MFMA)", 2.0,
+             "gemm_bf16_plain_fc6_256x256"),
+}
 
 
 def flops_per_frame(Nb):
@@ -47,121 +64,203 @@ def flops_per_frame(Nb):
 
 def pmc_traffic(kernel_key):
     """HBM-side bytes per launch from the latest committed PMC pass (profiles/rNN_pmc_counters.json: separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction).  A STATIC lookup of a committed
+    profile of the same kernel at the same shape -- not a counter read of this run.  (value, source file) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-        return d[kernel_key]["traffic_bytes_corrected"]
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if kernel_key in d:
+                return d[kernel_key]["traffic_bytes_corrected"], os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(Na, Ns, Nb, Ne, seconds_budget=25.0):
-    """CPU oracle (oracle/: plain PyTorch fp32 + C NMS/ROI-Align) on a bounded sample of the same workload:
-    `nf` frames through the detector + embeddings, then sim+loss at the full (R, Q) shape, all host cores."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline():
+    """the CPU oracle (oracle/: plain PyTorch fp32 + C NMS / ROI-Align -- a restatement, hence
+    kind "port") on config C1 EXACTLY (4 frames 224x224, 32 proposals/frame, 8 query slots, Na=2, Ns=2, lens [3,5], VGG16
+    random-init seed 1234, one forward + loss), all host cores, 1 warm-up + 5 timed runs (3 when a run takes > 8 s), median and
+    min, stage by stage; plus sim+loss forward+backward alone at the C2 shape (R=8192, Q=128)."""
+    import statistics
     import torch
     from nafae_amd import synthetic as syn
     from oracle import detector as OD
     from oracle import dvsa as O
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    nf = 4
+    Na, Ns, Nb, Ne, lens = 2, 2, 32, 8, [3, 5]
+    nf = Na * Ns
     sd = syn.detector_state(seed=1234, heads=False)
     im, im_info = syn.frames(nf, 224, 224, seed=1234)
-    ocfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
-                RPN_POST_NMS_TOP_N=Nb, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
-    t0 = time.time()
-    rois, rs, pooled, fc7 = OD.detector_forward(im, im_info, sd, ocfg)
-    t_det = time.time() - t0
-    # sim + loss (+ backward) at the full shape
-    V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, 512, seed=1)
-    lens = syn.entity_lengths(Na, Ne, seed=1234)
+    glove = syn.glove(Na, Ne, lens, dim=200, seed=1234)
+    g = torch.Generator().manual_seed(1234)
+    ve_w, ve_b = torch.randn(512, 4096, generator=g) / 64.0, torch.randn(512, generator=g) * 0.01
+    we_w, we_b = torch.randn(512, 200, generator=g) / 200 ** 0.5, torch.randn(512, generator=g) * 0.01
+    rp = {k[len('RCNN_rpn.'):]: v for k, v in sd.items() if k.startswith('RCNN_rpn.')}
+
+    def one_run():
+        t = [time.perf_counter()]
+        with torch.no_grad():
+            base = OD.vgg16_features(im, sd)
+            t.append(time.perf_counter())
+            prob, deltas = OD.rpn_head(base, rp)
+            s, props = OD.decode_proposals(prob, deltas, im_info, 16, [4, 8, 16, 32], [0.5, 1, 2])
+            order = OD.sort_desc(s)
+            rois, _, _ = OD.select_proposals(s, props, order, 6000, Nb, 0.7)
+            t.append(time.perf_counter())
+            pooled = OD.roi_align_avg(base, rois.view(-1, 5), 7, 1.0 / 16.0)
+            t.append(time.perf_counter())
+            fc7 = OD.head_to_tail(pooled, sd)
+            t.append(time.perf_counter())
+            V = O.vis_ebd(fc7, ve_w, ve_b)
+            W = O.word_ebd(glove, we_w, we_b, torch.ones(512), torch.zeros(512), torch.zeros(512), torch.ones(512), training=True)
+            O.dvsa_forward(V, W, lens, Na, Nb, Ne, 10.0, 4.13, 'train')
+            t.append(time.perf_counter())
+        return [t[i + 1] - t[i] for i in range(5)] + [t[-1] - t[0]]
+
+    first = one_run()                                   # warm-up
+    n_runs = 5 if first[-1] <= 8.0 else 3
+    runs = [one_run() for _ in range(n_runs)]
+    names = ["conv_stack", "rpn_nms", "roi_align", "fc_head", "sim_loss", "total"]
+    med = {n: statistics.median(r[i] for r in runs) for i, n in enumerate(names)}
+    mn = {n: min(r[i] for r in runs) for i, n in enumerate(names)}
+    # sim + loss (+ backward) alone at the C2 shape
+    V, W = syn.embeddings(8192, 128, 512, seed=1)
+    lens2 = syn.entity_lengths(8, 16, seed=1234)
     V.requires_grad_(); W.requires_grad_()
-    t0 = time.time()
-    Di, Ds, L = O.dvsa_forward(V, W, lens, Na, Nb, Ne, 10.0, 4.13, 'train')
-    L.backward()
-    t_sim = time.time() - t0
-    frames = Na * Ns
-    per_frame = t_det / nf + t_sim / frames
-    return {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle detector forward on %d of %d frames (%.1f s) + sim+loss fwd+bwd at R=%d,Q=%d (%.2f s), "
-                      "torch CPU fp32, %d threads" % (nf, frames, t_det, Na * Ns * Nb, Na * Ne, t_sim, cores),
-            "pairs_per_s": round(Na * Ns * Nb * Na * Ne / t_sim, 1)}
+    ts = []
+    for i in range(4):
+        V.grad = W.grad = None
+        t0 = time.perf_counter()
+        _, _, L = O.dvsa_forward(V, W, lens2, 8, 128, 16, 10.0, 4.13, 'train')
+        L.backward()
+        ts.append(time.perf_counter() - t0)
+    t_sim = statistics.median(ts[1:])
+    return {"value": round(nf / med["total"], 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "config C1 exactly: %d frames 224x224, %d proposals/frame, %d query slots, one forward + loss; 1 warm-up + %d "
+                      "timed runs, torch CPU fp32 + C NMS/ROI-Align, %d threads" % (nf, Nb, Ne, n_runs, cores),
+            "median_s": round(med["total"], 4), "min_s": round(mn["total"], 4), "frames_per_s_best": round(nf / mn["total"], 4),
+            "stages_median_ms": {k: round(1e3 * v, 2) for k, v in med.items() if k != "total"},
+            "stages_min_ms": {k: round(1e3 * v, 2) for k, v in mn.items() if k != "total"},
+            "sim_loss_c2_shape": {"R": 8192, "Q": 128, "fwd_bwd_median_s": round(t_sim, 4),
+                                  "pairs_per_s": round(8192 * 128 / t_sim, 1), "runs": 3}}
 
 
-def sim_loss_only(Na, Ns, Nb, Ne, dev, iters=50):
-    """The similarity + loss part alone (SURVEY.md section 8d, C5 note): synthetic V, W = tanh(N(0,1)) of the workload's shape,
-    sim+max forward, loss tail forward+backward, similarity backward; HIP-event time over `iters` back-to-back passes."""
+# ------------------------------------------------------------------------------------------------ sim + loss alone
+def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20):
+    """The similarity + loss part alone: synthetic V, W = tanh(N(0,1)) of the workload's shape; the
+    sim+max forward, and forward + loss tail + similarity backward.  Each is captured into a hipGraph of `iters` back-to-back
+    passes and replayed between two HIP events on the launch stream, so the per-pass time is device time (kernel + the
+    ~1.5 us dependent-launch boundary), not Python launch overhead."""
     import torch
     from nafae_amd import ops
     from nafae_amd import synthetic as syn
     F, Q, R, D = Na * Ns, Na * Ne, Na * Ns * Nb, 512
     V, W = syn.embeddings(R, Q, D, seed=1)
     V, W = V.to(dev), W.to(dev)
-    lens = torch.tensor(syn.entity_lengths(Na, Ne, seed=1234), dtype=torch.int32, device=dev)
+    lens = lens if lens is not None else syn.entity_lengths(Na, Ne, seed=1234)
+    live = sum(min(max(int(l), 0), Ne) for l in lens)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
     ws = ops.loss_workspace(Na, Ns, Nb, Ne, D, V.device)
 
     def fwd():
-        return ops.sim_max_fwd(V, W, lens, Na, Ns, Nb, Ne)
+        return ops.sim_max_fwd(V, W, lens_t, Na, Ns, Nb, Ne)
 
     def full():
         S_max, D_ind = fwd()
-        loss, dS, _ = ops.loss_fwd_bwd(S_max, D_ind, V, lens, Na, Ns, Nb, Ne, 10.0, 4.13, True, workspace=ws)
-        return ops.sim_bwd(dS, D_ind, V, W, lens, Na, Ns, Nb, Ne, True, ws)
+        loss, dS, _ = ops.loss_fwd_bwd(S_max, D_ind, V, lens_t, Na, Ns, Nb, Ne, 10.0, 4.13, True, workspace=ws)
+        return ops.sim_bwd(dS, D_ind, V, W, lens_t, Na, Ns, Nb, Ne, True, ws)
 
     def timeit(fn):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(iters):
+                    fn()
+            g.replay()
+            st.synchronize()
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                g.replay()
+                e1.record(st)
+                st.synchronize()
+                t = e0.elapsed_time(e1) / iters
+                best = t if best is None or t < best else best
+        return best
 
     t_f, t_fb = timeit(fwd), timeit(full)
     by_f = 4.0 * D * (R + Q) + 12.0 * F * Q                       # SURVEY 8d: forward algorithmic bytes
     by_fb = by_f + 4.0 * D * (R + Q) + 4.0 * D * F * Q            # + dense dV, dW and the arg-max row re-reads
-    return {"R": R, "Q": Q, "pairs": R * Q,
-            "fwd_ms": round(t_f, 4), "fwd_pairs_per_s": round(R * Q / (t_f * 1e-3), 1),
+    fl = 2.0 * R * Q * D
+    return {"R": R, "Q": Q, "pairs": R * Q, "live_query_columns": live, "timing": "hipGraph of %d back-to-back passes, best of 3" % iters,
+            "fwd_ms": round(t_f, 5), "fwd_pairs_per_s": round(R * Q / (t_f * 1e-3), 1),
+            "fwd_algorithmic_bytes": by_f, "fwd_GBps": round(by_f / (t_f * 1e-3) / 1e9, 1),
             "fwd_hbm_frac": round(by_f / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "fwd_fp32_mfma_frac": round(2.0 * R * Q * D / (t_f * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "fwd_bwd_ms": round(t_fb, 4), "fwd_bwd_pairs_per_s": round(R * Q / (t_fb * 1e-3), 1),
+            "fwd_dense_flops_frac_of_fp32_mfma": round(fl / (t_f * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "fwd_dense_flops_frac_of_bf16_mfma": round(fl / (t_f * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "fwd_live_bf16x3_mfma_frac": round(3.0 * 2.0 * R * live * D / (t_f * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "fwd_bwd_ms": round(t_fb, 5), "fwd_bwd_pairs_per_s": round(R * Q / (t_fb * 1e-3), 1),
             "fwd_bwd_hbm_frac": round(by_fb / (t_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="run detector and tail of a step back to back on one stream (default: the frozen detector of step "
-                         "k+1 overlaps the embedding/loss/backward/optimiser tail of step k on a second HIP stream)")
-    ap.add_argument("--no-other-precisions", action="store_true",
-                    help="skip the short extra runs in the other two arithmetic modes (N = 1 only)")
-    ap.add_argument("--dp-mode", default="replica", choices=["replica", "exact"],
-                    help="N > 1: 'replica' = per-GPU minibatch of whole segments, local loss, averaged gradients (default, "
-                         "BASELINE.json's DP); 'exact' = ONE global batch of N x the segments, frames sharded over the GPUs, "
-                         "S_max all-gathered, summed partial gradients (equals a 1-GPU step on the global batch)")
-    ap.add_argument("--precision", default=os.environ.get("NAFAE_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
-                    help="arithmetic of the detector contractions: exact fp32 MFMA | split-bf16 (fp32-accurate to ~1e-5) | bf16")
-    a = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-GPU run.  Never touches the GPU: torch.cuda.device_count() does not initialise it."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to time fewer ranks than asked\n"
+                         % (n, have))
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(a):
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: timing the %d rank(s) that exist\n" % (a.gpus, world, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     distributed = world > 1
@@ -174,7 +273,8 @@ def main():
     from nafae_amd.model import default_args
     from nafae_amd.train import PipelinedTrainer, make_batch, setup_training, shard_frames, train_step, train_step_exact
 
-    Na, Ns, Nb, Ne = WORKLOADS[a.workload]
+    workload = a.workload or ("c2" if world == 1 else "c4")
+    Na, Ns, Nb, Ne = WORKLOADS[workload]
     reset_cfg()
     cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
     cfg.TEST.RPN_POST_NMS_TOP_N = Nb
@@ -182,129 +282,160 @@ def main():
     Na_model = Na * world if exact else Na          # exact mode: ONE batch of world*Na segments, every rank sees all queries
     args = default_args(batch_size=Na_model, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
     model, opt, crit, reducer = setup_training(args, device=dev, seed=1234, distributed=distributed)
-    model.fasterRCNN.precision = a.precision
     if exact:
-        if args.dropout_rate:
-            torch.manual_seed(1234)                 # word-side dropout masks must agree across ranks
         batch = shard_frames(make_batch(Na_model, Ns, Ne, seed=1234, device=dev), rank, world)
     else:
         batch = make_batch(Na, Ns, Ne, seed=1234 + rank, device=dev)
+    F = Na * Ns
+    R, Q = F * Nb, Na * Ne
 
     def sync():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe = None if (a.no_pipeline or exact) else PipelinedTrainer(model, opt, crit, args, reducer)
+    def time_mode(prec, steps, warmup):
+        """warmup untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks."""
+        model.fasterRCNN.precision = prec
+        pipe = None if (a.no_pipeline or exact) else PipelinedTrainer(model, opt, crit, args, reducer)
 
-    def run_steps(n):
-        """exactly n detector forwards and n tails; everything is enqueued inside the caller's timed region"""
-        if exact:
-            for _ in range(n):
-                loss, _, _, _ = train_step_exact(model, opt, crit, batch, args, reducer)
+        def run_steps(n):
+            if exact:
+                for _ in range(n):
+                    loss, _, _, _ = train_step_exact(model, opt, crit, batch, args, reducer)
+                return loss
+            if pipe is None:
+                for _ in range(n):
+                    loss, _, _, _ = train_step(model, opt, crit, batch, args, reducer)
+                return loss
+            pipe.submit(batch)
+            for i in range(n):
+                loss, _, _, _ = pipe.step(batch if i + 1 < n else None)
             return loss
-        if pipe is None:
-            for _ in range(n):
-                loss, _, _, _ = train_step(model, opt, crit, batch, args, reducer)
-            return loss
-        pipe.submit(batch)
-        for i in range(n):
-            loss, _, _, _ = pipe.step(batch if i + 1 < n else None)
-        return loss
 
-    if a.warmup:
-        run_steps(a.warmup)
-    sync()
-    ops.profile_reset(enable=True)
-    t0 = time.perf_counter()
-    loss = run_steps(a.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    prof = ops.profile_summary()
-    ops.profile_reset(enable=False)
-    if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        F = Na * Ns
-        R, Q = F * Nb, Na * Ne
-        frames_per_s = world * F * a.steps / dt
-        out = {
-            "metric": "frames/sec + region-query-pairs/sec through sim+loss",
-            "value": round(frames_per_s, 2), "unit": "frames/s",
-            # replica DP: every rank pairs its own R regions with its own Q queries; exact mode: one global R x Q problem
-            "pairs_per_s": round(world * R * Q * (world if exact else 1) * a.steps / dt, 1),
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": "%s: %d frames 224x224 per GPU (Na=%d,Ns=%d), %d proposals/frame, %d query slots/segment, "
-                                   "VGG16 random-init, full train step" % (a.workload.upper(), F, Na, Ns, Nb, Ne),
-                       "frames_per_gpu": F, "proposals_per_frame": Nb, "queries_per_segment": Ne,
-                       "parallelism": ("dp%d" % world) + ("-exact-global-batch" if exact else ""), "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
-                       "step_pipeline": "detector(k+1) overlaps tail(k) on a second stream" if pipe else "sequential"},
-            "loss": round(float(loss), 5),
-        }
-        # dominant kernel: fc6 = [R,25088] x [4096,25088]^T on fp32 MFMA
+        if warmup:
+            run_steps(warmup)
+        sync()
+        ops.profile_reset(enable=True)
+        t0 = time.perf_counter()
+        loss = run_steps(steps)
+        sync()
+        dt = time.perf_counter() - t0
+        prof = ops.profile_summary()
+        ops.profile_reset(enable=False)
+        if distributed:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res = {"dtype": prec, "value": round(world * F * steps / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(1e3 * dt / steps, 3),
+               "pairs_per_s": round(world * R * Q * (world if exact else 1) * steps / dt, 1),
+               "step_pipeline": "detector(k+1) overlaps tail(k) on a second stream" if pipe else "sequential",
+               "loss": round(float(loss), 5)}
+        nprod, peak, kname, opb, pmc_key = MODE_INFO[prec]
         fc6 = prof.get("fc6")
         if fc6:
-            fl = 2.0 * R * 25088 * 4096
-            # MFMA flops actually issued per algorithmic flop, and the dense peak of the pipe they run on
-            nprod, peak, kname = {"f32": (1, FP32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel<128,128,2,2> (fc6, fp32 MFMA)"),
-                                  "bf16x3": (3, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,split,gemm,2> (fc6, 3 bf16 MFMAs per product)"),
-                                  "bf16": (1, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,plain,gemm,3> (fc6, bf16 MFMA)")}[a.precision]
-            ach = nprod * fl / (fc6["avg_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),
-                               "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "algorithmic_tflops": round(fl / (fc6["avg_ms"] * 1e-3) / 1e12, 2),
-                               "traffic": (pmc_traffic({"f32": "gemm_nt_fc6", "bf16x3": "gemm_bf16x3_fc6_256x256_il",
-                                                        "bf16": "gemm_bf16_plain_fc6_256x256"}.get(a.precision, ""))
-                                           if a.workload == "c2" else None),
-                               "algorithmic": (2.0 if a.precision == "bf16" else 4.0) * (R * 25088 + 4096 * 25088 + R * 4096),
-                               "avg_ms": round(fc6["avg_ms"], 4), "launches": fc6["n"]}
-        sim = prof.get("sim_max")
-        if sim:
-            by = 4.0 * 512 * (R + Q) + 12.0 * F * Q
-            ach = by / (sim["avg_ms"] * 1e-3) / 1e9
-            out["roofline_sim"] = {"kernel": "sim_max_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                   "traffic": pmc_traffic("sim_max") if a.workload == "c2" else None,
-                                   "avg_ms": round(sim["avg_ms"], 4),
-                                   "mfma_frac": round(2.0 * R * Q * 512 / (sim["avg_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
-        out["stage_ms"] = {k: round(v["avg_ms"], 4) for k, v in sorted(prof.items())}
+            fl = 2.0 * R * 25088 * 4096                         # algorithmic flops of one fc6 launch
+            alg = fl / (fc6["avg_ms"] * 1e-3) / 1e12
+            traffic, src = pmc_traffic(pmc_key) if workload == "c2" else (None, None)
+            res["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(alg / peak, 4), "mfma_issue_util": round(nprod * alg / peak, 4),
+                               "mfmas_per_product": nprod, "avg_ms": round(fc6["avg_ms"], 4), "launches": fc6["n"],
+                               "algorithmic_flops": fl, "algorithmic_bytes": opb * (R * 25088 + 4096 * 25088 + R * 4096),
+                               "traffic": traffic,
+                               "traffic_source": ("static: %s (separate --pmc passes on scripts/kernels*_only.py at this shape, "
+                                                  "FETCH_SIZE x2; not read in this run)" % src) if traffic else None}
+        res["stage_ms"] = {k: round(v["avg_ms"], 4) for k, v in sorted(prof.items())}
         det_ms = sum(v["avg_ms"] for k, v in prof.items() if k in ("base", "rpn", "roi_align", "fc6", "fc7"))
         if det_ms > 0:
-            out["detector_algorithmic_tflops"] = round(F * flops_per_frame(Nb) / (det_ms * 1e-3) / 1e12, 2)
-            out["detector_fp32_mfma_frac"] = round(F * flops_per_frame(Nb) / (det_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+            alg = F * flops_per_frame(Nb) / (det_ms * 1e-3) / 1e12
+            res["detector"] = {"algorithmic_tflops": round(alg, 2), "mfma_frac": round(alg / peak, 4),
+                               "mfma_issue_util": round(nprod * alg / peak, 4), "sum_of_stage_ms": round(det_ms, 3),
+                               "note": "stages timed with HIP events on the detector stream; under the step pipeline they "
+                                       "include contention with the overlapped tail"}
+        return res
+
+    head_prec = a.precision or "f32"
+    head = time_mode(head_prec, a.steps, a.warmup)
+    siblings = {}
+    if not a.no_other_precisions and not exact:
+        for prec in (("f32", "bf16x3", "bf16") if world == 1 else ("f32", "bf16x3")):
+            if prec != head_prec:
+                siblings[prec] = time_mode(prec, a.steps, max(a.warmup, 2))
+        model.fasterRCNN.precision = head_prec
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec + region-query-pairs/sec through sim+loss",
+            "value": head["value"], "unit": "frames/s", "pairs_per_s": head["pairs_per_s"],
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head_prec, "data": "synthetic",
+            "config": {"workload": "%s: %d frames 224x224 per GPU (Na=%d,Ns=%d), %d proposals/frame, %d query slots/segment, "
+                                   "VGG16 random-init, full train step" % (workload.upper(), F, Na, Ns, Nb, Ne),
+                       "frames_per_gpu": F, "proposals_per_frame": Nb, "queries_per_segment": Ne,
+                       "parallelism": ("dp%d" % world) + ("-exact-global-batch" if exact else ""),
+                       "rccl_world_size": world if distributed else 1,
+                       "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
+                       "step_pipeline": head["step_pipeline"]},
+            "loss": head["loss"],
+        }
+        for k in ("roofline", "stage_ms", "detector"):
+            if k in head:
+                out[k] = head[k]
+        if siblings:
+            out["modes"] = siblings
         if world == 1:
-            out["sim_loss_only"] = sim_loss_only(Na, Ns, Nb, Ne, dev)
-        if world == 1 and not a.no_other_precisions:
-            # the same step in the other arithmetic modes, a few steps each (reported, never the headline)
-            other = {}
-            for prec in ("f32", "bf16x3", "bf16"):
-                if prec == a.precision:
-                    continue
-                model.fasterRCNN.precision = prec
-                for _ in range(2):
-                    train_step(model, opt, crit, batch, args, reducer)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                n_o = max(3, min(a.steps, 5))
-                for _ in range(n_o):
-                    train_step(model, opt, crit, batch, args, reducer)
-                torch.cuda.synchronize()
-                d_o = (time.perf_counter() - t1) / n_o
-                other[prec] = {"frames_per_s": round(F / d_o, 2), "ms_per_step": round(1e3 * d_o, 3), "steps": n_o}
-            model.fasterRCNN.precision = a.precision
-            out["other_precisions"] = other
+            # the similarity kernel alone at this workload's shape, and at C5 (SURVEY 8d: the HBM-roofline configuration)
+            so = sim_loss_only(Na, Ns, Nb, Ne, dev)
+            out["roofline_sim"] = {"kernel": "sim_max (stand-alone, this workload's shape and entity-length histogram)",
+                                   "bound": "hbm", "achieved": so["fwd_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": so["fwd_hbm_frac"], "avg_ms": so["fwd_ms"], "algorithmic_bytes": so["fwd_algorithmic_bytes"],
+                                   "traffic": None, "in_step_avg_ms": head.get("stage_ms", {}).get("sim_max")}
+            out["sim_loss_only"] = so
+            c5 = WORKLOADS["c5"]
+            out["sim_loss_c5"] = {
+                "histogram_lengths": sim_loss_only(*c5, dev),
+                "all_slots_live": sim_loss_only(*c5, dev, lens=[c5[3]] * c5[0]),
+                "note": "C5 per-GPU shape R=19200 x Q=512, clustering on.  'histogram_lengths' draws the entity counts from the "
+                        "YouCookII train-split histogram like every other workload (most of the Ne=64 slots are padding, whose "
+                        "S_ columns are 0 by definition, model.py:551); 'all_slots_live' is the dense worst case."}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(Na, Ns, Nb, Ne)
+                out["cpu_baseline"] = cpu_baseline()
             except Exception as e:      # the baseline is reporting, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
+        sys.stdout.flush()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 on one GPU, c4 (BASELINE's 8-GPU data-parallel config, per GPU) on several")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run detector and tail of a step back to back on one stream (default: the frozen detector of step "
+                         "k+1 overlaps the embedding/loss/backward/optimiser tail of step k on a second HIP stream)")
+    ap.add_argument("--no-other-precisions", action="store_true", help="time the headline arithmetic mode only")
+    ap.add_argument("--dp-mode", default="replica", choices=["replica", "exact"],
+                    help="N > 1: 'replica' = per-GPU minibatch of whole segments, local loss, averaged gradients (default, "
+                         "BASELINE.json's DP); 'exact' = ONE global batch of N x the segments, frames sharded over the GPUs, "
+                         "S_max all-gathered, summed partial gradients (equals a 1-GPU step on the global batch)")
+    ap.add_argument("--precision", default=os.environ.get("NAFAE_PRECISION"), choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the HEADLINE run (default f32, what BASELINE config C2 names): exact fp32 MFMA | "
+                         "split-bf16 (fp32-accurate to ~1e-5) | bf16.  The other modes are reported under `modes`.")
+    a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    run_rank(a)
 
 
 if __name__ == "__main__":

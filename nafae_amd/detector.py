@@ -95,6 +95,12 @@ class _fasterRCNN(nn.Module):
         ps = list(self.parameters())
         return (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
 
+    def invalidate_packed(self):
+        """Drop the kernel-layout copies of the weights.  `_pack_key` sees load_state_dict / .to() / in-place ops on the
+        parameters, but NOT writes through `.data` (`p.data.copy_()`, `p.data.normal_()`), which do not bump the version
+        counter: call this after such a write (parallel.broadcast_parameters does)."""
+        self._packed, self._packed_key = None, None
+
     def _pack(self):
         key = self._pack_key()
         if self._packed is not None and key == self._packed_key:

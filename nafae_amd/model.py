@@ -89,9 +89,10 @@ def default_args(**over):
 
 
 # ---------------------------------------------------------------------------------------------------- autograd glue
-def _drop_mask(shape, p, device):
-    """Bernoulli keep mask for nn.Dropout(p) in train mode (random numbers are plumbing, like the allocator)."""
-    return (torch.rand(shape, device=device) >= p).to(torch.uint8)
+def _drop_mask(shape, p, device, generator=None):
+    """Bernoulli keep mask for nn.Dropout(p) in train mode (random numbers are plumbing, like the allocator).
+    `generator`: draw from this torch.Generator instead of the device's default one (shared-seed masks, exact DP mode)."""
+    return (torch.rand(shape, device=device, generator=generator) >= p).to(torch.uint8)
 
 
 class _VisEbdFn(torch.autograd.Function):
@@ -264,12 +265,13 @@ class WordEbd(nn.Module):
         self.fc1 = nn.Linear(args.glove_dim, args.word_ebd_dim)
         self.drop = nn.Dropout(p=args.dropout_rate)
         self.bn = nn.BatchNorm1d(args.word_ebd_dim)
+        self.mask_generator = None      # set by train_step_exact: replicated WordEbd must draw the same mask on every rank
 
     def forward(self, feats):
         p = self.drop.p
         mask, scale = (None, 1.0)
         if self.training and p > 0:
-            mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device), 1.0 / (1.0 - p)
+            mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device, self.mask_generator), 1.0 / (1.0 - p)
         if self.training:
             self.bn.num_batches_tracked += 1
         return _WordEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, self.bn.weight, self.bn.bias,

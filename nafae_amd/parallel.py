@@ -33,13 +33,33 @@ class GradAllReducer:
             o += p.numel()
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
+    def bind(self):
+        """Make sure every parameter's .grad still IS its slice of the flat buffer.  `optimizer.zero_grad()` /
+        `model.zero_grad()` of torch >= 2 set grads to None, after which backward allocates fresh tensors and an all-reduce or
+        optimiser step over the flat buffer would silently run on zeros.  A detached gradient is copied into its slice and
+        re-bound; a missing one (None) is re-bound to its (zeroed) slice.  Host-side pointer compares only."""
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            view = self.flat[o:o + k].view_as(p)
+            g = p.grad
+            if g is None:
+                view.zero_()
+                p.grad = view
+            elif g.data_ptr() != view.data_ptr() or g.dtype != torch.float32 or not g.is_contiguous():
+                view.copy_(g)
+                p.grad = view
+            o += k
+
     def zero_grad(self):
+        self.bind()
         self.flat.zero_()
 
     def allreduce(self, average=True):
         """Sum the flat gradient buffer over ranks; `average` divides by the world size afterwards (replicated-model DP
         with per-rank minibatches).  average=False is the frame-sharded exact mode, where every rank holds a PARTIAL
         gradient of one global loss."""
+        self.bind()
         if self.world > 1:
             _all_reduce_sum(self.flat, self.group)
             if average:
@@ -163,8 +183,12 @@ def broadcast_parameters(model, src=0, group=None):
     """Make every rank start from rank `src`'s weights and BatchNorm statistics."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t, src=src, group=group)      # in place on the tensor itself: bumps its version counter
+    det = getattr(model, "fasterRCNN", None)
+    if det is not None and hasattr(det, "invalidate_packed"):
+        det.invalidate_packed()                          # kernel-layout weight copies are rebuilt from the new values
 
 
 class FusedClipAdam:
@@ -199,7 +223,44 @@ class FusedClipAdam:
     def zero_grad(self):
         self.reducer.zero_grad()
 
+    def state_dict(self):
+        """torch.optim.Adam-shaped state ('state' keyed by parameter index over the reducer's parameter list, 'param_groups'),
+        so that the 'optimizer' entry of a vis_ground_*.pth checkpoint (model.py:1118-1124) round-trips."""
+        state, o = {}, 0
+        for i, p in enumerate(self.reducer.params):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[o:o + k].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view_as(p).clone()}
+            o += k
+        return {"state": state,
+                "param_groups": [{"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps,
+                                  "weight_decay": self.weight_decay, "max_norm": self.max_norm,
+                                  "params": list(range(len(self.reducer.params)))}]}
+
+    def load_state_dict(self, sd):
+        state = sd.get("state", {})
+        o = 0
+        with torch.no_grad():
+            for i, p in enumerate(self.reducer.params):
+                k = p.numel()
+                st = state.get(i, state.get(str(i)))
+                if st is not None:
+                    self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    self.step_count = int(float(st["step"]))
+                o += k
+        groups = sd.get("param_groups") or []
+        if groups:
+            g = groups[0]
+            self.param_groups[0]["lr"] = g.get("lr", self.param_groups[0]["lr"])
+            self.betas = tuple(g.get("betas", self.betas))
+            self.eps = g.get("eps", self.eps)
+            self.weight_decay = g.get("weight_decay", self.weight_decay)
+            self.max_norm = g.get("max_norm", self.max_norm)
+
     def step(self):
+        self.reducer.bind()
         self.step_count += 1
         self._ops.adam_step(self.flat_params, self.reducer.flat, self.exp_avg, self.exp_avg_sq, self.param_groups[0]["lr"],
                             self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm, self.step_count,

@@ -95,11 +95,23 @@ def make_optimizer(model, args):
     return torch.optim.Adam(params, lr=args.lr, weight_decay=args.weight_decay)
 
 
+def detector_forward(model, batch):
+    """The frozen detector as train() calls it (model.py:706-707), minus the fp32 `pooled_feat` that the training loop never
+    reads: 822 MB of HBM writes per 64 frames x 128 proposals in the bf16 modes (the kernels write fc6's operand planes either
+    way).  API-parity callers of `model.fasterRCNN(...)` still get it.  Returns (rois, roi_scores, None-or-pooled, fc7)."""
+    det = model.fasterRCNN
+    keep = det.materialize_pooled
+    det.materialize_pooled = False
+    try:
+        with torch.no_grad():
+            return det(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+    finally:
+        det.materialize_pooled = keep
+
+
 def train_step(model, optimizer, criterion, batch, args, reducer=None):
     """One iteration of model.py:684-775.  Returns the (device) loss; no host synchronisation inside."""
-    with torch.no_grad():
-        rois, roi_scores, roi_feats, fc_feats = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes,
-                                                                 batch.num_boxes)
+    rois, roi_scores, roi_feats, fc_feats = detector_forward(model, batch)
     vis_feats = model.vis_ebd(fc_feats)
     word_feats = model.word_ebd(batch.glove_feats)
     if reducer is not None:
@@ -133,12 +145,27 @@ def train_step_exact(model, optimizer, criterion, local_batch, args, reducer, gr
     """One training step on a GLOBAL batch whose frames are sharded over the ranks (exact mode): the
     result equals a single-GPU train_step on the whole batch (same loss; gradients equal up to fp32 summation order),
     unlike the default replicated-minibatch DP whose loss couples only the segments of one rank.  `local_batch` =
-    shard_frames(global_batch, rank, world).  Dropout must be off or seeded identically for the word side."""
-    with torch.no_grad():
-        rois, roi_scores, roi_feats, fc_feats = model.fasterRCNN(local_batch.im_data, local_batch.im_info,
-                                                                 local_batch.gt_boxes, local_batch.num_boxes)
+    shard_frames(global_batch, rank, world).
+
+    Dropout: WordEbd is REPLICATED, so every rank must draw the identical word-side mask or the gathered S_max columns
+    come from different word embeddings and the summed gradient is the gradient of no single loss (replicas would stay in
+    sync, so the error would be silent).  The mask is therefore drawn from a dedicated generator re-seeded on every rank
+    from the shared (exact_seed, step counter); the visual-side masks cover disjoint rows and stay per-rank."""
+    rois, roi_scores, roi_feats, fc_feats = detector_forward(model, local_batch)
     vis_feats = model.vis_ebd(fc_feats)                       # this rank's rows only
-    word_feats = model.word_ebd(local_batch.glove_feats)      # replicated: BatchNorm sees all Q rows on every rank
+    we = model.word_ebd
+    if we.training and we.drop.p > 0:
+        step = getattr(model, "_exact_step", 0)
+        model._exact_step = step + 1
+        gen = getattr(we, "_shared_gen", None)
+        if gen is None or gen.device != local_batch.glove_feats.device:
+            gen = we._shared_gen = torch.Generator(device=local_batch.glove_feats.device)
+        gen.manual_seed((int(getattr(args, "exact_seed", 20191234)) * 1000003 + step) & 0x7FFFFFFFFFFF)
+        we.mask_generator = gen
+    try:
+        word_feats = we(local_batch.glove_feats)              # replicated: BatchNorm sees all Q rows on every rank
+    finally:
+        we.mask_generator = None
     reducer.zero_grad()
     D, D_sim, margin_loss = dvsa_frame_sharded(model.DVSA, vis_feats, word_feats, local_batch.entities_length, group)
     loss = criterion(margin_loss, torch.zeros_like(margin_loss))
@@ -168,9 +195,7 @@ class PipelinedTrainer:
         main = torch.cuda.current_stream()
         self.det_stream.wait_stream(main)          # inputs (and any weight re-packing) issued so far are visible
         with torch.cuda.stream(self.det_stream):
-            with torch.no_grad():
-                rois, roi_scores, roi_feats, fc_feats = self.model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes,
-                                                                              batch.num_boxes)
+            rois, roi_scores, roi_feats, fc_feats = detector_forward(self.model, batch)
             ev = torch.cuda.Event()
             ev.record(self.det_stream)
         self.pending = (batch, rois, fc_feats, ev)

@@ -1,0 +1,106 @@
+"""Generates tests/golden/config_c2.npz: the CPU ORACLE (oracle/, itself pinned to the imported reference by the
+fixtures of make_golden.py) run once, in the build container, on BASELINE config C2 AT SIZE -- 64 frames 224x224
+(Na=8, Ns=8), 128 proposals/frame, 16 query slots -- because ~3 s/frame of CPU time is too slow to repeat inside a test.
+
+    python tests/golden/make_config_golden.py            (about 5 minutes on 8 cores)
+
+Weights and inputs are the seeded synthetic ones of nafae_amd.synthetic / nafae_amd.train.build_model (seed 1234), which a
+test regenerates bit-identically on any machine running the same torch build; only output arrays are stored:
+
+  detector  rois / roi_scores / n_keep for all 64 frames, base_feat of frames 0 and 63, 64 sampled fc7 rows
+  grounding V rows (sample) and all of W, D_ind / D_sim / loss of the oracle DVSA in train mode (dropout 0) on the oracle's
+            own features, the oracle's top-2 gap per (frame, query) (a D_ind mismatch is legitimate only where this gap is
+            below the fp32 noise of 14 conv layers), parameter gradients (full for the small ones, sampled rows + norm for
+            vis_ebd.fc1.weight)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from nafae_amd import synthetic as syn  # noqa: E402
+from oracle import detector as OD  # noqa: E402
+from oracle import dvsa as O  # noqa: E402
+
+SEED = 1234
+Na, Ns, Nb, Ne = 8, 8, 128, 16
+DELTA, VIS_LAM = 10.0, 4.13
+
+
+def embedding_params(seed=SEED, vis_fc_dim=4096, glove_dim=200, D=512):
+    """The trainable parameters exactly as nafae_amd.train.build_model seeds them (same generator, same draw order)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for name, shape in (("vis_ebd.fc1.weight", (D, vis_fc_dim)), ("vis_ebd.fc1.bias", (D,)),
+                        ("word_ebd.fc1.weight", (D, glove_dim)), ("word_ebd.fc1.bias", (D,))):
+        if len(shape) > 1:
+            p[name] = torch.randn(shape, generator=g) * (1.0 / shape[1]) ** 0.5
+        else:
+            p[name] = torch.randn(shape, generator=g) * 0.01
+    p["word_ebd.bn.weight"] = torch.ones(D)
+    p["word_ebd.bn.bias"] = torch.zeros(D)
+    return p
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    F = Na * Ns
+    sd = syn.detector_state(seed=SEED, heads=False)
+    im, im_info = syn.frames(F, 224, 224, seed=SEED)
+    lens = syn.entity_lengths(Na, Ne, seed=SEED)
+    glove = syn.glove(Na, Ne, lens, dim=200, seed=SEED)
+    ocfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
+                RPN_POST_NMS_TOP_N=Nb, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
+    t0 = time.time()
+    with torch.no_grad():
+        base = OD.vgg16_features(im, sd)
+        rp = {k[len('RCNN_rpn.'):]: v for k, v in sd.items() if k.startswith('RCNN_rpn.')}
+        prob, deltas = OD.rpn_head(base, rp)
+        s, props = OD.decode_proposals(prob, deltas, im_info, 16, ocfg['ANCHOR_SCALES'], ocfg['ANCHOR_RATIOS'])
+        order = OD.sort_desc(s)
+        rois, roi_scores, n_keep = OD.select_proposals(s, props, order, 6000, Nb, 0.7)
+        pooled = OD.roi_align_avg(base, rois.view(-1, 5), 7, 1.0 / 16.0)
+        fc7 = OD.head_to_tail(pooled, sd)
+    print("oracle detector: %.1f s" % (time.time() - t0))
+    del pooled
+    p = embedding_params()
+    leaves = {k: v.clone().requires_grad_() for k, v in p.items()}
+    V = O.vis_ebd(fc7, leaves["vis_ebd.fc1.weight"], leaves["vis_ebd.fc1.bias"])
+    W = O.word_ebd(glove, leaves["word_ebd.fc1.weight"], leaves["word_ebd.fc1.bias"], leaves["word_ebd.bn.weight"],
+                   leaves["word_ebd.bn.bias"], torch.zeros(512), torch.ones(512), training=True)
+    D_ind, D_sim, loss, parts = O.dvsa_forward(V, W, lens, Na, Nb, Ne, DELTA, VIS_LAM, 'train', return_parts=True)
+    loss.backward()
+    with torch.no_grad():
+        S3 = (V @ W.t()).view(F, Nb, Na * Ne)
+        top2 = S3.topk(2, dim=1)[0]
+        gap = (top2[:, 0] - top2[:, 1])                          # [F, Q]; masked columns are don't-care
+    fc7_rows = np.arange(0, F * Nb, 127)[:64]
+    v_rows = np.arange(0, F * Nb, 509)[:16]
+    gw = leaves["vis_ebd.fc1.weight"].grad
+    out = dict(
+        seed=np.int32(SEED), shape=np.array([Na, Ns, Nb, Ne]), lens=np.array(lens), Delta=np.float32(DELTA),
+        vis_lam=np.float32(VIS_LAM),
+        rois=rois.numpy(), roi_scores=roi_scores.numpy(), n_keep=np.array(n_keep, dtype=np.int32),
+        base_feat_f0=base[0].numpy(), base_feat_f63=base[F - 1].numpy(), base_absmax=np.float32(base.abs().max()),
+        fc7_rows=fc7_rows, fc7_sample=fc7[fc7_rows].numpy(), fc7_absmax=np.float32(fc7.abs().max()),
+        v_rows=v_rows, V_sample=V.detach()[v_rows].numpy(), W=W.detach().numpy(),
+        D_ind=D_ind.numpy(), D_sim=D_sim.detach().numpy(), loss=np.float32(loss.item()), top2_gap=gap.numpy(),
+        vis_loss=np.float32(parts['vis_loss'].item()), dem=np.int64(parts['dem']),
+        g_ve_w_rows=gw[:8].numpy(), g_ve_w_norm=np.float64(gw.double().norm()),
+        g_ve_b=leaves["vis_ebd.fc1.bias"].grad.numpy(), g_we_w=leaves["word_ebd.fc1.weight"].grad.numpy(),
+        g_we_b=leaves["word_ebd.fc1.bias"].grad.numpy(), g_bn_w=leaves["word_ebd.bn.weight"].grad.numpy(),
+        g_bn_b=leaves["word_ebd.bn.bias"].grad.numpy())
+    path = os.path.join(HERE, "config_c2.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s %.1f KB  (loss %.6f, kept %s..%s proposals/frame, total %.1f s)"
+          % (path, os.path.getsize(path) / 1024, loss.item(), min(n_keep), max(n_keep), time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

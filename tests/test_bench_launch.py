@@ -1,0 +1,48 @@
+"""bench.py's own multi-rank launcher: `python bench.py --gpus N` must start N ranks itself or refuse loudly -- never
+silently time fewer GPUs than it was asked for (the reference parses --mGPUs and ignores it, model.py:91-99)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=e,
+                          timeout=timeout)
+
+
+def test_gpus_flag_refuses_when_devices_missing_cpu():
+    """No GPU here: --gpus 2 must exit non-zero with a message and print no JSON line (the parent never touches a GPU)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("2+ GPUs visible")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_gpus_flag_refuses_on_one_gpu():
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "only 1 GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_share_one_gpu_is_not_attempted():
+    """With WORLD_SIZE preset (torchrun) but fewer devices than ranks, a rank must fail loudly, not fall back to device 0."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1",
+                                                                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert r.returncode != 0 and "LOCAL_RANK 1" in (r.stderr + r.stdout)
