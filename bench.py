@@ -89,11 +89,23 @@ def cpu_baseline():
     from oracle import detector as OD
     from oracle import dvsa as O
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     Na, Ns, Nb, Ne, lens = 2, 2, 32, 8, [3, 5]
     nf = Na * Ns
     sd = syn.detector_state(seed=1234, heads=False)
     im, im_info = syn.frames(nf, 224, 224, seed=1234)
+    # thread count: torch's CPU convolutions get SLOWER when a many-core host is oversubscribed (256 threads on the GPU box:
+    # 2.1 s/frame against 0.5 s/frame on 8 cores), so pick the fastest of a few counts on one frame and report it as `cores`
+    best_t, threads = None, cores
+    for n in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            OD.vgg16_features(im[:1], sd)
+            t0 = time.perf_counter()
+            OD.vgg16_features(im[:1], sd)
+            dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_t, threads = dt, n
+    torch.set_num_threads(threads)
     glove = syn.glove(Na, Ne, lens, dim=200, seed=1234)
     g = torch.Generator().manual_seed(1234)
     ve_w, ve_b = torch.randn(512, 4096, generator=g) / 64.0, torch.randn(512, generator=g) * 0.01
@@ -138,9 +150,9 @@ def cpu_baseline():
         L.backward()
         ts.append(time.perf_counter() - t0)
     t_sim = statistics.median(ts[1:])
-    return {"value": round(nf / med["total"], 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(nf / med["total"], 4), "unit": "frames/s", "cores": threads, "host_cores": cores, "kind": "port",
             "sample": "config C1 exactly: %d frames 224x224, %d proposals/frame, %d query slots, one forward + loss; 1 warm-up + %d "
-                      "timed runs, torch CPU fp32 + C NMS/ROI-Align, %d threads" % (nf, Nb, Ne, n_runs, cores),
+                      "timed runs, torch CPU fp32 + C NMS/ROI-Align, %d threads (fastest of 8/16/32/64/all on this host)" % (nf, Nb, Ne, n_runs, threads),
             "median_s": round(med["total"], 4), "min_s": round(mn["total"], 4), "frames_per_s_best": round(nf / mn["total"], 4),
             "stages_median_ms": {k: round(1e3 * v, 2) for k, v in med.items() if k != "total"},
             "stages_min_ms": {k: round(1e3 * v, 2) for k, v in mn.items() if k != "total"},
@@ -166,7 +178,7 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20):
     ws = ops.loss_workspace(Na, Ns, Nb, Ne, D, V.device)
 
     def fwd():
-        return ops.sim_max_fwd(V, W, lens_t, Na, Ns, Nb, Ne)
+        return ops.sim_max_fwd(V, W, lens_t, Na, Ns, Nb, Ne, lens=lens)
 
     def full():
         S_max, D_ind = fwd()

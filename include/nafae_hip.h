@@ -213,9 +213,27 @@ int nafae_roi_align_avg_nhwc_to_planes(const float *feat, int F, int H, int W, i
 /* S_ = V W^T with masked query slots, reduced on the fly to per-frame max / arg-max over the Nb proposals
  * (model.py:548-551, 580-583, 610-612); S_ is never written to HBM.
  * V [Na*Ns*Nb, D], W [Na*Ne, D], ent_len int32 [Na].
- * S_max f32 [F, Q], D_ind int64 [F, Q] (F = Na*Ns, Q = Na*Ne).  D % 4 == 0.  */
+ * S_max f32 [F, Q], D_ind int64 [F, Q] (F = Na*Ns, Q = Na*Ne).  D % 4 == 0.
+ * This entry point is the exact-fp32 variant (fp32 MFMA = a k-ordered fp32 FMA chain over all Q columns); it needs no
+ * workspace and takes any D % 4 == 0.  */
 int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, int Na, int Ns, int Nb, int Ne,
                       int D, float *S_max, int64_t *D_ind, void *stream);
+
+/* The production form of the call above (the host mirror uses this one), in terms of the F whole frames a caller holds
+ * (F = Na*Ns on one GPU; a rank's share in the frame-sharded multi-GPU mode, where Na stays the GLOBAL segment count):
+ *   - contracts V only against the LIVE query slots (e < ent_len[a]); masked slots are written as (0, 0);
+ *   - bf16x3 arithmetic on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate) with a top-2 per 32-row block;
+ *     wherever a runner-up lies within 2^-15*D + 2^-11*|score| of the winner, the candidates are re-evaluated with exact
+ *     fp32 FMA dot products, so D_ind is decided in fp32 where bf16x3 cannot separate them (precondition for the bound:
+ *     |V|, |W| <= 1, which tanh outputs satisfy; model.py:628,642);
+ *   - max_live_cols: an UPPER BOUND on the number of live slots, sum_a min(max(ent_len[a],0),Ne), if the host knows it
+ *     (it sizes the launch; a bound that is too small loses columns), or -1 = unknown (sized for all Na*Ne);
+ *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes, no initialisation needed.
+ * Shapes it does not take (D % 32 != 0, D > 1024, Na > 2048) run the exact-fp32 kernel of nafae_sim_max_fwd_frames.  */
+int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D);
+int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
+                         int max_live_cols, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
+                         void *stream);
 
 /* Bytes of workspace nafae_loss_fwd_bwd needs.  */
 int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D);

@@ -48,6 +48,8 @@ SIGNATURES = {
     "nafae_roi_align_avg_nhwc_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, c_float, P, P, P, P]),
     "nafae_roi_align_avg_nhwc_to_planes": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, P, P, P, P]),
     "nafae_sim_max_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "nafae_sim_max_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "nafae_sim_max_fwd_ws": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P]),
     "nafae_loss_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "nafae_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, P, P, P]),
     "nafae_sim_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),

@@ -1,0 +1,50 @@
+// hip_util.h -- host-side helpers shared by the translation units of libnafae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "../../include/nafae_hip.h"
+
+namespace nafae {
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// launch failures (bad configuration, missing code object, wrong runtime) must be loud, never silent
+inline int launch_status() { return hipGetLastError() == hipSuccess ? NAFAE_OK : NAFAE_ELAUNCH; }
+
+// Raise a kernel's dynamic-LDS limit above the 64 KB default, once per (device, kernel).  hipFuncSetAttribute is a
+// per-device property of the loaded code object, so a process that drives several GPUs (or several host threads) must
+// neither skip it on the second device nor race on a plain `static bool`.
+inline int allow_dynamic_lds(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, int> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NAFAE_ELAUNCH;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, kernel);
+  auto it = done.find(key);
+  if (it != done.end() && it->second >= bytes) return NAFAE_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return NAFAE_ELAUNCH;
+  }
+  done[key] = bytes;
+  return NAFAE_OK;
+}
+
+// Tuning / A-B switches.  A production build (default) has NO environment dependence: every switch returns its default
+// and the C ABI is a pure function of its arguments.  Building with -DNAFAE_EXPERIMENTS (python -m nafae_amd.build
+// --experiments) turns the NAFAE_* environment variables used by scripts/ back on.
+inline const char *experiment_env(const char *name) {
+#ifdef NAFAE_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
+}  // namespace nafae

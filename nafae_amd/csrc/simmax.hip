@@ -1,0 +1,475 @@
+// simmax.hip -- region x query similarity reduced to per-frame max / arg-max (DVSA.forward, reference
+// model.py:548-551, 580-583, 610-612), second generation, gfx950.
+//
+// What changed against sim_max_kernel (simloss.hip, kept as the exact-fp32 variant and as the fallback for odd shapes):
+//
+//   * LIVE COLUMNS ONLY.  The reference zero-fills every S_ column of a padded query slot (a, e >= len_a) after the
+//     product (model.py:551) -- with max_ent_len 13 and 2.07 entities per segment on average, ~85 % of the columns.
+//     The kernel builds the list of live columns from ent_len on the device and contracts V against those alone;
+//     masked slots are written as (0, 0) by the finish kernel.  Results are identical, the product shrinks.
+//   * V IS STREAMED ONCE, STRAIGHT INTO MFMA FRAGMENTS.  A wave owns 32 proposals of one frame.  Lane (r, h) of the
+//     v_mfma_f32_32x32x16_bf16 A operand needs 8 consecutive k of row r, i.e. 32 contiguous bytes of fp32 V: the wave
+//     loads them with global_load_dwordx4 directly (no LDS round trip, no barrier in the k-loop), four 128-B-line
+//     "chunks" (32 k each) in flight per wave, and splits them in registers into bf16 hi/lo.
+//   * W (live columns of one column group, all of K) is converted once per workgroup into LDS as bf16 hi/lo planes in
+//     fragment order: lane (c, h) reads its 16-B B fragment with one conflict-free ds_read_b128 per plane.
+//   * bf16x3 ARITHMETIC: hi*hi + hi*lo + lo*hi, fp32 accumulate -- 3 bf16 MFMAs instead of 16 MFMA-cycles of fp32.
+//     Every (frame, query) keeps the TOP-2 (value, index) per 32-row block; the finish kernel merges the blocks of a
+//     frame and, where the runner-up of ANY block is within `margin` of the winner, re-evaluates those candidates with
+//     exact fp32 FMA dot products and picks the larger (ties -> smaller index, torch.max's rule).  So D_ind is decided by
+//     fp32 arithmetic wherever bf16x3 could not separate the candidates, and S_max of such entries is the fp32 value.
+//     margin = 2^-15 * D + 2^-11 * |score|: twice the rigorous bf16x3 bound 2^-16 * sum|v||w| for |v|,|w| <= 1 (tanh
+//     outputs, model.py:628,642), plus a relative guard.
+//   * Parallelism follows the problem, not a fixed grid: 4 waves per workgroup = RBW row blocks x KS k-splits (K is split
+//     over waves when there are too few row blocks to fill the chip; the partial accumulators are summed through LDS in a
+//     fixed order); a workgroup walks RPW consecutive row groups so that W is converted once; workgroups of the same
+//     rows but different column groups are placed on the same XCD (blockIdx % 8) so that V comes out of that XCD's L2.
+//
+// Algorithmic bytes: 4*D*(R+Q) + 12*F*Q.  Everything here is deterministic (no atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hip_util.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+using namespace nafae;
+
+namespace {
+
+constexpr int NA_MAX = 2048;   // segments per batch the live-column prefix table holds (LDS)
+constexpr int NBUF = 4;        // 32-k chunks of V in flight per wave (4 x 4 KB)
+
+__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+// exclusive prefix of the clamped entity counts into LDS (prefix[Na] = number of live columns); wave 0 works, caller syncs
+__device__ __forceinline__ void build_prefix(const int32_t *__restrict__ ent_len, int Na, int Ne, int *prefix) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < Na; base += 64) {
+      const int a = base + lane;
+      int x = 0;
+      if (a < Na) {
+        const int l = ent_len[a];
+        x = l < 0 ? 0 : (l > Ne ? Ne : l);
+      }
+      int incl = x;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (a < Na) prefix[a] = carry + incl - x;
+      carry += __shfl(incl, 63);
+    }
+    if (lane == 0) prefix[Na] = carry;
+  }
+}
+
+// segment a with prefix[a] <= c < prefix[a+1]  (c < prefix[Na])
+__device__ __forceinline__ int find_seg(const int *prefix, int Na, int c) {
+  int lo = 0, hi = Na;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= c) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+    hi[e] = h0;
+    hi[4 + e] = h1;
+    lo[e] = (__bf16)(x0[e] - (float)h0);
+    lo[4 + e] = (__bf16)(x1[e] - (float)h1);
+  }
+}
+
+// partial result of one 32-row block for one live column: top-2 (value, proposal index), 16 bytes
+__device__ __forceinline__ f32x4 pack_part(float m1, int i1, float m2, int i2) {
+  f32x4 p = {m1, m2, __int_as_float(i1), __int_as_float(i2)};
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------- partial kernel
+// grid: ceil(NSG / 8) * 8 * G workgroups of 256 threads, NSG = number of row super-groups (RPW row groups each).
+// LDS: [W planes: D * NC * 4 B][qmap: NC ints][scratch: max((Na+1) ints, (4 - RBW) * NCB * 4 KB)]
+template <int NCB>
+__global__ __launch_bounds__(256) void sim_part_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
+                                                       const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
+                                                       int D, int nrb, int G, int KS, int RPW, int Qpad,
+                                                       f32x4 *__restrict__ part) {
+  constexpr int NC = 32 * NCB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *wl = smem;                                           // bf16 fragments of W
+  int *qmap = reinterpret_cast<int *>(smem + (size_t)D * NC * 4);
+  unsigned char *scr = smem + (size_t)D * NC * 4 + NC * 4;            // prefix table, later the k-split partials
+  int *prefix = reinterpret_cast<int *>(scr);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+  const int RBW = 4 / KS;
+  const int rbi = wave / KS, ks = wave - rbi * KS;
+  const int TRB = F * nrb;
+  const int NRG = (TRB + RBW - 1) / RBW;
+  const int NSG = (NRG + RPW - 1) / RPW;
+  const int blk8 = blockIdx.x >> 3;
+  const int sg = (blk8 / G) * 8 + (blockIdx.x & 7);
+  const int g = blk8 % G;
+  if (sg >= NSG) return;
+
+  const int nchunks = D >> 5;
+  const int cpw = nchunks / KS;          // 32-k chunks this wave contracts
+  const int c0 = ks * cpw;
+
+  // ---- this wave's rows for row group `rho`, and its V prefetch ring
+  f32x4 ring[NBUF][4];
+  const float *vrow = V;
+  auto set_rows = [&](int rho, bool &active, int &rb, int &b0) {
+    rb = rho * RBW + rbi;
+    active = rb < TRB;
+    const int rbc = active ? rb : TRB - 1;
+    const int f = rbc / nrb;
+    b0 = (rbc - f * nrb) * 32;
+    int row = b0 + lr;
+    row = row < Nb ? row : Nb - 1;
+    vrow = V + ((size_t)f * Nb + row) * D + (size_t)c0 * 32 + 8 * h;
+  };
+  auto load_chunk = [&](int j, int ci) {
+    const int cc = ci < cpw ? ci : cpw - 1;
+    const float *p = vrow + (size_t)cc * 32;
+    ring[j][0] = *reinterpret_cast<const f32x4 *>(p);
+    ring[j][1] = *reinterpret_cast<const f32x4 *>(p + 4);
+    ring[j][2] = *reinterpret_cast<const f32x4 *>(p + 16);
+    ring[j][3] = *reinterpret_cast<const f32x4 *>(p + 20);
+  };
+  bool active;
+  int rb, b0;
+  const int rho0 = sg * RPW;
+  set_rows(rho0, active, rb, b0);
+#pragma unroll
+  for (int j = 0; j < NBUF; j++) load_chunk(j, j);
+
+  // ---- live columns of this column group
+  build_prefix(ent_len, Na, Ne, prefix);
+  __syncthreads();
+  const int Ql = prefix[Na];
+  if (g * NC >= Ql) return;              // over-provisioned column group (the host only knows an upper bound)
+  if (tid < NC) {
+    const int c = g * NC + tid;
+    int q = -1;
+    if (c < Ql) {
+      const int a = find_seg(prefix, Na, c);
+      q = a * Ne + (c - prefix[a]);
+    }
+    qmap[tid] = q;
+  }
+  __syncthreads();
+  // ---- W -> bf16 hi/lo fragments in LDS: 16-B slot of (k-step s, half hh, plane, column cl) at (((s*2+hh)*2+plane)*NC+cl)*16
+  {
+    const int k4n = D >> 2;
+    for (int idx = tid; idx < NC * k4n; idx += 256) {
+      const int cl = idx / k4n, k4 = idx - cl * k4n;
+      const int q = qmap[cl];
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (q >= 0) w = *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + k4 * 4);
+      bf16x4 whi, wlo;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const __bf16 t = (__bf16)w[e];
+        whi[e] = t;
+        wlo[e] = (__bf16)(w[e] - (float)t);
+      }
+      const int k = k4 * 4;
+      const int s2h = k >> 3;            // = s*2 + hh
+      const int off = ((s2h * 2) * NC + cl) * 16 + (k & 4) * 2;
+      *reinterpret_cast<bf16x4 *>(wl + off) = whi;
+      *reinterpret_cast<bf16x4 *>(wl + off + NC * 16) = wlo;
+    }
+  }
+  __syncthreads();
+
+  const unsigned char *bbase = wl + (size_t)(h * 2 * NC + lr) * 16;   // + s*4*NC*16 + plane*NC*16 + cb*512
+  for (int rr = 0; rr < RPW; rr++) {
+    const int rho = rho0 + rr;
+    if (rho >= NRG) break;
+    if (rr > 0) {
+      set_rows(rho, active, rb, b0);
+#pragma unroll
+      for (int j = 0; j < NBUF; j++) load_chunk(j, j);
+    }
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+
+    for (int base = 0; base < cpw; base += NBUF) {
+#pragma unroll
+      for (int j = 0; j < NBUF; j++) {
+        const int ci = base + j;
+        if (ci < cpw && active) {
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            bf16x8 ahi, alo;
+            split8(ring[j][2 * t], ring[j][2 * t + 1], ahi, alo);
+            const unsigned char *bp = bbase + (size_t)((c0 + ci) * 2 + t) * (4 * NC * 16);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+              const bf16x8 bhi = *reinterpret_cast<const bf16x8 *>(bp + cb * 512);
+              const bf16x8 blo = *reinterpret_cast<const bf16x8 *>(bp + NC * 16 + cb * 512);
+              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[cb], 0, 0, 0);
+            }
+          }
+        }
+        load_chunk(j, ci + NBUF);
+      }
+    }
+
+    if (KS > 1) {          // sum the k-splits of a row block in a fixed order (ks = 1, 2, 3 onto ks = 0)
+      float *sc = reinterpret_cast<float *>(scr);
+      __syncthreads();     // (first trip: everyone is done with the prefix table that aliases the scratch)
+      if (ks > 0) {
+        float *dst = sc + (size_t)((rbi * (KS - 1) + (ks - 1)) * NCB) * 16 * 64 + lane;
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) dst[(cb * 16 + r) * 64] = acc[cb][r];
+      }
+      __syncthreads();
+      if (ks == 0) {
+        for (int k = 1; k < KS; k++) {
+          const float *src = sc + (size_t)((rbi * (KS - 1) + (k - 1)) * NCB) * 16 * 64 + lane;
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[cb][r] += src[(cb * 16 + r) * 64];
+        }
+      }
+    }
+
+    if (ks == 0 && active) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        float m1 = -INFINITY, m2 = -INFINITY;
+        int i1 = 0, i2 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {       // this lane's rows in ascending order
+          const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[cb][r];
+          if (row < Nb) {
+            if (v > m1) {
+              m2 = m1; i2 = i1; m1 = v; i1 = row;
+            } else if (v > m2) {
+              m2 = v; i2 = row;
+            }
+          }
+        }
+        // merge with the other half of the column (lane ^ 32), ordering (value desc, index asc)
+        const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+        const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
+        float n1, n2;
+        int k1, k2;
+        if (better(o1, j1, m1, i1)) {
+          n1 = o1; k1 = j1;
+          if (better(m1, i1, o2, j2)) { n2 = m1; k2 = i1; } else { n2 = o2; k2 = j2; }
+        } else {
+          n1 = m1; k1 = i1;
+          if (better(m2, i2, o1, j1)) { n2 = m2; k2 = i2; } else { n2 = o1; k2 = j1; }
+        }
+        const int c = g * NC + cb * 32 + lr;
+        if (h == 0 && c < Ql) part[(size_t)rb * Qpad + c] = pack_part(n1, k1, n2, k2);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- finish kernel
+// one thread per (frame, query slot); masked slots -> (0, 0); live slots merge the frame's row blocks and refine near-ties
+__global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict__ part, const float *__restrict__ V,
+                                                         const float *__restrict__ Wm, const int32_t *__restrict__ ent_len,
+                                                         int F, int Nb, int Na, int Ne, int D, int nrb, int Qpad,
+                                                         float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
+  __shared__ int prefix[NA_MAX + 1];
+  build_prefix(ent_len, Na, Ne, prefix);
+  __syncthreads();
+  const int Q = Na * Ne;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool in = idx < (long)F * Q;
+  const int lane = threadIdx.x & 63;
+  int f = 0, q = 0, c = 0;
+  bool live = false;
+  if (in) {
+    f = (int)(idx / Q);
+    q = (int)(idx - (long)f * Q);
+    const int a = q / Ne, e = q - a * Ne;
+    const int l = ent_len[a];
+    live = e < (l > Ne ? Ne : l);
+    c = prefix[a] + e;
+  }
+  float best = 0.f, margin = 0.f;
+  int bi = 0;
+  bool amb = false;
+  if (live) {
+    const f32x4 *p = part + (size_t)f * nrb * Qpad + c;
+    float bm = -INFINITY;
+    int bidx = 0;
+    for (int k = 0; k < nrb; k++) {
+      const f32x4 e = p[(size_t)k * Qpad];
+      const int i1 = __float_as_int(e[2]);
+      if (better(e[0], i1, bm, bidx)) {
+        bm = e[0];
+        bidx = i1;
+      }
+    }
+    margin = 3.0517578125e-05f * (float)D + 4.8828125e-04f * fabsf(bm);   // 2^-15 * D + 2^-11 * |score|
+    for (int k = 0; k < nrb; k++) {
+      const f32x4 e = p[(size_t)k * Qpad];
+      const int i1 = __float_as_int(e[2]), i2 = __float_as_int(e[3]);
+      if (i1 != bidx && bm - e[0] < margin) amb = true;
+      if (i2 != bidx && bm - e[1] < margin) amb = true;
+    }
+    best = bm;
+    bi = bidx;
+  }
+  // exact fp32 re-evaluation of every listed candidate within the margin (wave-cooperative, rare)
+  unsigned long long todo = __ballot(amb);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int sf = __shfl(f, src), sq = __shfl(q, src), sc = __shfl(c, src);
+    const float sbm = __shfl(best, src), smg = __shfl(margin, src);
+    const float *wrow = Wm + (size_t)sq * D;
+    float eb = -INFINITY;
+    int ei = 0x7fffffff;
+    for (int k2 = 0; k2 < 2 * nrb; k2++) {
+      const f32x4 e = part[((size_t)sf * nrb + (k2 >> 1)) * Qpad + sc];
+      const float m = (k2 & 1) ? e[1] : e[0];
+      const int i = __float_as_int((k2 & 1) ? e[3] : e[2]);
+      if (sbm - m < smg) {               // wave-uniform; the winner itself qualifies (0 < margin)
+        const float *vrow = V + ((size_t)sf * Nb + i) * D;
+        float acc = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
+          const f32x4 x = *reinterpret_cast<const f32x4 *>(vrow + d);
+          const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + d);
+          acc = fmaf(x[0], w[0], acc);
+          acc = fmaf(x[1], w[1], acc);
+          acc = fmaf(x[2], w[2], acc);
+          acc = fmaf(x[3], w[3], acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (better(acc, i, eb, ei)) {
+          eb = acc;
+          ei = i;
+        }
+      }
+    }
+    if (lane == src) {
+      best = eb;
+      bi = ei;
+    }
+  }
+  if (in) {
+    S_max[idx] = live ? best : 0.f;      // masked query slot: the whole S_ column is 0 (model.py:551)
+    D_ind[idx] = live ? (int64_t)bi : (int64_t)0;
+  }
+}
+
+struct Plan {
+  int ok, NCB, NC, G, KS, RBW, RPW, nrb, TRB, NRG, NSG, Qpad;
+  size_t lds;
+  int64_t ws_bytes;
+};
+
+inline Plan make_plan(int F, int Nb, int Na, int Ne, int D, int max_live) {
+  Plan p{};
+  const int Q = Na * Ne;
+  int Qh = (max_live < 0 || max_live > Q) ? Q : max_live;
+  if (Qh < 1) Qh = 1;
+  p.ok = (D % 32 == 0) && D <= 1024 && Na <= NA_MAX && F >= 1 && Nb >= 1;
+  if (!p.ok) return p;
+  p.NCB = (Qh <= 32 || D > 512) ? 1 : 2;
+  p.NC = 32 * p.NCB;
+  p.G = (Qh + p.NC - 1) / p.NC;
+  p.nrb = (Nb + 31) / 32;
+  p.TRB = F * p.nrb;
+  const int nchunks = D / 32;
+  int KS = 1;
+  while (KS < 4 && (long)p.TRB * p.G * KS < 1024 && nchunks % (KS * 2) == 0 && nchunks / (KS * 2) >= 2) KS *= 2;
+  p.KS = KS;
+  p.RBW = 4 / KS;
+  p.NRG = (p.TRB + p.RBW - 1) / p.RBW;
+  const int occ = p.NCB == 1 && D <= 512 ? 2 : 1;                 // workgroups per CU the LDS footprint allows
+  long units = (long)p.NRG * p.G;
+  int RPW = (int)(units / (256L * occ));
+  if (RPW < 1) RPW = 1;
+  if (RPW > 16) RPW = 16;
+  p.RPW = RPW;
+  p.NSG = (p.NRG + RPW - 1) / RPW;
+  p.Qpad = p.G * p.NC;
+  const size_t scratch_ks = (size_t)(4 - p.RBW) * p.NCB * 16 * 64 * 4;
+  const size_t scratch_px = (size_t)(Na + 1) * 4;
+  p.lds = (size_t)D * p.NC * 4 + p.NC * 4 + (scratch_ks > scratch_px ? scratch_ks : scratch_px);
+  p.lds = (p.lds + 15) & ~(size_t)15;
+  if (p.lds > 160 * 1024) p.ok = 0;
+  p.ws_bytes = (int64_t)p.TRB * p.Qpad * 16;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// exact-fp32 first-generation kernel (simloss.hip): the fallback for shapes this file does not take
+int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
+                             float *S_max, int64_t *D_ind, void *stream);
+
+int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D) {
+  if (F <= 0 || Nb <= 0 || Na <= 0 || Ne <= 0 || D <= 0) return NAFAE_EINVAL;
+  const Plan p = make_plan(F, Nb, Na, Ne, D, -1);
+  if (!p.ok) return 0;                   // the fallback kernel needs none
+  // the all-live plan is the largest (ws = TRB * Qpad * 16 with Qpad = Q rounded up to a column group)
+  const int64_t q64 = ((int64_t)Na * Ne + 63) / 64 * 64;
+  return (int64_t)p.TRB * q64 * 16;
+}
+
+int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
+                         int max_live_cols, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
+                         void *stream) {
+  if (!V || !W || !ent_len || !S_max || !D_ind) return NAFAE_EINVAL;
+  if (Na <= 0 || F <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  const Plan p = make_plan(F, Nb, Na, Ne, D, max_live_cols);
+  if (!p.ok) return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
+  if (!workspace || workspace_bytes < p.ws_bytes) return NAFAE_EINVAL;
+  if ((long)F * Na * Ne > (1L << 31) - 256) return NAFAE_ELIMIT;
+  const void *kern = p.NCB == 1 ? reinterpret_cast<const void *>(sim_part_kernel<1>)
+                                : reinterpret_cast<const void *>(sim_part_kernel<2>);
+  if (p.lds > 64 * 1024) {
+    const int rc = allow_dynamic_lds(kern, 160 * 1024);
+    if (rc != NAFAE_OK) return rc;
+  }
+  const int grid = ((p.NSG + 7) / 8) * 8 * p.G;
+  f32x4 *part = reinterpret_cast<f32x4 *>(workspace);
+  hipStream_t st = as_stream(stream);
+  if (p.NCB == 1)
+    hipLaunchKernelGGL(sim_part_kernel<1>, dim3(grid), dim3(256), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
+                       p.RPW, p.Qpad, part);
+  else
+    hipLaunchKernelGGL(sim_part_kernel<2>, dim3(grid), dim3(256), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
+                       p.RPW, p.Qpad, part);
+  const long total = (long)F * Na * Ne;
+  hipLaunchKernelGGL(sim_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, V, W, ent_len, F, Nb, Na,
+                     Ne, D, p.nrb, p.Qpad, S_max, D_ind);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -155,9 +155,9 @@ class _DVSAFn(torch.autograd.Function):
     pass as the loss; backward only scatters it to dV / dW."""
 
     @staticmethod
-    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train):
+    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, lens=None):
         with ops.timed("sim_max"):
-            S_max, D_ind = ops.sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne)
+            S_max, D_ind = ops.sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne, lens=lens)
         need = V.requires_grad or W.requires_grad
         with ops.timed("loss_tail"):
             loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train,
@@ -176,7 +176,7 @@ class _DVSAFn(torch.autograd.Function):
         gs = g_loss.detach().reshape(1).float().contiguous()
         with ops.timed("sim_bwd"):
             dV, dW = ops.sim_bwd(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, train, ws, grad_scale=gs)
-        return dV, dW, None, None, None, None, None, None, None, None
+        return dV, dW, None, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------- modules
@@ -236,7 +236,7 @@ class DVSA(nn.Module):
         ent_len = torch.tensor([int(x) for x in entities_length], dtype=torch.int32, device=vis_feats.device)
         D_ind, D_sim, margin_loss = _DVSAFn.apply(vis_feats.contiguous(), word_feats.contiguous(), ent_len, Na, Ns, Nb,
                                                   Ne, float(self.args.Delta), float(self.args.vis_lam),
-                                                  self.phase == 'train')
+                                                  self.phase == 'train', [int(x) for x in entities_length])
         return D_ind, D_sim, margin_loss
 
 

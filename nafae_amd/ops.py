@@ -448,35 +448,56 @@ def roi_align_avg_nhwc(feat_nhwc, rois, spatial_scale):
 
 
 # ------------------------------------------------------------------------------------------------ sim + loss
-def sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne):
-    _chk(V); _chk(W); _chk(ent_len, torch.int32)
-    D = V.shape[1]
-    F, Q = Na * Ns, Na * Ne
-    if V.shape[0] != F * Nb or W.shape[0] != Q or W.shape[1] != D:
-        raise NafaeOpError("sim_max_fwd: shape mismatch V %s W %s (Na,Ns,Nb,Ne)=(%d,%d,%d,%d)"
-                           % (tuple(V.shape), tuple(W.shape), Na, Ns, Nb, Ne))
-    S_max = torch.empty(F, Q, device=V.device, dtype=torch.float32)
-    D_ind = torch.empty(F, Q, device=V.device, dtype=torch.int64)
-    _rc(_lib.lib().nafae_sim_max_fwd(_p(V), _p(W), _p(ent_len), Na, Ns, Nb, Ne, D, _p(S_max), _p(D_ind), _stream()),
-        "nafae_sim_max_fwd")
-    return S_max, D_ind
+_sim_ws = {}
 
 
-def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne):
-    """Frame-sharded sim+max: V holds F whole frames ([F*Nb, D]) of a global batch with Na segments; W holds all
-    Q = Na*Ne query rows.  -> this rank's rows of S_max / D_ind, [F, Q]."""
+def _sim_workspace(nbytes, device):
+    """Scratch of the two-kernel similarity (top-2 partials per 32-row block), one buffer per (device, stream)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _sim_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+        _sim_ws[key] = t
+    return t
+
+
+def _live_cols(lens, Ne):
+    return None if lens is None else int(sum(min(max(int(l), 0), Ne) for l in lens))
+
+
+def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=None, exact_fp32=False):
+    """Sim + max for F whole frames (V [F*Nb, D]) of a batch with Na segments against all Q = Na*Ne query rows W
+    -> S_max f32 [F, Q], D_ind int64 [F, Q].  On one GPU F = Na*Ns; in the frame-sharded multi-GPU mode F is this rank's share.
+    `lens`: the host-side entity_length list (what DVSA.forward is called with), if available: it sizes the launch for the
+    live query slots without a device read-back.  exact_fp32=True selects the first-generation exact-fp32 MFMA kernel."""
     _chk(V); _chk(W); _chk(ent_len, torch.int32)
     D = V.shape[1]
     Q = Na * Ne
-    if V.shape[0] % Nb or W.shape[0] != Q or W.shape[1] != D:
+    if V.shape[0] % Nb or W.shape[0] != Q or W.shape[1] != D or ent_len.numel() != Na:
         raise NafaeOpError("sim_max_fwd_frames: shape mismatch V %s W %s (Nb,Na,Ne)=(%d,%d,%d)"
                            % (tuple(V.shape), tuple(W.shape), Nb, Na, Ne))
     F = V.shape[0] // Nb
     S_max = torch.empty(F, Q, device=V.device, dtype=torch.float32)
     D_ind = torch.empty(F, Q, device=V.device, dtype=torch.int64)
-    _rc(_lib.lib().nafae_sim_max_fwd_frames(_p(V), _p(W), _p(ent_len), F, Nb, Na, Ne, D, _p(S_max), _p(D_ind), _stream()),
-        "nafae_sim_max_fwd_frames")
+    L = _lib.lib()
+    if exact_fp32:
+        _rc(L.nafae_sim_max_fwd_frames(_p(V), _p(W), _p(ent_len), F, Nb, Na, Ne, D, _p(S_max), _p(D_ind), _stream()),
+            "nafae_sim_max_fwd_frames")
+        return S_max, D_ind
+    nws = int(L.nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D))
+    if nws < 0:
+        raise NafaeOpError("nafae_sim_max_workspace_bytes failed")
+    ws = _sim_workspace(nws, V.device)
+    live = _live_cols(lens, Ne)
+    _rc(L.nafae_sim_max_fwd_ws(_p(V), _p(W), _p(ent_len), F, Nb, Na, Ne, D, -1 if live is None else live, _p(S_max),
+                               _p(D_ind), _p(ws), ws.numel(), _stream()), "nafae_sim_max_fwd_ws")
     return S_max, D_ind
+
+
+def sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne, lens=None, exact_fp32=False):
+    if V.shape[0] != Na * Ns * Nb:
+        raise NafaeOpError("sim_max_fwd: shape mismatch V %s (Na,Ns,Nb,Ne)=(%d,%d,%d,%d)" % (tuple(V.shape), Na, Ns, Nb, Ne))
+    return sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=lens, exact_fp32=exact_fp32)
 
 
 def sim_bwd_frames(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, cluster_rows, workspace, pre_scale=None, grad_scale=None):

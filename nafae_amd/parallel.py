@@ -129,14 +129,14 @@ class _FrameShardedDVSAFn(torch.autograd.Function):
     global-batch loss."""
 
     @staticmethod
-    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, group, ops):
+    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, group, ops, lens=None):
         world, rank = _world(group), _rank(group)
         F = Na * Ns
         if F % world or V.shape[0] != (F // world) * Nb:
             raise ValueError("frame-sharded DVSA: %d frames do not split over %d ranks as %d rows of V each"
                              % (F, world, V.shape[0]))
         Fl = F // world
-        S_loc, D_loc = ops.sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne)
+        S_loc, D_loc = ops.sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=lens)
         S_max = all_gather_rows(S_loc, group)
         D_ind = all_gather_rows(D_loc, group)
         V0 = V[:Nb].detach().clone() if rank == 0 else torch.empty(Nb, V.shape[1], device=V.device, dtype=V.dtype)
@@ -158,7 +158,7 @@ class _FrameShardedDVSAFn(torch.autograd.Function):
         Na, Ns, Nb, Ne, cluster_rows = ctx.dims
         gs = g_loss.detach().reshape(1).float().contiguous()
         dV, dW = ctx.ops.sim_bwd_frames(dS_loc, D_loc, V, W, ent_len, Na, Ns, Nb, Ne, cluster_rows, ws, grad_scale=gs)
-        return dV, dW, None, None, None, None, None, None, None, None, None, None
+        return dV, dW, None, None, None, None, None, None, None, None, None, None, None
 
 
 def dvsa_frame_sharded(dvsa, vis_feats_local, word_feats, entities_length, group=None, kernels=None):
@@ -176,7 +176,8 @@ def dvsa_frame_sharded(dvsa, vis_feats_local, word_feats, entities_length, group
         raise ValueError("entities_length has %d entries, Na = %d" % (len(entities_length), Na))
     ent_len = torch.tensor([int(x) for x in entities_length], dtype=torch.int32, device=vis_feats_local.device)
     return _FrameShardedDVSAFn.apply(vis_feats_local.contiguous(), word_feats.contiguous(), ent_len, Na, Ns, Nb, Ne,
-                                     float(dvsa.args.Delta), float(dvsa.args.vis_lam), dvsa.phase == 'train', group, kernels)
+                                     float(dvsa.args.Delta), float(dvsa.args.vis_lam), dvsa.phase == 'train', group, kernels,
+                                     [int(x) for x in entities_length])
 
 
 def broadcast_parameters(model, src=0, group=None):

@@ -48,7 +48,7 @@ class CpuKernels:
     """Same call signatures as nafae_amd.ops.{sim_max_fwd_frames, loss_fwd_bwd, sim_bwd_frames}."""
 
     @staticmethod
-    def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne):
+    def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=None, exact_fp32=False):
         Q = Na * Ne
         masked = (torch.arange(Ne)[None, :] >= ent_len.long()[:, None]).view(1, Q)
         S_ = (V.detach() @ W.detach().t()).masked_fill(masked, 0)

@@ -1,0 +1,157 @@
+"""The second-generation similarity kernel (nafae_sim_max_fwd_ws: live columns only, bf16x3 MFMA, top-2 per row block,
+fp32 re-evaluation of near-ties) against an fp64 evaluation of model.py:548-551,580-583,610-612 and against the
+first-generation exact-fp32 kernel, over ragged / degenerate / adversarial shapes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(V, W, lens, Na, Nb, Ne):
+    """fp64: masked S_ -> per-frame max / first arg-max, plus the top-2 gap."""
+    Q = Na * Ne
+    S = (V.double() @ W.double().t())
+    masked = (torch.arange(Ne)[None, :] >= torch.tensor(lens)[:, None]).view(1, Q)
+    S = S.masked_fill(masked, 0).view(-1, Nb, Q)
+    m, i = S.max(1)
+    if Nb > 1:
+        t2 = S.topk(2, dim=1)[0]
+        gap = t2[:, 0] - t2[:, 1]
+    else:
+        gap = torch.full_like(m, float("inf"))
+    return m, i, gap, masked.expand(m.shape[0], Q)
+
+
+def _run(V, W, lens, Na, Ns, Nb, Ne, **kw):
+    from nafae_amd import ops
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    return ops.sim_max_fwd(V.cuda(), W.cuda(), lt, Na, Ns, Nb, Ne, **kw)
+
+
+CASES = [
+    # Na, Ns, Nb, Ne, D, lens
+    (2, 2, 32, 8, 512, [3, 5]),                 # C1
+    (3, 5, 20, 13, 64, [2, 0, 4]),              # reference defaults, a zero-length segment, Nb < 32
+    (1, 4, 32, 8, 64, [3]),
+    (4, 3, 7, 5, 32, [5, 1, 0, 2]),             # D = 32: a single 32-k chunk
+    (4, 6, 40, 6, 128, [1, 6, 3, 2]),           # Nb = 40: second row block has 8 valid rows
+    (8, 8, 128, 16, 512, None),                 # C2, histogram lengths (k-split over 4 waves)
+    (2, 3, 300, 64, 512, [64, 10]),             # 74 live columns: two column groups of 64
+    (2, 2, 33, 4, 512, [4, 4]),                 # one row beyond a block
+    (1, 1, 1, 1, 32, [1]),                      # a single pair
+    (2, 2, 64, 40, 1024, [40, 17]),             # D = 1024: 32-column groups only
+    (2, 2, 50, 4, 96, [2, 4]),                  # 3 chunks (no k-split possible)
+    (3, 2, 16, 4, 40, [1, 4, 2]),               # D % 32 != 0: falls back to the exact-fp32 kernel
+    (2, 2, 32, 8, 512, [0, 0]),                 # nothing live
+    (5, 1, 10, 3, 64, [3, 3, 3, 3, 3]),         # every slot live
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "Na%d_Ns%d_Nb%d_Ne%d_D%d" % c[:5])
+@pytest.mark.parametrize("with_hint", [True, False])
+def test_sim_max_v2_matches_fp64(case, with_hint):
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, D, lens = case
+    lens = lens if lens is not None else syn.entity_lengths(Na, Ne, seed=1234)
+    V = torch.tanh(syn.randn(21, "V%d" % D, (Na * Ns * Nb, D)))
+    W = torch.tanh(syn.randn(21, "W%d" % D, (Na * Ne, D)))
+    m, i, gap, masked = _ref(V, W, lens, Na, Nb, Ne)
+    S, Di = _run(V, W, lens, Na, Ns, Nb, Ne, lens=lens if with_hint else None)
+    S, Di = S.cpu().double(), Di.cpu()
+    scale = max(float(m.abs().max()), 1e-6)
+    assert (S[masked] == 0).all() and (Di[masked] == 0).all()
+    assert float((S - m).abs().max()) < 2e-5 * scale
+    bad = (Di != i) & ~masked & (gap > 1e-5 * scale)
+    assert not bad.any(), "D_ind differs from the fp64 arg-max at %d decided entries" % int(bad.sum())
+    # and the first-generation exact-fp32 kernel agrees with it wherever fp32 itself is decided
+    S1, D1 = _run(V, W, lens, Na, Ns, Nb, Ne, exact_fp32=True)
+    assert not ((D1.cpu() != Di) & ~masked & (gap > 1e-5 * scale)).any()
+    assert float((S1.cpu().double() - S).abs().max()) < 2e-5 * scale
+
+
+def test_sim_max_v2_ties_pick_first_index():
+    """Duplicate proposals (zero-padded rois give identical rows) -> the FIRST maximal index, like torch.max(dim)."""
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, D = 2, 2, 70, 4, 512
+    lens = [4, 2]
+    V = torch.tanh(syn.randn(5, "Vt", (Na * Ns * Nb, D)))
+    W = torch.tanh(syn.randn(5, "Wt", (Na * Ne, D)))
+    V3 = V.view(Na * Ns, Nb, D)
+    V3[:, 37] = V3[:, 5]            # same block / different blocks, higher index never wins
+    V3[:, 69] = V3[:, 5]
+    V3[0, :] = V3[0, 0]             # a frame of identical rows: every column's arg-max is 0
+    m, i, gap, masked = _ref(V, W, lens, Na, Nb, Ne)
+    S, Di = _run(V, W, lens, Na, Ns, Nb, Ne, lens=lens)
+    Di = Di.cpu()
+    assert (Di[0][~masked[0]] == 0).all()
+    assert not (Di == 37).any() and not (Di == 69).any()
+    decided_or_dup = (gap > 1e-5 * float(m.abs().max())) | (gap == 0)
+    assert not ((Di != i) & ~masked & decided_or_dup).any()
+
+
+def test_sim_max_v2_near_ties_are_decided_in_fp32():
+    """Two proposals whose exact scores differ by ~1e-5 -- far inside the bf16x3 error but well above fp32 rounding: the
+    refinement path (exact fp32 dot products of the listed candidates) must pick the fp64 winner in both index orders."""
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, D = 2, 2, 96, 4, 512
+    lens = [4, 3]
+    V = torch.tanh(syn.randn(9, "Vn", (Na * Ns * Nb, D))) * 0.5
+    W = torch.tanh(syn.randn(9, "Wn", (Na * Ne, D)))
+    V3 = V.view(Na * Ns, Nb, D)
+    Wd = W.double()
+    # make row 11 of every frame the clear winner for query 0 (segment 0 slot 0), then plant near-copies of it
+    V3[:, 11] = torch.tanh(W[0] * 1.5) * 0.1       # score ~28 (ulp 2e-6) against <10 for the random rows
+    for f, (j, sign) in enumerate([(70, +1.0), (3, +1.0), (70, -1.0), (3, -1.0)]):
+        r = V3[f, 11].clone()
+        k = int(torch.argmax(W[0].abs()))
+        r[k] = r[k] + sign * 2.0 ** -14 * torch.sign(W[0, k])      # exact score changes by +-2^-14 * |w_k| ~ 5e-5
+        V3[f, j] = r
+    m, i, gap, masked = _ref(V, W, lens, Na, Nb, Ne)
+    assert float(gap[:, 0].max()) < 2e-4 and float(gap[:, 0].min()) > 1e-5       # planted: tiny but fp32-resolvable
+    S, Di = _run(V, W, lens, Na, Ns, Nb, Ne, lens=lens)
+    assert Di.cpu()[:, 0].tolist() == i[:, 0].tolist() == [70, 3, 11, 11]
+    # refined entries carry the fp32 value of the winner
+    assert float((S.cpu().double()[:, 0] - m[:, 0]).abs().max()) < 3e-6 * float(m.abs().max())
+
+
+def test_sim_max_v2_frames_equals_whole_batch():
+    """The frame-sharded call (a rank's F frames against all Q queries) returns the rows of the whole-batch call."""
+    from nafae_amd import ops
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, D = 4, 4, 48, 6, 512
+    lens = [2, 6, 0, 3]
+    V = torch.tanh(syn.randn(3, "Vf", (Na * Ns * Nb, D))).cuda()
+    W = torch.tanh(syn.randn(3, "Wf", (Na * Ne, D))).cuda()
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    S, Di = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)
+    for lo, hi in ((0, 4), (4, 16), (15, 16)):
+        Sl, Dl = ops.sim_max_fwd_frames(V[lo * Nb:hi * Nb].contiguous(), W, lt, Nb, Na, Ne, lens=lens)
+        # (the launch plan -- how K is split over waves -- depends on the number of frames, so the fp32 sums may differ in
+        # the last bit between the two calls; the indices may not)
+        assert torch.allclose(Sl, S[lo:hi], rtol=0, atol=2e-6 * float(S.abs().max())) and torch.equal(Dl, Di[lo:hi])
+
+
+def test_sim_max_v2_is_deterministic_and_graph_capturable():
+    from nafae_amd import ops
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, D = 8, 8, 300, 64, 512
+    lens = syn.entity_lengths(Na, Ne, seed=1234)
+    V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, D, seed=2)
+    V, W = V.cuda(), W.cuda()
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    a = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)
+    b = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne)               # no hint: sized for all Q columns, another K split
+    assert torch.allclose(a[0], b[0], rtol=0, atol=2e-6 * float(a[0].abs().max())) and torch.equal(a[1], b[1])
+    a2 = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)   # same plan: bit-identical run to run
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)    # allocate the stream's workspace outside the capture
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            c = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)
+        g.replay()
+        st.synchronize()
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
