@@ -5,7 +5,9 @@
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller allocates every
  *     buffer (outputs need not be pre-zeroed) and keeps ownership; nothing is allocated, freed or
- *     synchronised inside, so every call is hipGraph-capturable;
+ *     synchronised inside, so every call is hipGraph-capturable; the library reads no environment variable and keeps no
+ *     state between calls other than a mutex-protected, per-device record of which kernels have had their dynamic-LDS limit
+ *     raised (hipFuncSetAttribute, first launch of such a kernel on a device);
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
  *   - return value: 0 = launched, negative = NAFAE_E* (argument error: nothing launched; NAFAE_ELAUNCH: the
  *     runtime refused the launch);
@@ -174,9 +176,9 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
 /* 3x3 conv + bias (+ReLU), NHWC planes in, fp32 and/or planes out; w planes are [Cout,3,3,Cin].
  * `relu`: bit 0 = apply ReLU; bit 4 = also apply the 2x2/2 max-pool that follows the layer (outputs are then
  * [F, H/2, W/2, Cout]; available where the 2-D patch kernel runs -- otherwise NAFAE_ELIMIT is returned and the caller
- * pools separately with nafae_maxpool2x2_bf16).  Bits 8 and 9 are timing experiments used by scripts/layer_times.py (staging loads served
- * from one cached zero line / stores skipped -- the results are then meaningless); production callers pass 0 or 1.
- * Likewise `act` = -1 / -2 of nafae_gemm_nt_bf16.  */
+ * pools separately with nafae_maxpool2x2_bf16).  Any other bit -> NAFAE_EINVAL.  (Builds made with -DNAFAE_EXPERIMENTS --
+ * python -m nafae_amd.build --experiments, a separate libnafae_hip_exp.so for scripts/ -- additionally accept the timing
+ * experiment bits 8 / 9 and `act` = -1 / -2 of nafae_gemm_nt_bf16, and honour the NAFAE_* tuning environment variables.)  */
 int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
                        float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,
                        void *stream);

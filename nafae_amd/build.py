@@ -43,13 +43,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, experiments=False):
+    """experiments=True builds libnafae_hip_exp.so with -DNAFAE_EXPERIMENTS: the timing-experiment modes and the NAFAE_*
+    tuning environment variables that scripts/ use (select it with NAFAE_LIB=<path>); the default build has neither."""
     deps_common = [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
     objs = []
     rebuilt = False
+    lib = LIB.replace(".so", "_exp.so") if experiments else LIB
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", "_exp.o" if experiments else ".o"))
+        if experiments:
+            extra = extra + ["-DNAFAE_EXPERIMENTS"]
         if force or _stale(o, [s] + deps_common):
             cmd = [_hipcc()] + COMMON + extra + ["-c", s, "-o", o]
             if verbose:
@@ -57,13 +62,13 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
             rebuilt = True
         objs.append(o)
-    if force or rebuilt or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    if force or rebuilt or _stale(lib, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

@@ -9,6 +9,7 @@
 #include "mfma_tile.h"
 #include <stdlib.h>
 #include "../../include/nafae_hip.h"
+#include "hip_util.h"
 
 using namespace nafae;
 
@@ -461,12 +462,12 @@ static int launch_gemm_tn(const float *A, int lda, const float *B, int ldb, floa
 
 static int gemm_tn_dispatch(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K, float alpha,
                             int accumulate, const int32_t *rows, const int32_t *count, hipStream_t st) {
-  const char *e = getenv("NAFAE_GEMM_TN_SPLITK");
+  const char *e = nafae::experiment_env("NAFAE_GEMM_TN_SPLITK");
   const bool splitk = e && e[0] == '1';
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long)((M + 63) / 64) * ((N + 127) / 128);
   static int pref = -1;   // NAFAE_GEMM_TN_MIN_TILES: workgroups wanted before a larger tile is accepted (default 384)
   if (pref < 0) {
-    const char *t = getenv("NAFAE_GEMM_TN_MIN_TILES");
+    const char *t = nafae::experiment_env("NAFAE_GEMM_TN_MIN_TILES");
     pref = t && atoi(t) > 0 ? atoi(t) : 384;
   }
   if (splitk || t128 >= pref) return launch_gemm_tn<128, 128>(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, rows, count, splitk, st);

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "../../include/nafae_hip.h"
+#include "hip_util.h"
 
 using namespace nafae;
 
@@ -1227,11 +1228,7 @@ int launch_gemm(const void *Xhi, const void *Xlo, int ldx, const void *Whi, cons
   const size_t lds = 2 * E::STAGE * sizeof(__bf16);
   auto kern = gemm_nt_bf16_kernel<BX, BW, WX, WW, SPLIT>;
   if (lds > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      once = true;
-    }
+    if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, ldx,
                      (const __bf16 *)Whi, (const __bf16 *)Wlo, ldw, Cf, (__bf16 *)Chi, (__bf16 *)Clo, ldc, bias, M, N, K, alpha,
@@ -1248,11 +1245,7 @@ int launch_conv(const void *Xhi, const void *Xlo, const void *Whi, const void *W
   const size_t lds = 2 * E::STAGE * sizeof(__bf16);
   auto kern = conv3x3_bf16_kernel<BX, BW, WX, WW, SPLIT>;
   if (lds > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      once = true;
-    }
+    if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo,
                      (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu,
@@ -1269,7 +1262,7 @@ inline bool host_il(const void *hi, const void *lo) {
 inline bool use_s16() {
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("NAFAE_MFMA");
+    const char *e = nafae::experiment_env("NAFAE_MFMA");
     v = (e && atoi(e) == 16) ? 1 : 0;
   }
   return v == 1;
@@ -1284,11 +1277,7 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   const size_t lds = NST * E::STAGE * sizeof(__bf16);
   auto kern = (use_s16() && !PAIR) ? bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, true>
                                     : bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, false, PAIR>;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
-  }
+  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, ldx,
                      (const __bf16 *)Whi, (const __bf16 *)Wlo, ldw, Cf, (__bf16 *)Chi, (__bf16 *)Clo, ldc, bias, M, N, K, alpha,
                      act, tiles_m, tiles_n, H, W, Cin);
@@ -1304,11 +1293,7 @@ int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const voi
   const size_t lds = (size_t)(2 * RR * BKH * PL + NSTW * BW * BKH * PL) * sizeof(__bf16);
   auto kern = (use_s16() && !PAIR) ? conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, true>
                                     : conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, false, PAIR>;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
-  }
+  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo,
                      (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu,
                      tiles_m, tiles_n);
@@ -1330,7 +1315,7 @@ inline int num_cus() {
 inline bool sk_pays(long tiles, int G) {
   // NAFAE_CONV_SK=0 disables it (A/B, and runs that must not depend on the batch size in the last bit: which tiles are
   // cut -- hence the order their partial sums are added in -- depends on the tile count).  Read on every call.
-  const char *e = getenv("NAFAE_CONV_SK");
+  const char *e = nafae::experiment_env("NAFAE_CONV_SK");
   if ((e && e[0] == '0') || tiles <= G) return false;
   const long rounds = (tiles + G - 1) / G;
   return (double)(rounds * G - tiles) / (double)(rounds * G) > 0.10;
@@ -1344,11 +1329,7 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   const int M = F * H * W;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
   auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES);
-    once = true;
-  }
+  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)R::LDS_BYTES) != NAFAE_OK) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
                      (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch);
   if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
@@ -1365,11 +1346,7 @@ int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const vo
   const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
   const size_t lds = (size_t)(2 * 320 * BKH * 2 + 6 * BW * BKH * 2) * sizeof(__bf16);
   auto kern = use_s16() ? conv3x3_run3_kernel<BW, WX, WW, IL, true> : conv3x3_run3_kernel<BW, WX, WW, IL, false>;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
-  }
+  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo,
                      (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu,
                      tiles_m, tiles_n);
@@ -1383,18 +1360,13 @@ int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void 
   const long T = (long)F * tiles_y * tiles_x * tiles_n;
   if (T >= (1L << 31)) return NAFAE_ELIMIT;
   const size_t lds = (size_t)(2 * PROWS * 64 + 6 * 64 * 64) * sizeof(__bf16);
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel<PAIR, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    once = true;
-  }
+  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(conv3x3_patch_kernel<PAIR, POOL>), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   // a few workgroups per CU rather than exactly one: each still runs several tiles back to back (the prologue is paid once
   // per workgroup), but workgroups retire every few tiles, which lets the small kernels of another stream (the training
   // tail that the pipelined trainer overlaps with the next detector) onto the CUs instead of waiting for the whole launch
   static int per_cu = 0;
   if (!per_cu) {
-    const char *e = getenv("NAFAE_PATCH_WG_PER_CU");
+    const char *e = nafae::experiment_env("NAFAE_PATCH_WG_PER_CU");
     per_cu = e && atoi(e) > 0 ? atoi(e) : 4;
   }
   const long want = (long)per_cu * num_cus();
@@ -1408,7 +1380,7 @@ int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void 
 inline bool use_run() {
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("NAFAE_CONV_RUN");
+    const char *e = nafae::experiment_env("NAFAE_CONV_RUN");
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v == 1;
@@ -1417,7 +1389,7 @@ inline bool use_run() {
 inline bool use_dma() {
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("NAFAE_BF16_PIPE");
+    const char *e = nafae::experiment_env("NAFAE_BF16_PIPE");
     v = (e && e[0] == 'r') ? 0 : 1;
   }
   return v == 1;
@@ -1450,14 +1422,18 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
                        void *stream) {
   if (!X_hi || !W_hi || (!C_f32 && !C_hi) || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((K & 7) || (ldx & 7) || (ldw & 7) || (N & 3) || (ldc & 3) || !al16(X_hi) || !al16(W_hi)) return NAFAE_EINVAL;
+#ifdef NAFAE_EXPERIMENTS
   if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU && (act > 0 || act < -2)) return NAFAE_EINVAL;   // -1 / -2: timing experiments
+#else
+  if (act != NAFAE_ACT_NONE && act != NAFAE_ACT_RELU) return NAFAE_EINVAL;
+#endif
   const bool split = X_lo && W_lo;
   if (!split && (X_lo || W_lo)) return NAFAE_EINVAL;
   if (host_il(X_hi, X_lo) && !use_dma()) return NAFAE_EINVAL;  // I32 operands: LDS-DMA kernels only
   if (use_dma()) {
     static int big = -1;  // NAFAE_BF16_TILE=128 forces the 256x128 tile (A/B experiments)
     if (big < 0) {
-      const char *e = getenv("NAFAE_BF16_TILE");
+      const char *e = nafae::experiment_env("NAFAE_BF16_TILE");
       big = (e && atoi(e) == 128) ? 0 : 1;
     }
     const bool il = split && host_il(X_hi, X_lo) && host_il(W_hi, W_lo);  // interleaved I32 operands (K % 32 == 0)
@@ -1484,7 +1460,7 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     // 32 instead of 16 MFMAs per wave between barriers (NAFAE_BF16_PAIR=0 falls back to the 32-deep k-tile kernels)
     static int pair = -1;
     if (pair < 0) {
-      const char *e = getenv("NAFAE_BF16_PAIR");
+      const char *e = nafae::experiment_env("NAFAE_BF16_PAIR");
       pair = (e && e[0] == '0') ? 0 : 1;
     }
     if (pair && !split && (K % 64) == 0 && (ldx % 64) == 0 && (ldw % 64) == 0 && M >= 256 && N >= 128) {
@@ -1529,6 +1505,9 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
                           void *workspace, int64_t workspace_bytes, void *stream) {
   if (!in_hi || !w_hi || !bias || (!out_f32 && !out_hi) || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
   if (Cin % 32 || Cout % 4 || !al16(in_hi) || !al16(w_hi)) return NAFAE_EINVAL;
+#ifndef NAFAE_EXPERIMENTS
+  if (relu & ~0x11) return NAFAE_EINVAL;   // bit 0 = ReLU, bit 4 = fused max-pool; the timing-experiment bits exist in experiment builds only
+#endif
   if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
   const bool split = in_lo && w_lo;
   if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
@@ -1542,7 +1521,7 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
       {   // narrow layers: 2-D patch kernel (NAFAE_CONV_PATCH=0 disables it, =all widens it to every eligible layer).
           // Measured at C2: 64->64@224^2 1.04 -> 0.80 ms, 64->128@112^2 0.48 -> 0.37, 128->128@112^2 0.83 -> 0.66; wider
           // layers re-read the patch once per 64 output channels and stay on the run-reuse kernels.
-        const char *pe = getenv("NAFAE_CONV_PATCH");
+        const char *pe = nafae::experiment_env("NAFAE_CONV_PATCH");
         const bool off = pe && pe[0] == '0', all = pe && pe[0] == 'a';
         if (il && !off && !out_f32 && out_hi && out_lo && host_il(out_hi, out_lo) && H % PT == 0 && W % PT == 0 && Cout % 64 == 0 &&
             (all || (Cin <= 128 && Cout <= 128)) && (long)F * (H / PT) * (W / PT) * (Cout / 64) >= num_cus())
@@ -1553,7 +1532,7 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
       if (Cout <= 64) {
         static int g3 = -1;  // NAFAE_CONV_RUN3=0: one barrier per tap instead of per 3-tap group (A/B)
         if (g3 < 0) {
-          const char *e = getenv("NAFAE_CONV_RUN3");
+          const char *e = nafae::experiment_env("NAFAE_CONV_RUN3");
           g3 = (e && e[0] == '0') ? 0 : 1;
         }
         if (g3 && il)
@@ -1571,7 +1550,7 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
       // 224-pixel tiles when that lowers ceil(workgroups / 256 CUs) * pixels-per-tile (tile-count quantisation)
       static int q224 = -1;
       if (q224 < 0) {
-        const char *e = getenv("NAFAE_CONV_224");
+        const char *e = nafae::experiment_env("NAFAE_CONV_224");
         q224 = (e && e[0] == '1') ? 1 : 0;   // measured slower than 256-pixel tiles (1x8 wave grid re-reads X 8x): off
       }
       auto cost = [&](int bx, int bw) {
@@ -1606,11 +1585,11 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
     // Cin/2 "pairs" (bf16_tile.h, PAIR): the split kernels run it with 64-channel k-tiles -- twice the MFMAs per barrier of
     // the 32-channel plain kernels below -- including the stream-K schedule.  NAFAE_BF16_PAIR=0 disables it.
     {
-      const char *pe = getenv("NAFAE_BF16_PAIR");
+      const char *pe = nafae::experiment_env("NAFAE_BF16_PAIR");
       const bool pair = !(pe && pe[0] == '0');
       if (pair && !split && Cin % 64 == 0 && !host_il(out_hi, out_lo)) {
         const int Ce = Cin / 2, G = num_cus();
-        const char *pp = getenv("NAFAE_CONV_PATCH");
+        const char *pp = nafae::experiment_env("NAFAE_CONV_PATCH");
         if (!(pp && pp[0] == '0') && !out_f32 && out_hi && H % PT == 0 && W % PT == 0 && Cout % 64 == 0 &&
             ((pp && pp[0] == 'a') || (Cin <= 128 && Cout <= 128)) && (long)F * (H / PT) * (W / PT) * (Cout / 64) >= G)
           return (relu & 16) ? launch_conv_patch<true, true>(in_hi, w_hi, bias, out_hi, nullptr, F, H, W, Ce, Cout, relu, S(stream))

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/nafae_hip.h"
+#include "hip_util.h"
 
 namespace {
 
@@ -511,12 +512,7 @@ int nafae_sort_desc(const float *scores, int32_t *order, int F, int n, void *str
   while (P < n) P <<= 1;
   const size_t lds = (size_t)P * sizeof(unsigned long long);
   if (lds > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          128 * 1024);
-      once = true;
-    }
+    if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(sort_kernel), 128 * 1024) != NAFAE_OK) return NAFAE_ELAUNCH;
   }
   hipLaunchKernelGGL(sort_kernel, dim3(F), dim3(P < 1024 ? P : 1024), lds, S(stream), scores, order, n, P);
   return launched();
@@ -528,12 +524,7 @@ static int launch_nms(const float *boxes, int box_stride, const float *scores, c
   if (topN > 8192) return NAFAE_ELIMIT;
   const size_t lds = (size_t)topN * sizeof(f32x4);
   if (lds > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          128 * 1024);
-      once = true;
-    }
+    if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(nms_kernel), 128 * 1024) != NAFAE_OK) return NAFAE_ELAUNCH;
   }
   hipLaunchKernelGGL(nms_kernel, dim3(F), dim3(64), lds, st, boxes, box_stride, scores, order, n, n_sorted, thresh, topN,
                      keep_out, num_out, rois, roi_scores);

@@ -13,6 +13,7 @@
 // All reductions run in a fixed order (no float atomics), so results are bit-reproducible run to run.
 #include "mfma_tile.h"
 #include "../../include/nafae_hip.h"
+#include "hip_util.h"
 
 using namespace nafae;
 
@@ -791,12 +792,7 @@ int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V,
     const size_t lds = (size_t)2 * Ns * D * sizeof(float);
     if (lds > 64 * 1024) {
       if (lds > 144 * 1024) return NAFAE_ELIMIT;
-      static bool once = false;
-      if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cluster_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        once = true;
-      }
+      if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(cluster_kernel), 144 * 1024) != NAFAE_OK) return NAFAE_ELAUNCH;
     }
     hipLaunchKernelGGL(cluster_kernel, dim3(Na * Ne), dim3(256), lds, S(stream), S_max, D_ind, V, ent_len, Na, Ns, Ne, D,
                        ws, L);

@@ -15,9 +15,9 @@
 //     fragment order: lane (c, h) reads its 16-B B fragment with one conflict-free ds_read_b128 per plane.
 //   * bf16x3 ARITHMETIC: hi*hi + hi*lo + lo*hi, fp32 accumulate -- 3 bf16 MFMAs instead of 16 MFMA-cycles of fp32.
 //     Every (frame, query) keeps the TOP-2 (value, index) per 32-row block; the finish kernel merges the blocks of a
-//     frame and, where the runner-up of ANY block is within `margin` of the winner, re-evaluates those candidates with
-//     exact fp32 FMA dot products and picks the larger (ties -> smaller index, torch.max's rule).  So D_ind is decided by
-//     fp32 arithmetic wherever bf16x3 could not separate the candidates, and S_max of such entries is the fp32 value.
+//     frame and re-evaluates with exact fp32 FMA dot products the winner and every listed runner-up within `margin` of it,
+//     taking the largest (ties -> smaller index, torch.max's rule).  So bf16x3 only FILTERS: S_max is always an fp32 dot
+//     product, and D_ind is decided by fp32 arithmetic wherever bf16x3 could not separate the candidates.
 //     margin = 2^-15 * D + 2^-11 * |score|: twice the rigorous bf16x3 bound 2^-16 * sum|v||w| for |v|,|w| <= 1 (tanh
 //     outputs, model.py:628,642), plus a relative guard.
 //   * Parallelism follows the problem, not a fixed grid: 4 waves per workgroup = RBW row blocks x KS k-splits (K is split
@@ -293,99 +293,108 @@ __global__ __launch_bounds__(256) void sim_part_kernel(const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------- finish kernel
-// one thread per (frame, query slot); masked slots -> (0, 0); live slots merge the frame's row blocks and refine near-ties
+// One WAVE per (frame, live column): merge the frame's row blocks, then evaluate with exact fp32 FMA dot products the winner
+// and every listed runner-up within the margin, and take the best of those (ties -> smaller index).  S_max is therefore always
+// an fp32 dot product of the winning pair (the loss tail divides by max - min over frames and is sensitive to ~1e-6 relative
+// errors), and D_ind is decided in fp32 wherever bf16x3 could not separate the candidates.  The workgroups also zero-fill the
+// masked query slots.  grid: ceil(F * Qh / 4) workgroups of 256 threads (Qh = the host's upper bound on live columns).
 __global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict__ part, const float *__restrict__ V,
                                                          const float *__restrict__ Wm, const int32_t *__restrict__ ent_len,
-                                                         int F, int Nb, int Na, int Ne, int D, int nrb, int Qpad,
+                                                         int F, int Nb, int Na, int Ne, int D, int nrb, int Qpad, int Qh,
                                                          float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
   __shared__ int prefix[NA_MAX + 1];
   build_prefix(ent_len, Na, Ne, prefix);
   __syncthreads();
   const int Q = Na * Ne;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool in = idx < (long)F * Q;
-  const int lane = threadIdx.x & 63;
-  int f = 0, q = 0, c = 0;
-  bool live = false;
-  if (in) {
-    f = (int)(idx / Q);
-    q = (int)(idx - (long)f * Q);
-    const int a = q / Ne, e = q - a * Ne;
-    const int l = ent_len[a];
-    live = e < (l > Ne ? Ne : l);
-    c = prefix[a] + e;
-  }
-  float best = 0.f, margin = 0.f;
-  int bi = 0;
-  bool amb = false;
-  if (live) {
-    const f32x4 *p = part + (size_t)f * nrb * Qpad + c;
-    float bm = -INFINITY;
-    int bidx = 0;
-    for (int k = 0; k < nrb; k++) {
-      const f32x4 e = p[(size_t)k * Qpad];
-      const int i1 = __float_as_int(e[2]);
-      if (better(e[0], i1, bm, bidx)) {
-        bm = e[0];
-        bidx = i1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {  // masked slots: the whole S_ column is 0 (model.py:551) -> (0, 0)
+    const long total = (long)F * Q;
+    const long per = (total + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per;
+    long hi = lo + per;
+    hi = hi < total ? hi : total;
+    for (long idx = lo + threadIdx.x; idx < hi; idx += 256) {
+      const int q = (int)(idx % Q);
+      const int a = q / Ne, e = q - a * Ne;
+      if (e >= ent_len[a]) {
+        S_max[idx] = 0.f;
+        D_ind[idx] = 0;
       }
     }
-    margin = 3.0517578125e-05f * (float)D + 4.8828125e-04f * fabsf(bm);   // 2^-15 * D + 2^-11 * |score|
-    for (int k = 0; k < nrb; k++) {
-      const f32x4 e = p[(size_t)k * Qpad];
-      const int i1 = __float_as_int(e[2]), i2 = __float_as_int(e[3]);
-      if (i1 != bidx && bm - e[0] < margin) amb = true;
-      if (i2 != bidx && bm - e[1] < margin) amb = true;
-    }
-    best = bm;
-    bi = bidx;
   }
-  // exact fp32 re-evaluation of every listed candidate within the margin (wave-cooperative, rare)
-  unsigned long long todo = __ballot(amb);
-  while (todo) {
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const int sf = __shfl(f, src), sq = __shfl(q, src), sc = __shfl(c, src);
-    const float sbm = __shfl(best, src), smg = __shfl(margin, src);
-    const float *wrow = Wm + (size_t)sq * D;
-    float eb = -INFINITY;
-    int ei = 0x7fffffff;
-    for (int k2 = 0; k2 < 2 * nrb; k2++) {
-      const f32x4 e = part[((size_t)sf * nrb + (k2 >> 1)) * Qpad + sc];
-      const float m = (k2 & 1) ? e[1] : e[0];
-      const int i = __float_as_int((k2 & 1) ? e[3] : e[2]);
-      if (sbm - m < smg) {               // wave-uniform; the winner itself qualifies (0 < margin)
-        const float *vrow = V + ((size_t)sf * Nb + i) * D;
-        float acc = 0.f;
-        for (int d = lane * 4; d < D; d += 256) {
-          const f32x4 x = *reinterpret_cast<const f32x4 *>(vrow + d);
-          const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + d);
-          acc = fmaf(x[0], w[0], acc);
-          acc = fmaf(x[1], w[1], acc);
-          acc = fmaf(x[2], w[2], acc);
-          acc = fmaf(x[3], w[3], acc);
-        }
+  const long item = (long)blockIdx.x * 4 + wave;
+  const int f = (int)(item / Qh), c = (int)(item - (long)f * Qh);
+  if (f >= F || c >= prefix[Na]) return;
+  const int a = find_seg(prefix, Na, c);
+  const int q = a * Ne + (c - prefix[a]);
+
+  f32x4 e = {-INFINITY, -INFINITY, 0.f, 0.f};
+  if (lane < nrb) e = part[((size_t)f * nrb + lane) * Qpad + c];
+  const int i1 = __float_as_int(e[2]), i2 = __float_as_int(e[3]);
+  float bm = e[0];
+  int bidx = i1;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (better(acc, i, eb, ei)) {
-          eb = acc;
-          ei = i;
-        }
-      }
-    }
-    if (lane == src) {
-      best = eb;
-      bi = ei;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(bm, o);
+    const int oi = __shfl_xor(bidx, o);
+    if (better(om, oi, bm, bidx)) {
+      bm = om;
+      bidx = oi;
     }
   }
-  if (in) {
-    S_max[idx] = live ? best : 0.f;      // masked query slot: the whole S_ column is 0 (model.py:551)
-    D_ind[idx] = live ? (int64_t)bi : (int64_t)0;
+  const float margin = 3.0517578125e-05f * (float)D + 4.8828125e-04f * fabsf(bm);   // 2^-15 * D + 2^-11 * |score|
+  unsigned long long c1 = __ballot(lane < nrb && bm - e[0] < margin);   // includes the winner (0 < margin)
+  unsigned long long c2 = __ballot(lane < nrb && bm - e[1] < margin);
+  // this lane's slice of the query row (D <= 1024: at most 4 pieces of 4 floats)
+  const float *wrow = Wm + (size_t)q * D;
+  f32x4 wf[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int d = lane * 4 + 256 * t;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    wf[t] = d < D ? *reinterpret_cast<const f32x4 *>(wrow + d) : z;
+  }
+  float eb = -INFINITY;
+  int ei = 0x7fffffff;
+  auto eval = [&](int i) {
+    const float *vrow = V + ((size_t)f * Nb + i) * D;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int d = lane * 4 + 256 * t;
+      if (d < D) {
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(vrow + d);
+        acc = fmaf(x[0], wf[t][0], acc);
+        acc = fmaf(x[1], wf[t][1], acc);
+        acc = fmaf(x[2], wf[t][2], acc);
+        acc = fmaf(x[3], wf[t][3], acc);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (better(acc, i, eb, ei)) {
+      eb = acc;
+      ei = i;
+    }
+  };
+  while (c1) {
+    const int src = __ffsll((long long)c1) - 1;
+    c1 &= c1 - 1;
+    eval(__shfl(i1, src));
+  }
+  while (c2) {
+    const int src = __ffsll((long long)c2) - 1;
+    c2 &= c2 - 1;
+    eval(__shfl(i2, src));
+  }
+  if (lane == 0) {
+    S_max[(size_t)f * Q + q] = eb;
+    D_ind[(size_t)f * Q + q] = (int64_t)ei;
   }
 }
 
 struct Plan {
-  int ok, NCB, NC, G, KS, RBW, RPW, nrb, TRB, NRG, NSG, Qpad;
+  int ok, NCB, NC, G, KS, RBW, RPW, nrb, TRB, NRG, NSG, Qpad, Qh;
   size_t lds;
   int64_t ws_bytes;
 };
@@ -395,7 +404,8 @@ inline Plan make_plan(int F, int Nb, int Na, int Ne, int D, int max_live) {
   const int Q = Na * Ne;
   int Qh = (max_live < 0 || max_live > Q) ? Q : max_live;
   if (Qh < 1) Qh = 1;
-  p.ok = (D % 32 == 0) && D <= 1024 && Na <= NA_MAX && F >= 1 && Nb >= 1;
+  p.Qh = Qh;
+  p.ok = (D % 32 == 0) && D <= 1024 && Na <= NA_MAX && F >= 1 && Nb >= 1 && Nb <= 2048;   // (Nb: <= 64 row blocks per frame)
   if (!p.ok) return p;
   p.NCB = (Qh <= 32 || D > 512) ? 1 : 2;
   p.NC = 32 * p.NCB;
@@ -466,9 +476,9 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
   else
     hipLaunchKernelGGL(sim_part_kernel<2>, dim3(grid), dim3(256), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
                        p.RPW, p.Qpad, part);
-  const long total = (long)F * Na * Ne;
-  hipLaunchKernelGGL(sim_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, V, W, ent_len, F, Nb, Na,
-                     Ne, D, p.nrb, p.Qpad, S_max, D_ind);
+  const long items = (long)F * p.Qh;
+  hipLaunchKernelGGL(sim_finish_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, part, V, W, ent_len, F, Nb, Na, Ne, D,
+                     p.nrb, p.Qpad, p.Qh, S_max, D_ind);
   return launch_status();
 }
 

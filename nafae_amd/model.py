@@ -292,8 +292,24 @@ class GroundModel(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------- helpers
+def auto_step_size(det, im_shape, device, need_roi_feats=True, lo=8, hi=512, budget_frac=0.4):
+    """Frames per detector launch for a streamed segment, sized to the HBM that is actually free instead of the reference's
+    fixed 64 (model.py:431): per frame the two 64-channel full-resolution activations that are alive together (4 B per element
+    in every arithmetic mode: fp32, or two bf16 planes) plus the per-ROI buffers (fc6 operand planes, optional fp32 pooled_feat,
+    fc6 / fc7 outputs).  With 288 GB per GPU this is the upper clamp (512) for 224 x 224 frames; the clamp keeps single
+    launches short enough for the copy stream to stay ahead."""
+    H, W = (im_shape[1], im_shape[2]) if im_shape[-1] == 3 else (im_shape[2], im_shape[3])
+    Nb = cfg.TEST.RPN_POST_NMS_TOP_N
+    per_frame = 2 * H * W * 64 * 4 + H * W * 3 * 4 + Nb * (512 * 49 * 4 * (2 if need_roi_feats else 1) + 3 * 4096 * 4)
+    free, _ = torch.cuda.mem_get_info(device)
+    return int(max(lo, min(hi, (budget_frac * free) // per_frame)))
+
+
 def stepRCNN(im_data, im_info, gt_boxes, num_boxes, ground_model, step_size=64, need_roi_feats=True):
     """model.py:429-454: run the detector over a long segment in chunks of `step_size` (64) frames.
+    `step_size=None` drops the fixed chunk: the chunk is sized from the free HBM (auto_step_size), which together with
+    `validate_epoch(max_frames=None)` removes the reference's 64-frame / 800-frame limits (model.py:431, :851-854) -- a
+    segment of any length streams through two pinned and two device buffers.
 
     `im_data` may be what the reference passes -- a float32 [Ns,3,H,W] tensor already on the GPU -- or, streamed
     (SURVEY.md section 8f.4), a HOST tensor: float32 [Ns,3,H,W], or raw decoded frames uint8 [Ns,H,W,3] (BGR; the -127.5 and
@@ -304,6 +320,8 @@ def stepRCNN(im_data, im_info, gt_boxes, num_boxes, ground_model, step_size=64, 
     validate() never reads (model.py:880-882); the second return value is then None."""
     det = ground_model.fasterRCNN
     Ns = im_data.shape[0]
+    if step_size is None:
+        step_size = auto_step_size(det, tuple(im_data.shape), next(det.parameters()).device, need_roi_feats)
     chunks = [(s, min(s + step_size, Ns)) for s in range(0, Ns, step_size)]
     rois_lst, roi_feats_lst, fc_feats_lst = [], [], []
     keep = getattr(det, "materialize_pooled", True)

@@ -294,7 +294,7 @@ def setup_training(args, device='cuda', seed=1234, distributed=False):
     return model, optimizer, criterion, reducer
 
 
-def validate_segment(model, batch, vid_entities, img_ids, args, dets):
+def validate_segment(model, batch, vid_entities, img_ids, args, dets, step_size=64):
     """Body of validate() for one video (model.py:869-947): chunked detector (stepRCNN), embeddings, DVSA in eval mode,
     postprocess, record_det.  `dets` = [img_inds, obj_labels, obj_bboxes, obj_confs] is appended to in place."""
     import numpy as np
@@ -304,7 +304,7 @@ def validate_segment(model, batch, vid_entities, img_ids, args, dets):
     Na, Ne = len(batch.entities_length), args.max_ent_len
     with torch.no_grad():
         rois, roi_feats, fc_feats = stepRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes, model,
-                                             need_roi_feats=False)     # validate() never reads roi_feats
+                                             step_size=step_size, need_roi_feats=False)     # validate() never reads roi_feats
         vis_feats = model.vis_ebd(fc_feats)
         word_feats = model.word_ebd(batch.glove_feats)
         D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
@@ -316,12 +316,13 @@ def validate_segment(model, batch, vid_entities, img_ids, args, dets):
 
 
 def validate_epoch(val_loader, model, glove, args, recs=None, class_list=None, device='cuda', raw_frames=False,
-                   result_path=None, max_frames=800):
+                   result_path=None, max_frames=800, step_size=64):
     """The reference's validate() (model.py:800-991) over any iterable of loader tuples: eval mode, per video the 800-frame
     cap (model.py:850-853), host preparation, chunked detector + embeddings + DVSA(eval) + postprocess + record_det
     (validate_segment); then the detection list [img_inds, obj_labels, obj_bboxes, obj_confs] is optionally pickled under
     the reference's file format (model.py:972-981) and scored with evaluate_box when ground-truth `recs` / `class_list`
-    (youcook_eval.parse_gt) are given.  Returns (accuracy or None, mean validation loss, dets)."""
+    (youcook_eval.parse_gt) are given.  `max_frames=None` lifts the 800-frame cap and `step_size=None` the fixed 64-frame
+    detector chunk (sized from the free HBM instead, model.auto_step_size).  Returns (accuracy or None, mean validation loss, dets)."""
     import pickle
     model.eval()
     model.DVSA.init_eval()
@@ -331,13 +332,13 @@ def validate_epoch(val_loader, model, glove, args, recs=None, class_list=None, d
         im_blobs, entities, entities_length, frm_length, rl_seg_inds, seg_nums, im_paths, img_ids = lb
         if max(entities_length) == 0:
             continue
-        if len(im_blobs) > max_frames:
+        if max_frames is not None and len(im_blobs) > max_frames:
             im_blobs, im_paths, img_ids = im_blobs[:max_frames], im_paths[:max_frames], img_ids[:max_frames]
         batch = prepare_batch((im_blobs, entities, entities_length, frm_length, rl_seg_inds, seg_nums, im_paths, img_ids), glove,
                               args, device=device, raw_frames=raw_frames)
         ents = list(entities)
         vid_entities = [[ents.pop(0) for _ in range(l)] for l in entities_length]      # model.py:906-909
-        losses.append(validate_segment(model, batch, vid_entities, list(img_ids), args, dets))
+        losses.append(validate_segment(model, batch, vid_entities, list(img_ids), args, dets, step_size=step_size))
     if result_path:
         with open(result_path, 'wb') as f:
             pickle.dump(dets, f)

@@ -21,6 +21,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
 
 
+def box_iou(a, b):
+    """IoU with the +1 width convention of the reference (nms_cuda_kernel.cu:31-39); a [n,4], b [m,4] -> [n,m]."""
+    x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.maximum(x2 - x1 + 1, 0) * np.maximum(y2 - y1 + 1, 0)
+    sa = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+    sb = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    return inter / (sa[:, None] + sb[None, :] - inter)
+
+
 def relerr(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -50,11 +60,15 @@ def c2():
 # precision: (base_feat / fc7 / V tolerance relative to tensor scale, min identical-ROI fraction, loss tolerance,
 #             min D_ind agreement on comparable entries, gradient tolerance)
 C2_BARS = {
-    "f32": dict(feat=1e-4, rois=0.995, loss=1e-4, dind=1.0, grad=5e-4),
-    "bf16x3": dict(feat=1e-4, rois=0.995, loss=1e-4, dind=1.0, grad=5e-4),
+    # measured (round 2): f32 8192/8192 identical rois, bf16x3 8182/8192 (59 of 64 frames with all 128 identical)
+    "f32": dict(feat=1e-4, rois=1.0, loss=1e-4, dind=1.0, grad=5e-4, ground=1.0),
+    "bf16x3": dict(feat=1e-4, rois=0.998, loss=1e-4, dind=1.0, grad=5e-4, ground=0.995),
     # BASELINE config C3: bf16 operands (8-bit mantissa), fp32 accumulation.  Stated tolerance: 3e-2 of the tensor scale on
-    # features, and proposals / grounding compared statistically (a 1e-2 feature error moves NMS decisions).
-    "bf16": dict(feat=3e-2, rois=0.5, loss=5e-2, dind=0.8, grad=None),
+    # features and 2e-2 on the loss; proposals and grounding are compared geometrically (a 1e-2 feature error moves box
+    # coordinates by more than 0.02 px and flips NMS decisions, so index-wise comparison is meaningless): the share of oracle
+    # proposals that have a HIP proposal with IoU >= 0.9 in the same frame, and the share of live (frame, query) pairs whose
+    # grounded box overlaps the oracle's grounded box with IoU >= 0.5.
+    "bf16": dict(feat=3e-2, rois=None, loss=2e-2, dind=None, grad=None, ground=None, roi_iou=0.5, ground_iou=0.3),
 }
 
 
@@ -77,8 +91,10 @@ def test_c2_full_size_detector_and_grounding(c2, precision, capsys):
                  relerr(base[F - 1].permute(2, 0, 1).cpu(), g["base_feat_f63"]) * np.abs(g["base_feat_f63"]).max()) / float(g["base_absmax"])
     rois, roi_scores, pooled, fc7 = fr(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
     assert tuple(rois.shape) == (F, Nb, 5) and tuple(fc7.shape) == (F * Nb, 4096)
-    same = (np.abs(rois.cpu().numpy() - g["rois"]) < 0.02).all(-1)                  # [F, Nb]: same proposal within 0.02 px
+    rois_np = rois.cpu().numpy()
+    same = (np.abs(rois_np - g["rois"]) < 0.02).all(-1)                             # [F, Nb]: same proposal within 0.02 px
     frame_ok = same.all(1)
+    roi_iou = np.mean([(box_iou(g["rois"][f_, :, 1:], rois_np[f_, :, 1:]).max(1) >= 0.9).mean() for f_ in range(F)])
     fr_rows = g["fc7_rows"]
     row_same = same.reshape(-1)[fr_rows]
     e_fc7 = float(np.abs(fc7[torch.from_numpy(fr_rows).cuda()].cpu().numpy()[row_same] - g["fc7_sample"][row_same]).max()
@@ -108,19 +124,31 @@ def test_c2_full_size_detector_and_grounding(c2, precision, capsys):
     dind_rate = float(agree[comparable & decided].mean()) if n_cmp else float("nan")
     n_close = int((comparable & ~decided).sum())
     e_sim = float(np.abs(D_sim.cpu().numpy() - g["D_sim"])[comparable].max() / scale) if comparable.any() else float("nan")
-    e_loss = abs(float(L) - float(g["loss"])) / abs(float(g["loss"]))
+    e_loss = abs(float(L.detach()) - float(g["loss"])) / abs(float(g["loss"]))
+    # grounded boxes (what the evaluation consumes): box of the arg-max proposal, HIP vs oracle, for every live (frame, query)
+    fi, qi = np.nonzero(np.broadcast_to(live.reshape(1, Q), (F, Q)))
+    gb_hip = rois_np[fi, Dg[fi, qi], 1:]
+    gb_ora = g["rois"][fi, g["D_ind"][fi, qi], 1:]
+    giou = np.array([box_iou(gb_hip[k:k + 1], gb_ora[k:k + 1])[0, 0] for k in range(len(fi))])
+    ground_same, ground_half = float((giou >= 0.999).mean()), float((giou >= 0.5).mean())
     with capsys.disabled():
         print("\n[C2 %-6s] base_feat %.2e | identical rois %.4f (%d/%d), frames with all %d rois identical %d/%d | fc7 %.2e | V %.2e W %.2e"
               " | D_ind agree %.5f on %d decided entries (%d near-ties excluded) | D_sim %.2e | loss %.6f vs %.6f (rel %.1e)"
+              " | oracle rois matched at IoU>=0.9: %.4f | grounded box identical %.4f, IoU>=0.5 %.4f (%d live pairs)"
               % (precision, e_base, same.mean(), same.sum(), same.size, Nb, frame_ok.sum(), F, e_fc7, e_V, e_W, dind_rate, n_cmp,
-                 n_close, e_sim, float(L), float(g["loss"]), e_loss))
+                 n_close, e_sim, float(L.detach()), float(g["loss"]), e_loss, roi_iou, ground_same, ground_half, len(fi)))
     assert e_base < bars["feat"], e_base
+    assert e_W < 1e-4
+    if precision == "bf16":
+        assert roi_iou >= bars["roi_iou"] and ground_half >= bars["ground_iou"], (roi_iou, ground_half)
+        assert e_loss < bars["loss"], e_loss
+        return
     assert same.mean() >= bars["rois"], same.mean()
     assert e_fc7 < bars["feat"], e_fc7
-    assert e_W < 1e-4 and (np.isnan(e_V) or e_V < bars["feat"])
+    assert np.isnan(e_V) or e_V < bars["feat"]
     assert n_cmp > 0 and dind_rate >= bars["dind"], (dind_rate, n_cmp)
-    if precision != "bf16":
-        assert e_sim < 1e-4, e_sim
+    assert ground_same >= bars["ground"], ground_same
+    assert e_sim < 1e-4, e_sim
     if frame_ok.all():
         assert e_loss < bars["loss"], e_loss
     else:       # a frame whose proposal set differs feeds different rows into the loss: bounded, not equal

@@ -23,9 +23,9 @@ def _ref(V, W, lens, Na, Nb, Ne):
     return m, i, gap, masked.expand(m.shape[0], Q)
 
 
-def _run(V, W, lens, Na, Ns, Nb, Ne, **kw):
+def _run(V, W, lens_dev, Na, Ns, Nb, Ne, **kw):
     from nafae_amd import ops
-    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    lt = torch.tensor(lens_dev, dtype=torch.int32, device="cuda")
     return ops.sim_max_fwd(V.cuda(), W.cuda(), lt, Na, Ns, Nb, Ne, **kw)
 
 
@@ -61,7 +61,7 @@ def test_sim_max_v2_matches_fp64(case, with_hint):
     S, Di = S.cpu().double(), Di.cpu()
     scale = max(float(m.abs().max()), 1e-6)
     assert (S[masked] == 0).all() and (Di[masked] == 0).all()
-    assert float((S - m).abs().max()) < 2e-5 * scale
+    assert float((S - m).abs().max()) < 2e-6 * scale             # S_max is an fp32 dot product of the winning pair
     bad = (Di != i) & ~masked & (gap > 1e-5 * scale)
     assert not bad.any(), "D_ind differs from the fp64 arg-max at %d decided entries" % int(bad.sum())
     # and the first-generation exact-fp32 kernel agrees with it wherever fp32 itself is decided
