@@ -282,6 +282,12 @@ int nafae_dropout_tanh(const float *x, const uint8_t *mask, float scale, float *
 /* g_in = g_out * (1 - y^2) * mask * scale.  */
 int nafae_dropout_tanh_bwd(const float *g_out, const float *y, const uint8_t *mask, float scale, float *g_in,
                            int64_t n, void *stream);
+/* The same pair with the keep mask generated in the kernel: element i is kept iff hash(seed, i) >= p * 2^32 (a counter-based
+ * generator: the backward regenerates the forward's decisions from the same seed), kept values are scaled by 1/(1-p).
+ * No mask tensor, no RNG launches.  0 <= p < 1.  */
+int nafae_dropout_tanh_seeded(const float *x, uint64_t seed, float p, float *y, int64_t n, void *stream);
+int nafae_dropout_tanh_bwd_seeded(const float *g_out, const float *y, uint64_t seed, float p, float *g_in, int64_t n,
+                                  void *stream);
 /* BatchNorm1d over rows of x [Q, D] (model.py:638,641).  training: batch statistics (biased variance for
  * the normalisation, unbiased for the running update, momentum 0.1) else running statistics.
  * save_mean / save_invstd: f32 [D] (written in training, used by the backward).  */

@@ -57,6 +57,8 @@ SIGNATURES = {
     "nafae_sim_bwd_frames": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "nafae_dropout_tanh": (c_int, [P, P, c_float, P, c_int64, P]),
     "nafae_dropout_tanh_bwd": (c_int, [P, P, P, c_float, P, c_int64, P]),
+    "nafae_dropout_tanh_seeded": (c_int, [P, ctypes.c_uint64, c_float, P, c_int64, P]),
+    "nafae_dropout_tanh_bwd_seeded": (c_int, [P, P, ctypes.c_uint64, c_float, P, c_int64, P]),
     "nafae_batchnorm_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "nafae_batchnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "nafae_colsum": (c_int, [P, P, c_int, c_int, P]),

@@ -566,6 +566,50 @@ __global__ __launch_bounds__(256) void dropout_tanh_bwd_kernel(const float *__re
   }
 }
 
+// Seeded dropout: the keep decision of element i is a pure function of (seed, i) -- Philox-style counter-based generation with
+// a 2 x 32-bit multiply-xorshift mix (not bit-compatible with torch's Philox stream, which nothing downstream depends on: the
+// reference draws its masks from the device generator, model.py:627,641) -- so no mask tensor is written by the forward or
+// read by the backward, and no torch RNG kernels run (rand + compare + cast = 3 launches and 36 MB of traffic per VisEbd call).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t i, uint32_t thresh) {
+  const uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
+  uint32_t h = mix32(lo ^ (uint32_t)seed);
+  h = mix32(h + hi * 0x9e3779b9U + (uint32_t)(seed >> 32));
+  return h >= thresh;                 // P(drop) = thresh / 2^32
+}
+
+__global__ __launch_bounds__(256) void dropout_tanh_seeded_kernel(const float *__restrict__ x, uint64_t seed, uint32_t thresh,
+                                                                  float scale, float *__restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = keep_elem(seed, (uint64_t)i * 4 + k, thresh) ? tanhf(v[k] * scale) : 0.f;
+    reinterpret_cast<f32x4 *>(y)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_tanh_bwd_seeded_kernel(const float *__restrict__ go, const float *__restrict__ y,
+                                                                      uint64_t seed, uint32_t thresh, float scale,
+                                                                      float *__restrict__ gi, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 g = reinterpret_cast<const f32x4 *>(go)[i];
+    const f32x4 t = reinterpret_cast<const f32x4 *>(y)[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      o[k] = keep_elem(seed, (uint64_t)i * 4 + k, thresh) ? g[k] * (1.0f - t[k] * t[k]) * scale : 0.f;
+    reinterpret_cast<f32x4 *>(gi)[i] = o;
+  }
+}
+
 // BatchNorm1d, one thread per feature column (Q is a few hundred rows at most)
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                      const float *__restrict__ b, float *__restrict__ rmean,
@@ -838,6 +882,30 @@ int nafae_dropout_tanh_bwd(const float *g_out, const float *y, const uint8_t *ma
   const long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(dropout_tanh_bwd_kernel, dim3(blocks), dim3(256), 0, S(stream), g_out, y, mask, scale, g_in, n4);
+  return launched();
+}
+
+static inline uint32_t drop_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+}
+
+int nafae_dropout_tanh_seeded(const float *x, uint64_t seed, float p, float *y, int64_t n, void *stream) {
+  if (!x || !y || n <= 0 || (n & 3) || !(p >= 0.f) || !(p < 1.f)) return NAFAE_EINVAL;
+  const long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(dropout_tanh_seeded_kernel, dim3(blocks), dim3(256), 0, S(stream), x, seed, drop_threshold(p),
+                     1.0f / (1.0f - p), y, n4);
+  return launched();
+}
+
+int nafae_dropout_tanh_bwd_seeded(const float *g_out, const float *y, uint64_t seed, float p, float *g_in, int64_t n,
+                                  void *stream) {
+  if (!g_out || !y || !g_in || n <= 0 || (n & 3) || !(p >= 0.f) || !(p < 1.f)) return NAFAE_EINVAL;
+  const long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(dropout_tanh_bwd_seeded_kernel, dim3(blocks), dim3(256), 0, S(stream), g_out, y, seed, drop_threshold(p),
+                     1.0f / (1.0f - p), g_in, n4);
   return launched();
 }
 

@@ -38,10 +38,21 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 using namespace nafae;
 
+#ifdef NAFAE_EXPERIMENTS
+// phase stamps of sim_part_kernel (experiments build only; scripts/sim_stamps.py): wall_clock64() = 100 MHz
+__device__ unsigned long long nafae_sim_stamps[8 * 4096];
+#define STAMP(k)                                                                              \
+  do {                                                                                        \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)                                          \
+      nafae_sim_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64();     \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int NA_MAX = 2048;   // segments per batch the live-column prefix table holds (LDS)
-constexpr int NBUF = 4;        // 32-k chunks of V in flight per wave (4 x 4 KB)
 
 __device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
@@ -98,14 +109,30 @@ __device__ __forceinline__ f32x4 pack_part(float m1, int i1, float m2, int i2) {
 }
 
 // ---------------------------------------------------------------------------------------------------- partial kernel
-// grid: ceil(NSG / 8) * 8 * G workgroups of 256 threads, NSG = number of row super-groups (RPW row groups each).
-// LDS: [W planes: D * NC * 4 B][qmap: NC ints][scratch: max((Na+1) ints, (4 - RBW) * NCB * 4 KB)]
-template <int NCB>
-__global__ __launch_bounds__(256) void sim_part_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
+// grid: ceil(NSG / 8) * 8 * G workgroups of NW waves (NW = 4 or 8 = blockDim.x / 64), NSG = number of row super-groups (RPW
+// row groups each); a row group = RBW = NW / KS row blocks of 32 proposals.  One 32-column group of live queries per workgroup.
+// LDS: [W planes: D * 32 * 4 B][qmap: 32 ints][scratch: max((Na+1) ints, (NW - RBW) * 4 KB)][V rings: NW * NB * 4 KB]
+//
+// V path: each wave streams ITS 32 rows through its own LDS ring of NB chunks (a chunk = 32 rows x 32 k fp32 = 4 KB) with
+// LDS-DMA (global_load_lds_dwordx4): an instruction covers 8 rows x one full 128-B line, so every L1/TA request is a whole
+// line (loading the MFMA A fragments straight from global memory touches 32 lines per instruction for 32 B each and ran at
+// ~13 B/clk/CU, measured -- the kernel was TA bound at 1/5 of the L2 rate).  The 16-B slots of a row are XOR-swizzled by
+// (row >> 1) & 7 on the SOURCE address (DMA destinations are lane-linear), and un-swizzled by the ds_read_b128 fragment
+// reads, which are then conflict-free in every 16-lane group.  The ring is wave-private: the wave's own counted
+// s_waitcnt vmcnt orders its DMA against its reads, no barrier in the k-loop.
+constexpr int CHUNK_BYTES = 32 * 128;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void sim_part_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
                                                        const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
-                                                       int D, int nrb, int G, int KS, int RPW, int Qpad,
+                                                       int D, int nrb, int G, int KS, int RPW, int Qpad, int scratch_bytes,
                                                        f32x4 *__restrict__ part) {
-  constexpr int NC = 32 * NCB;
+  constexpr int NC = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *wl = smem;                                           // bf16 fragments of W
   int *qmap = reinterpret_cast<int *>(smem + (size_t)D * NC * 4);
@@ -113,8 +140,10 @@ __global__ __launch_bounds__(256) void sim_part_kernel(const float *__restrict__
   int *prefix = reinterpret_cast<int *>(scr);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = blockDim.x, NW = NT >> 6;
+  unsigned char *ring = scr + scratch_bytes + (size_t)wave * NB * CHUNK_BYTES;   // this wave's V ring
   const int lr = lane & 31, h = lane >> 5;
-  const int RBW = 4 / KS;
+  const int RBW = NW / KS;
   const int rbi = wave / KS, ks = wave - rbi * KS;
   const int TRB = F * nrb;
   const int NRG = (TRB + RBW - 1) / RBW;
@@ -123,42 +152,28 @@ __global__ __launch_bounds__(256) void sim_part_kernel(const float *__restrict__
   const int sg = (blk8 / G) * 8 + (blockIdx.x & 7);
   const int g = blk8 % G;
   if (sg >= NSG) return;
+  STAMP(0);
 
-  const int nchunks = D >> 5;
-  const int cpw = nchunks / KS;          // 32-k chunks this wave contracts
-  const int c0 = ks * cpw;
-
-  // ---- this wave's rows for row group `rho`, and its V prefetch ring
-  f32x4 ring[NBUF][4];
-  const float *vrow = V;
-  auto set_rows = [&](int rho, bool &active, int &rb, int &b0) {
-    rb = rho * RBW + rbi;
-    active = rb < TRB;
-    const int rbc = active ? rb : TRB - 1;
-    const int f = rbc / nrb;
-    b0 = (rbc - f * nrb) * 32;
-    int row = b0 + lr;
-    row = row < Nb ? row : Nb - 1;
-    vrow = V + ((size_t)f * Nb + row) * D + (size_t)c0 * 32 + 8 * h;
-  };
-  auto load_chunk = [&](int j, int ci) {
-    const int cc = ci < cpw ? ci : cpw - 1;
-    const float *p = vrow + (size_t)cc * 32;
-    ring[j][0] = *reinterpret_cast<const f32x4 *>(p);
-    ring[j][1] = *reinterpret_cast<const f32x4 *>(p + 4);
-    ring[j][2] = *reinterpret_cast<const f32x4 *>(p + 16);
-    ring[j][3] = *reinterpret_cast<const f32x4 *>(p + 20);
-  };
-  bool active;
-  int rb, b0;
-  const int rho0 = sg * RPW;
-  set_rows(rho0, active, rb, b0);
+  // ---- live columns of this column group: exclusive prefix of the clamped entity counts (wave 0), then the column map
+  if (wave == 0) {
+    int carry = 0;
+    for (int base = 0; base < Na; base += 64) {
+      const int a = base + lane;
+      int x = a < Na ? ent_len[a] : 0;
+      x = x < 0 ? 0 : (x > Ne ? Ne : x);
+      int incl = x;
 #pragma unroll
-  for (int j = 0; j < NBUF; j++) load_chunk(j, j);
-
-  // ---- live columns of this column group
-  build_prefix(ent_len, Na, Ne, prefix);
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (a < Na) prefix[a] = carry + incl - x;
+      carry += __shfl(incl, 63);
+    }
+    if (lane == 0) prefix[Na] = carry;
+  }
   __syncthreads();
+  STAMP(1);
   const int Ql = prefix[Na];
   if (g * NC >= Ql) return;              // over-provisioned column group (the host only knows an upper bound)
   if (tid < NC) {
@@ -171,124 +186,185 @@ __global__ __launch_bounds__(256) void sim_part_kernel(const float *__restrict__
     qmap[tid] = q;
   }
   __syncthreads();
-  // ---- W -> bf16 hi/lo fragments in LDS: 16-B slot of (k-step s, half hh, plane, column cl) at (((s*2+hh)*2+plane)*NC+cl)*16
-  {
-    const int k4n = D >> 2;
-    for (int idx = tid; idx < NC * k4n; idx += 256) {
-      const int cl = idx / k4n, k4 = idx - cl * k4n;
-      const int q = qmap[cl];
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (q >= 0) w = *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + k4 * 4);
-      bf16x4 whi, wlo;
+  STAMP(2);
+
+  const int nchunks = D >> 5;
+  const int cpw = nchunks / KS;          // 32-k chunks this wave contracts
+  const int c0 = ks * cpw;
+
+  // ---- this wave's rows for row group `rho`; DMA lane l of instruction j moves row 8j + l/8, physical slot l%8
+  const float *vsrc[4];
+  bool active;
+  int rb, b0;
+  auto set_rows = [&](int rho) {
+    rb = rho * RBW + rbi;
+    active = rb < TRB;
+    const int rbc = active ? rb : TRB - 1;
+    const int f = rbc / nrb;
+    b0 = (rbc - f * nrb) * 32;
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const __bf16 t = (__bf16)w[e];
-        whi[e] = t;
-        wlo[e] = (__bf16)(w[e] - (float)t);
+    for (int j = 0; j < 4; j++) {
+      const int rl = 8 * j + (lane >> 3);
+      int row = b0 + rl;
+      row = row < Nb ? row : Nb - 1;
+      const int slot = (lane & 7) ^ ((rl >> 1) & 7);
+      vsrc[j] = V + ((size_t)f * Nb + row) * D + (size_t)c0 * 32 + slot * 4;
+    }
+  };
+  auto dma_chunk = [&](int ci) {         // chunk ci of this wave's k-range -> ring slot ci % NB
+    unsigned char *dst = ring + (size_t)(ci % NB) * CHUNK_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc[j] + (size_t)ci * 32),
+                                       (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+  };
+  const int rho0 = sg * RPW;
+  set_rows(rho0);
+
+  // ---- W -> bf16 hi/lo fragments in LDS: 16-B slot of (k-step s, half hh, plane, column cl) at (((s*2+hh)*2+plane)*NC+cl)*16.
+  // U independent 16-B loads per thread are issued before the first one is converted; (column, k4) advance incrementally.
+  // The V ring is started right BEHIND the first batch of W loads: the conversion's wait then covers both (vmcnt retires in
+  // order), and the first chunks are in LDS when the k-loop starts.
+  {
+    constexpr int U = 16;
+    const int k4n = D >> 2;
+    const int total = NC * k4n;
+    const int dcl = NT / k4n, dk4 = NT - dcl * k4n;       // one step of NT float4s in (column, k4) coordinates
+    int cl = tid / k4n, k4 = tid - cl * k4n;
+    bool ring_started = false;
+    for (int base = tid; base < total || !ring_started; base += NT * U) {
+      f32x4 w[U];
+      int off[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool ok = cl < NC;
+        const int q = ok ? qmap[cl] : -1;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        w[u] = q >= 0 ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + k4 * 4) : z;
+        const int k = k4 * 4;
+        off[u] = ok ? (((k >> 3) * 2) * NC + cl) * 16 + (k & 4) * 2 : -1;
+        cl += dcl;
+        k4 += dk4;
+        if (k4 >= k4n) {
+          k4 -= k4n;
+          cl += 1;
+        }
       }
-      const int k = k4 * 4;
-      const int s2h = k >> 3;            // = s*2 + hh
-      const int off = ((s2h * 2) * NC + cl) * 16 + (k & 4) * 2;
-      *reinterpret_cast<bf16x4 *>(wl + off) = whi;
-      *reinterpret_cast<bf16x4 *>(wl + off + NC * 16) = wlo;
+      if (!ring_started) {
+        for (int ci = 0; ci < NB && ci < cpw; ci++) dma_chunk(ci);
+        ring_started = true;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        bf16x4 whi, wlo;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const __bf16 t = (__bf16)w[u][e];
+          whi[e] = t;
+          wlo[e] = (__bf16)(w[u][e] - (float)t);
+        }
+        if (off[u] >= 0) {
+          *reinterpret_cast<bf16x4 *>(wl + off[u]) = whi;
+          *reinterpret_cast<bf16x4 *>(wl + off[u] + NC * 16) = wlo;
+        }
+      }
     }
   }
   __syncthreads();
+  STAMP(3);
 
-  const unsigned char *bbase = wl + (size_t)(h * 2 * NC + lr) * 16;   // + s*4*NC*16 + plane*NC*16 + cb*512
+  const unsigned char *bbase = wl + (size_t)(h * 2 * NC + lr) * 16;   // + s*4*NC*16 + plane*NC*16
+  const int aswz = (lr >> 1) & 7;
   for (int rr = 0; rr < RPW; rr++) {
     const int rho = rho0 + rr;
     if (rho >= NRG) break;
     if (rr > 0) {
-      set_rows(rho, active, rb, b0);
-#pragma unroll
-      for (int j = 0; j < NBUF; j++) load_chunk(j, j);
+      set_rows(rho);
+      for (int ci = 0; ci < NB && ci < cpw; ci++) dma_chunk(ci);
     }
-    f32x16 acc[NCB];
+    f32x16 acc;
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
-    for (int base = 0; base < cpw; base += NBUF) {
+    for (int ci = 0; ci < cpw; ci++) {
+      // chunk ci has landed once at most the (NB-1) younger chunks' DMAs are outstanding; near the end fewer are younger
+      if (ci + NB - 1 < cpw) wait_vm<4 * (NB - 1)>(); else wait_vm<0>();
+      const unsigned char *ap = ring + (size_t)(ci % NB) * CHUNK_BYTES + lr * 128;
+      bf16x8 ahi[2], alo[2];
 #pragma unroll
-      for (int j = 0; j < NBUF; j++) {
-        const int ci = base + j;
-        if (ci < cpw && active) {
+      for (int t = 0; t < 2; t++) {
+        const int s0 = 4 * t + 2 * h;
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(ap + ((s0 ^ aswz) << 4));
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(ap + (((s0 + 1) ^ aswz) << 4));
+        split8(x0, x1, ahi[t], alo[t]);
+      }
+      // the fragments are in registers: the slot can be refilled (the DMA is ordered behind these reads by lgkmcnt(0))
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ci + NB < cpw) dma_chunk(ci + NB);
+      if (active) {
 #pragma unroll
-          for (int t = 0; t < 2; t++) {
-            bf16x8 ahi, alo;
-            split8(ring[j][2 * t], ring[j][2 * t + 1], ahi, alo);
-            const unsigned char *bp = bbase + (size_t)((c0 + ci) * 2 + t) * (4 * NC * 16);
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) {
-              const bf16x8 bhi = *reinterpret_cast<const bf16x8 *>(bp + cb * 512);
-              const bf16x8 blo = *reinterpret_cast<const bf16x8 *>(bp + NC * 16 + cb * 512);
-              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[cb], 0, 0, 0);
-              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[cb], 0, 0, 0);
-              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[cb], 0, 0, 0);
-            }
-          }
+        for (int t = 0; t < 2; t++) {
+          const unsigned char *bp = bbase + (size_t)((c0 + ci) * 2 + t) * (4 * NC * 16);
+          const bf16x8 bhi = *reinterpret_cast<const bf16x8 *>(bp);
+          const bf16x8 blo = *reinterpret_cast<const bf16x8 *>(bp + NC * 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], bhi, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], blo, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], bhi, acc, 0, 0, 0);
         }
-        load_chunk(j, ci + NBUF);
       }
     }
+    STAMP(4);
 
-    if (KS > 1) {          // sum the k-splits of a row block in a fixed order (ks = 1, 2, 3 onto ks = 0)
+    if (KS > 1) {          // sum the k-splits of a row block in a fixed order (ks = 1, 2, ... onto ks = 0)
       float *sc = reinterpret_cast<float *>(scr);
       __syncthreads();     // (first trip: everyone is done with the prefix table that aliases the scratch)
       if (ks > 0) {
-        float *dst = sc + (size_t)((rbi * (KS - 1) + (ks - 1)) * NCB) * 16 * 64 + lane;
+        float *dst = sc + (size_t)(rbi * (KS - 1) + (ks - 1)) * 16 * 64 + lane;
 #pragma unroll
-        for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) dst[(cb * 16 + r) * 64] = acc[cb][r];
+        for (int r = 0; r < 16; r++) dst[r * 64] = acc[r];
       }
       __syncthreads();
       if (ks == 0) {
         for (int k = 1; k < KS; k++) {
-          const float *src = sc + (size_t)((rbi * (KS - 1) + (k - 1)) * NCB) * 16 * 64 + lane;
+          const float *src = sc + (size_t)(rbi * (KS - 1) + (k - 1)) * 16 * 64 + lane;
 #pragma unroll
-          for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[cb][r] += src[(cb * 16 + r) * 64];
+          for (int r = 0; r < 16; r++) acc[r] += src[r * 64];
         }
       }
     }
 
+    STAMP(5);
     if (ks == 0 && active) {
+      float m1 = -INFINITY, m2 = -INFINITY;
+      int i1 = 0, i2 = 0;
 #pragma unroll
-      for (int cb = 0; cb < NCB; cb++) {
-        float m1 = -INFINITY, m2 = -INFINITY;
-        int i1 = 0, i2 = 0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {       // this lane's rows in ascending order
-          const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float v = acc[cb][r];
-          if (row < Nb) {
-            if (v > m1) {
-              m2 = m1; i2 = i1; m1 = v; i1 = row;
-            } else if (v > m2) {
-              m2 = v; i2 = row;
-            }
+      for (int r = 0; r < 16; r++) {       // this lane's rows in ascending order
+        const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[r];
+        if (row < Nb) {
+          if (v > m1) {
+            m2 = m1; i2 = i1; m1 = v; i1 = row;
+          } else if (v > m2) {
+            m2 = v; i2 = row;
           }
         }
-        // merge with the other half of the column (lane ^ 32), ordering (value desc, index asc)
-        const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
-        const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
-        float n1, n2;
-        int k1, k2;
-        if (better(o1, j1, m1, i1)) {
-          n1 = o1; k1 = j1;
-          if (better(m1, i1, o2, j2)) { n2 = m1; k2 = i1; } else { n2 = o2; k2 = j2; }
-        } else {
-          n1 = m1; k1 = i1;
-          if (better(m2, i2, o1, j1)) { n2 = m2; k2 = i2; } else { n2 = o1; k2 = j1; }
-        }
-        const int c = g * NC + cb * 32 + lr;
-        if (h == 0 && c < Ql) part[(size_t)rb * Qpad + c] = pack_part(n1, k1, n2, k2);
       }
+      // merge with the other half of the column (lane ^ 32), ordering (value desc, index asc)
+      const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+      const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
+      float n1, n2;
+      int k1, k2;
+      if (better(o1, j1, m1, i1)) {
+        n1 = o1; k1 = j1;
+        if (better(m1, i1, o2, j2)) { n2 = m1; k2 = i1; } else { n2 = o2; k2 = j2; }
+      } else {
+        n1 = m1; k1 = i1;
+        if (better(m2, i2, o1, j1)) { n2 = m2; k2 = i2; } else { n2 = o1; k2 = j1; }
+      }
+      const int c = g * NC + lr;
+      if (h == 0 && c < Ql) part[(size_t)rb * Qpad + c] = pack_part(n1, k1, n2, k2);
     }
+    STAMP(6);
   }
 }
 
@@ -330,6 +406,15 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict
 
   f32x4 e = {-INFINITY, -INFINITY, 0.f, 0.f};
   if (lane < nrb) e = part[((size_t)f * nrb + lane) * Qpad + c];
+  // this lane's slice of the query row (D <= 1024: at most 4 pieces of 4 floats); requested beside the partials
+  const float *wrow = Wm + (size_t)q * D;
+  f32x4 wf[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int d = lane * 4 + 256 * t;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    wf[t] = d < D ? *reinterpret_cast<const f32x4 *>(wrow + d) : z;
+  }
   const int i1 = __float_as_int(e[2]), i2 = __float_as_int(e[3]);
   float bm = e[0];
   int bidx = i1;
@@ -345,15 +430,6 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict
   const float margin = 3.0517578125e-05f * (float)D + 4.8828125e-04f * fabsf(bm);   // 2^-15 * D + 2^-11 * |score|
   unsigned long long c1 = __ballot(lane < nrb && bm - e[0] < margin);   // includes the winner (0 < margin)
   unsigned long long c2 = __ballot(lane < nrb && bm - e[1] < margin);
-  // this lane's slice of the query row (D <= 1024: at most 4 pieces of 4 floats)
-  const float *wrow = Wm + (size_t)q * D;
-  f32x4 wf[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    const int d = lane * 4 + 256 * t;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    wf[t] = d < D ? *reinterpret_cast<const f32x4 *>(wrow + d) : z;
-  }
   float eb = -INFINITY;
   int ei = 0x7fffffff;
   auto eval = [&](int i) {
@@ -394,7 +470,7 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict
 }
 
 struct Plan {
-  int ok, NCB, NC, G, KS, RBW, RPW, nrb, TRB, NRG, NSG, Qpad, Qh;
+  int ok, NCB, NC, G, KS, RBW, RPW, NW, NB, scratch, nrb, TRB, NRG, NSG, Qpad, Qh;
   size_t lds;
   int64_t ws_bytes;
 };
@@ -405,32 +481,41 @@ inline Plan make_plan(int F, int Nb, int Na, int Ne, int D, int max_live) {
   int Qh = (max_live < 0 || max_live > Q) ? Q : max_live;
   if (Qh < 1) Qh = 1;
   p.Qh = Qh;
-  p.ok = (D % 32 == 0) && D <= 1024 && Na <= NA_MAX && F >= 1 && Nb >= 1 && Nb <= 2048;   // (Nb: <= 64 row blocks per frame)
+  p.ok = (D % 32 == 0) && D <= 512 && Na <= NA_MAX && F >= 1 && Nb >= 1 && Nb <= 2048;   // (Nb: <= 64 row blocks per frame)
   if (!p.ok) return p;
-  p.NCB = (Qh <= 32 || D > 512) ? 1 : 2;
-  p.NC = 32 * p.NCB;
+  p.NCB = 1;
+  p.NC = 32;
   p.G = (Qh + p.NC - 1) / p.NC;
   p.nrb = (Nb + 31) / 32;
   p.TRB = F * p.nrb;
   const int nchunks = D / 32;
+  // One workgroup fits per CU (W planes + rings ~ 156 KB of LDS).  K is split over the waves of a workgroup only while
+  // 4-wave workgroups of whole row blocks would leave CUs without any workgroup (fewer than 1024 row blocks x column
+  // groups); workgroups have 8 waves (two per SIMD, 2-chunk rings) once every CU gets at least 8 waves of work anyway,
+  // else 4 (5-chunk rings: 80 KB of V in flight per CU, what it takes to pull ~25 GB/s per CU out of HBM).
   int KS = 1;
-  while (KS < 4 && (long)p.TRB * p.G * KS < 1024 && nchunks % (KS * 2) == 0 && nchunks / (KS * 2) >= 2) KS *= 2;
+  while (KS < 4 && (long)p.TRB * p.G * KS * 2 <= 1024 && nchunks % (KS * 2) == 0 && nchunks / (KS * 2) >= 2) KS *= 2;
   p.KS = KS;
-  p.RBW = 4 / KS;
+  p.NW = (KS == 1 && (long)p.TRB * p.G >= 8L * 256) ? 8 : 4;
+  p.RBW = p.NW / KS;
+  p.NB = p.NW == 8 ? 2 : 5;
+  const size_t scratch_ks = (size_t)(p.NW - p.RBW) * 16 * 64 * 4;
+  const size_t scratch_px = (((size_t)(Na + 1) * 4) + 15) & ~(size_t)15;
+  p.scratch = (int)(scratch_ks > scratch_px ? scratch_ks : scratch_px);
+  p.lds = (size_t)D * p.NC * 4 + p.NC * 4 + p.scratch + (size_t)p.NW * p.NB * CHUNK_BYTES;
+  if (p.lds > 160 * 1024) {
+    p.ok = 0;
+    return p;
+  }
   p.NRG = (p.TRB + p.RBW - 1) / p.RBW;
-  const int occ = p.NCB == 1 && D <= 512 ? 2 : 1;                 // workgroups per CU the LDS footprint allows
-  long units = (long)p.NRG * p.G;
-  int RPW = (int)(units / (256L * occ));
+  // row groups per workgroup: one round of workgroups over the chip (W is converted once per workgroup)
+  const long units = (long)p.NRG * p.G;
+  long RPW = (units + 255) / 256;
   if (RPW < 1) RPW = 1;
   if (RPW > 16) RPW = 16;
-  p.RPW = RPW;
-  p.NSG = (p.NRG + RPW - 1) / RPW;
+  p.RPW = (int)RPW;
+  p.NSG = (p.NRG + p.RPW - 1) / p.RPW;
   p.Qpad = p.G * p.NC;
-  const size_t scratch_ks = (size_t)(4 - p.RBW) * p.NCB * 16 * 64 * 4;
-  const size_t scratch_px = (size_t)(Na + 1) * 4;
-  p.lds = (size_t)D * p.NC * 4 + p.NC * 4 + (scratch_ks > scratch_px ? scratch_ks : scratch_px);
-  p.lds = (p.lds + 15) & ~(size_t)15;
-  if (p.lds > 160 * 1024) p.ok = 0;
   p.ws_bytes = (int64_t)p.TRB * p.Qpad * 16;
   return p;
 }
@@ -438,6 +523,12 @@ inline Plan make_plan(int F, int Nb, int Na, int Ne, int D, int max_live) {
 }  // namespace
 
 extern "C" {
+
+#ifdef NAFAE_EXPERIMENTS
+int nafae_sim_debug_stamps(unsigned long long *out_host, int n) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(nafae_sim_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#endif
 
 // exact-fp32 first-generation kernel (simloss.hip): the fallback for shapes this file does not take
 int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
@@ -461,8 +552,8 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
   if (!p.ok) return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
   if (!workspace || workspace_bytes < p.ws_bytes) return NAFAE_EINVAL;
   if ((long)F * Na * Ne > (1L << 31) - 256) return NAFAE_ELIMIT;
-  const void *kern = p.NCB == 1 ? reinterpret_cast<const void *>(sim_part_kernel<1>)
-                                : reinterpret_cast<const void *>(sim_part_kernel<2>);
+  const void *kern = p.NB == 2 ? reinterpret_cast<const void *>(sim_part_kernel<2>)
+                               : reinterpret_cast<const void *>(sim_part_kernel<5>);
   if (p.lds > 64 * 1024) {
     const int rc = allow_dynamic_lds(kern, 160 * 1024);
     if (rc != NAFAE_OK) return rc;
@@ -470,12 +561,12 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
   const int grid = ((p.NSG + 7) / 8) * 8 * p.G;
   f32x4 *part = reinterpret_cast<f32x4 *>(workspace);
   hipStream_t st = as_stream(stream);
-  if (p.NCB == 1)
-    hipLaunchKernelGGL(sim_part_kernel<1>, dim3(grid), dim3(256), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
-                       p.RPW, p.Qpad, part);
+  if (p.NB == 2)
+    hipLaunchKernelGGL(sim_part_kernel<2>, dim3(grid), dim3(64 * p.NW), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
+                       p.RPW, p.Qpad, p.scratch, part);
   else
-    hipLaunchKernelGGL(sim_part_kernel<2>, dim3(grid), dim3(256), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
-                       p.RPW, p.Qpad, part);
+    hipLaunchKernelGGL(sim_part_kernel<5>, dim3(grid), dim3(64 * p.NW), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
+                       p.RPW, p.Qpad, p.scratch, part);
   const long items = (long)F * p.Qh;
   hipLaunchKernelGGL(sim_finish_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, part, V, W, ent_len, F, Nb, Na, Ne, D,
                      p.nrb, p.Qpad, p.Qh, S_max, D_ind);

@@ -88,6 +88,10 @@ class _fasterRCNN(nn.Module):
         self.precision = os.environ.get("NAFAE_PRECISION", "bf16x3")
         self.materialize_pooled = True     # bf16 modes: also hand out pooled_feat as fp32 (API parity)
         self.conv_streams = int(os.environ.get("NAFAE_CONV_STREAMS", "1"))
+        # stream-K schedule of the quantised conv layers (nafae_conv3x3_bf16_ws with a workspace).  Which tiles it cuts -- hence
+        # the fp32 order their partial sums are added in -- depends on the number of frames in the call; False = one tile per
+        # workgroup, whose results do not depend on the batch size in the last bit (multi-rank equality tests use that)
+        self.conv_stream_k = True
         self._streams = None
 
     # ------------------------------------------------------------------ weights -> kernel layout
@@ -162,10 +166,10 @@ class _fasterRCNN(nn.Module):
                 w, b = P['convs_h'][li]
                 li += 1
                 if k + 1 < len(seq) and seq[k + 1] == 'M':       # conv + ReLU + max-pool: fused where the library can
-                    _, x = ops.conv3x3_bf16(x, w, b, relu=True, pool=True)
+                    _, x = ops.conv3x3_bf16(x, w, b, relu=True, pool=True, use_workspace=self.conv_stream_k)
                     k += 2
                 else:
-                    _, x = ops.conv3x3_bf16(x, w, b, relu=True)
+                    _, x = ops.conv3x3_bf16(x, w, b, relu=True, use_workspace=self.conv_stream_k)
                     k += 1
             return x
         x = ops.conv1_3x3_relu(im_data.contiguous(), P['conv1_w'], P['conv1_b'])
@@ -224,7 +228,8 @@ class _fasterRCNN(nn.Module):
         r = self.RCNN_rpn
         A = r.nc_score_out // 2
         if self.precision != 'f32':
-            x, _ = ops.conv3x3_bf16(base_feat, P['rpn_w_h'], P['rpn_b'], relu=True, want_f32=True, want_planes=False)
+            x, _ = ops.conv3x3_bf16(base_feat, P['rpn_w_h'], P['rpn_b'], relu=True, want_f32=True, want_planes=False,
+                                    use_workspace=self.conv_stream_k)
         else:
             x = ops.conv3x3_relu(base_feat, P['rpn_w'], P['rpn_b'], relu=True)
         head = ops.gemm_nt(x.view(F * h * w, 512), P['head_w'], P['head_b'])

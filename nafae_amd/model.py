@@ -90,16 +90,45 @@ def default_args(**over):
 
 # ---------------------------------------------------------------------------------------------------- autograd glue
 def _drop_mask(shape, p, device, generator=None):
-    """Bernoulli keep mask for nn.Dropout(p) in train mode (random numbers are plumbing, like the allocator).
-    `generator`: draw from this torch.Generator instead of the device's default one (shared-seed masks, exact DP mode)."""
+    """Explicit Bernoulli keep mask (uint8) for nn.Dropout(p): the legacy / test form of the dropout argument."""
     return (torch.rand(shape, device=device, generator=generator) >= p).to(torch.uint8)
+
+
+class DropSeed:
+    """nn.Dropout(p) in train mode as a (seed, p) pair: the kernels derive the keep decision of element i from hash(seed, i),
+    so neither a mask tensor nor any RNG launch exists (random numbers are plumbing, like the allocator).  The seed is drawn on
+    the HOST from torch's default CPU generator (so torch.manual_seed governs it) or from `generator` (a CPU torch.Generator:
+    ranks that must agree on a mask share its seed, exact DP mode)."""
+    __slots__ = ("seed", "p")
+
+    def __init__(self, p, generator=None):
+        self.seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device='cpu'))
+        self.p = float(p)
+
+
+def _tanh_drop(x, drop):
+    if isinstance(drop, DropSeed):
+        return ops.dropout_tanh_seeded(x, drop.seed, drop.p)
+    if drop is None:
+        return ops.dropout_tanh(x, None, 1.0)
+    mask, scale = drop                                   # explicit (uint8 mask, scale)
+    return ops.dropout_tanh(x, mask, scale)
+
+
+def _tanh_drop_bwd(gy, y, drop):
+    if isinstance(drop, DropSeed):
+        return ops.dropout_tanh_bwd_seeded(gy, y, drop.seed, drop.p)
+    if drop is None:
+        return ops.dropout_tanh_bwd(gy, y, None, 1.0)
+    mask, scale = drop
+    return ops.dropout_tanh_bwd(gy, y, mask, scale)
 
 
 class _VisEbdFn(torch.autograd.Function):
     """tanh(drop(fc1(x / 100)))  -- model.py:624-629."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, mask, scale, planes=None):
+    def forward(ctx, feats, weight, bias, drop, planes=None):
         with ops.timed("vis_ebd"):
             if planes is not None:
                 # fc7 arrived with its split-bf16 planes (detector in 'bf16x3' mode): the same 3-MFMA arithmetic as fc6 / fc7
@@ -108,46 +137,46 @@ class _VisEbdFn(torch.autograd.Function):
                 pre, _ = ops.gemm_nt_bf16(planes, wp, bias, alpha=0.01, want_f32=True, want_planes=False)
             else:
                 pre = ops.gemm_nt(feats, weight, bias, alpha=0.01)  # (x/100) W^T + b  ==  0.01 (x W^T) + b
-            y = ops.dropout_tanh(pre, mask, scale)
-        ctx.save_for_backward(feats, y, mask)
-        ctx.scale = scale
+            y = _tanh_drop(pre, drop)
+        ctx.save_for_backward(feats, y)
+        ctx.drop = drop
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        feats, y, mask = ctx.saved_tensors
+        feats, y = ctx.saved_tensors
         with ops.timed("vis_ebd_bwd"):
-            gpre = ops.dropout_tanh_bwd(gy.contiguous(), y, mask, ctx.scale)
+            gpre = _tanh_drop_bwd(gy.contiguous(), y, ctx.drop)
             # only the arg-max (and clustering) rows carry gradient: contract over those rows alone
             rows, count = ops.nonzero_rows(gpre)
             gw = ops.gemm_tn_rows(gpre, feats, rows, count, alpha=0.01)   # [D, 4096]
             gb = ops.colsum(gpre)
-        return None, gw, gb, None, None, None
+        return None, gw, gb, None, None
 
 
 class _WordEbdFn(torch.autograd.Function):
     """tanh(drop(bn(fc1(x))))  -- model.py:640-642."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, bn_w, bn_b, run_mean, run_var, training, momentum, eps, mask, scale):
+    def forward(ctx, feats, weight, bias, bn_w, bn_b, run_mean, run_var, training, momentum, eps, drop):
         with ops.timed("word_ebd"):
             lin = ops.gemm_nt(feats, weight, bias)
             bn, save_mean, save_invstd = ops.batchnorm_fwd(lin, bn_w, bn_b, run_mean, run_var, training, momentum, eps)
-            y = ops.dropout_tanh(bn, mask, scale)
-        ctx.save_for_backward(feats, lin, bn_w, save_mean, save_invstd, y, mask, run_var)
-        ctx.scale, ctx.training, ctx.eps = scale, training, eps
+            y = _tanh_drop(bn, drop)
+        ctx.save_for_backward(feats, lin, bn_w, save_mean, save_invstd, y, run_var)
+        ctx.drop, ctx.training, ctx.eps = drop, training, eps
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        feats, lin, bn_w, save_mean, save_invstd, y, mask, run_var = ctx.saved_tensors
-        gbn = ops.dropout_tanh_bwd(gy.contiguous(), y, mask, ctx.scale)
+        feats, lin, bn_w, save_mean, save_invstd, y, run_var = ctx.saved_tensors
+        gbn = _tanh_drop_bwd(gy.contiguous(), y, ctx.drop)
         if not ctx.training:
             raise NotImplementedError("WordEbd backward in eval mode is never taken by the reference")
         glin, g_bn_w, g_bn_b = ops.batchnorm_bwd(gbn, lin, bn_w, save_mean, save_invstd)
         gw = ops.gemm_tn(glin, feats)                                # [D, glove_dim]
         gb = ops.colsum(glin)
-        return None, gw, gb, g_bn_w, g_bn_b, None, None, None, None, None, None, None
+        return None, gw, gb, g_bn_w, g_bn_b, None, None, None, None, None, None
 
 
 class _DVSAFn(torch.autograd.Function):
@@ -248,15 +277,13 @@ class VisEbd(nn.Module):
 
     def forward(self, feats):
         p = self.drop.p
-        mask, scale = (None, 1.0)
-        if self.training and p > 0:
-            mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device), 1.0 / (1.0 - p)
+        drop = DropSeed(p) if (self.training and p > 0) else None
         # the detector hands fc7 over together with its split-bf16 planes (an attribute on the very tensor it returned)
         planes = getattr(feats, "_nafae_planes", None)
         if planes is not None and (tuple(planes.shape) != tuple(feats.shape) or not feats.is_contiguous()
                                    or getattr(feats, "_nafae_planes_version", None) != feats._version):
             planes = None
-        return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, mask, scale, planes)
+        return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, drop, planes)
 
 
 class WordEbd(nn.Module):
@@ -269,14 +296,12 @@ class WordEbd(nn.Module):
 
     def forward(self, feats):
         p = self.drop.p
-        mask, scale = (None, 1.0)
-        if self.training and p > 0:
-            mask, scale = _drop_mask((feats.shape[0], self.fc1.out_features), p, feats.device, self.mask_generator), 1.0 / (1.0 - p)
+        drop = DropSeed(p, self.mask_generator) if (self.training and p > 0) else None
         if self.training:
             self.bn.num_batches_tracked += 1
         return _WordEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, self.bn.weight, self.bn.bias,
                                 self.bn.running_mean, self.bn.running_var, self.training, self.bn.momentum,
-                                self.bn.eps, mask, scale)
+                                self.bn.eps, drop)
 
 
 class GroundModel(nn.Module):

@@ -562,6 +562,23 @@ def dropout_tanh_bwd(g_out, y, mask=None, scale=1.0):
     return g_in
 
 
+def dropout_tanh_seeded(x, seed, p):
+    """tanh(dropout_p(x)) with the keep mask generated in the kernel from (seed, element index); no mask tensor."""
+    _chk(x)
+    y = torch.empty_like(x)
+    _rc(_lib.lib().nafae_dropout_tanh_seeded(_p(x), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), _p(y), x.numel(), _stream()),
+        "nafae_dropout_tanh_seeded")
+    return y
+
+
+def dropout_tanh_bwd_seeded(g_out, y, seed, p):
+    _chk(g_out); _chk(y)
+    g_in = torch.empty_like(g_out)
+    _rc(_lib.lib().nafae_dropout_tanh_bwd_seeded(_p(g_out), _p(y), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), _p(g_in),
+                                                 g_out.numel(), _stream()), "nafae_dropout_tanh_bwd_seeded")
+    return g_in
+
+
 def batchnorm_fwd(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
     _chk(x); _chk(weight); _chk(bias); _chk(running_mean); _chk(running_var)
     Q, D = x.shape

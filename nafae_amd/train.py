@@ -109,6 +109,19 @@ def detector_forward(model, batch):
         det.materialize_pooled = keep
 
 
+def criterion_backward(criterion, margin_loss):
+    """loss = criterion(margin_loss, 0); loss.backward()  (model.py:771-772).  For the reference's criterion, L1Loss against a
+    zero target on a scalar, that is |margin_loss| with upstream gradient sign(margin_loss): two elementwise launches instead
+    of the eight of zeros_like + L1Loss forward + its autograd backward.  Any other criterion takes the generic path."""
+    if type(criterion) is torch.nn.L1Loss and criterion.reduction == 'mean' and margin_loss.dim() == 0:
+        m = margin_loss.detach()
+        margin_loss.backward(torch.sign(m))
+        return m.abs()
+    loss = criterion(margin_loss, torch.zeros_like(margin_loss))
+    loss.backward()
+    return loss.detach()
+
+
 def train_step(model, optimizer, criterion, batch, args, reducer=None):
     """One iteration of model.py:684-775.  Returns the (device) loss; no host synchronisation inside."""
     rois, roi_scores, roi_feats, fc_feats = detector_forward(model, batch)
@@ -119,8 +132,7 @@ def train_step(model, optimizer, criterion, batch, args, reducer=None):
     else:
         optimizer.zero_grad()
     D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
-    loss = criterion(margin_loss, torch.zeros_like(margin_loss))
-    loss.backward()
+    loss = criterion_backward(criterion, margin_loss)
     if reducer is not None:
         reducer.allreduce()
     if isinstance(optimizer, FusedClipAdam):
@@ -128,7 +140,7 @@ def train_step(model, optimizer, criterion, batch, args, reducer=None):
     else:
         torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
         optimizer.step()
-    return loss.detach(), D, D_sim, rois
+    return loss, D, D_sim, rois
 
 
 def shard_frames(batch, rank, world):
@@ -139,6 +151,20 @@ def shard_frames(batch, rank, world):
     k = F // world
     return Batch(batch.im_data[rank * k:(rank + 1) * k], batch.im_info[rank * k:(rank + 1) * k], batch.glove_feats,
                  batch.entities_length)
+
+
+def shared_word_dropout_generator(model, args):
+    """The generator the replicated WordEbd draws its dropout seed from in exact DP mode: re-seeded from the SHARED pair
+    (args.exact_seed, number of exact steps taken so far), so every rank draws the same mask whatever its own RNG state is
+    (a per-rank torch.manual_seed(seed + rank) is the usual idiom and would silently break the exactness otherwise)."""
+    step = getattr(model, "_exact_step", 0)
+    model._exact_step = step + 1
+    we = model.word_ebd
+    gen = getattr(we, "_shared_gen", None)
+    if gen is None:
+        gen = we._shared_gen = torch.Generator()          # CPU: only the 62-bit seed of the in-kernel mask is drawn from it
+    gen.manual_seed((int(getattr(args, "exact_seed", 20191234)) * 1000003 + step) & 0x7FFFFFFFFFFF)
+    return gen
 
 
 def train_step_exact(model, optimizer, criterion, local_batch, args, reducer, group=None):
@@ -155,24 +181,17 @@ def train_step_exact(model, optimizer, criterion, local_batch, args, reducer, gr
     vis_feats = model.vis_ebd(fc_feats)                       # this rank's rows only
     we = model.word_ebd
     if we.training and we.drop.p > 0:
-        step = getattr(model, "_exact_step", 0)
-        model._exact_step = step + 1
-        gen = getattr(we, "_shared_gen", None)
-        if gen is None or gen.device != local_batch.glove_feats.device:
-            gen = we._shared_gen = torch.Generator(device=local_batch.glove_feats.device)
-        gen.manual_seed((int(getattr(args, "exact_seed", 20191234)) * 1000003 + step) & 0x7FFFFFFFFFFF)
-        we.mask_generator = gen
+        we.mask_generator = shared_word_dropout_generator(model, args)
     try:
         word_feats = we(local_batch.glove_feats)              # replicated: BatchNorm sees all Q rows on every rank
     finally:
         we.mask_generator = None
     reducer.zero_grad()
     D, D_sim, margin_loss = dvsa_frame_sharded(model.DVSA, vis_feats, word_feats, local_batch.entities_length, group)
-    loss = criterion(margin_loss, torch.zeros_like(margin_loss))
-    loss.backward()
+    loss = criterion_backward(criterion, margin_loss)
     reducer.allreduce(average=False)                          # partial gradients of ONE loss: sum, do not average
     optimizer.step()
-    return loss.detach(), D, D_sim, rois
+    return loss, D, D_sim, rois
 
 
 class PipelinedTrainer:
@@ -221,15 +240,14 @@ class PipelinedTrainer:
         word_feats = model.word_ebd(batch.glove_feats)
         self.reducer.zero_grad()
         D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
-        loss = self.criterion(margin_loss, torch.zeros_like(margin_loss))
-        loss.backward()
+        loss = criterion_backward(self.criterion, margin_loss)
         self.reducer.allreduce()
         if isinstance(self.optimizer, FusedClipAdam):
             self.optimizer.step()
         else:
             torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
             self.optimizer.step()
-        return loss.detach(), D, D_sim, rois
+        return loss, D, D_sim, rois
 
 
 def train_epoch(train_loader, model, glove, criterion, optimizer, reducer, args, device='cuda', raw_frames=False,

@@ -1,0 +1,19 @@
+"""Only the similarity kernels (sim_part_kernel + sim_finish_kernel), for rocprofv3 --kernel-trace / --pmc runs:
+    python scripts/sim_only.py [c2|c4|c5] [hist|dense] [iters]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nafae_amd import ops, synthetic as syn
+W = {"c2": (8, 8, 128, 16), "c4": (8, 8, 256, 32), "c5": (8, 8, 300, 64)}
+name = sys.argv[1] if len(sys.argv) > 1 else "c5"
+kind = sys.argv[2] if len(sys.argv) > 2 else "hist"
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+Na, Ns, Nb, Ne = W[name]
+lens = syn.entity_lengths(Na, Ne, seed=1234) if kind == "hist" else [Ne] * Na
+V, Wt = syn.embeddings(Na * Ns * Nb, Na * Ne, 512, seed=1)
+V, Wt = V.cuda(), Wt.cuda()
+lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+for _ in range(iters):
+    S, D = ops.sim_max_fwd(V, Wt, lt, Na, Ns, Nb, Ne, lens=lens)
+torch.cuda.synchronize()
+print(name, kind, "live", sum(lens), "checksum", float(S.sum()), int(D.sum()))

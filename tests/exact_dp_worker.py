@@ -25,6 +25,7 @@ def main():
     Na, Ns, Ne = 4, 4, 8
     args = default_args(batch_size=Na, sample_num=Ns, max_ent_len=Ne, dropout_rate=0.0, Delta=10.0, vis_lam=4.13)
     model, opt, crit, red = setup_training(args, seed=21, distributed=True)
+    model.fasterRCNN.conv_stream_k = False      # detector bit-identical for any number of frames per rank (see the test)
     losses = []
     for k in range(steps):
         gb = make_batch(Na, Ns, Ne, seed=100 + k, lens=[3, 0, 8, 5])

@@ -58,11 +58,10 @@ def test_frames_entries_are_slices_of_the_whole():
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_exact_mode_equals_single_process(world, monkeypatch):
+def test_exact_mode_equals_single_process(world):
     # the stream-K conv schedule adds the partial sums of a cut tile in an order that depends on the tile count, i.e. on
-    # how many frames a rank holds; switch it off so that the detector is bit-identical for 4, 8 and 16 frames and the
-    # tolerances below measure the exchange alone
-    monkeypatch.setenv("NAFAE_CONV_SK", "0")
+    # how many frames a rank holds; switch it off (fasterRCNN.conv_stream_k = False, here and in the workers) so that the
+    # detector is bit-identical for 4, 8 and 16 frames and the tolerances below measure the exchange alone
     from nafae_amd.model import default_args
     from nafae_amd.train import make_batch, setup_training, train_step
     steps = 2
@@ -79,6 +78,7 @@ def test_exact_mode_equals_single_process(world, monkeypatch):
         _cfg()
         args = default_args(batch_size=Na, sample_num=Ns, max_ent_len=Ne, dropout_rate=0.0, Delta=10.0, vis_lam=4.13)
         model, opt, crit, red = setup_training(args, seed=21)
+        model.fasterRCNN.conv_stream_k = False
         ref_losses = []
         for k in range(steps):
             gb = make_batch(Na, Ns, Ne, seed=100 + k, lens=[3, 0, 8, 5])

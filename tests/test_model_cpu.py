@@ -169,3 +169,32 @@ def test_prepare_batch_mirrors_train_loop():
     lb4 = list(lb); lb4[1] = ['egg', 'spatula', 'oil', 'salt', 'bowl']
     with pytest.raises(Exception, match="spatula is not in glove vocabulary"):
         prepare_batch(tuple(lb4), glove, args, device='cpu')
+
+
+def test_exact_dp_word_dropout_seed_is_shared_across_ranks():
+    """in exact DP mode the replicated WordEbd must draw the same dropout mask on every rank.  The mask is a
+    pure function of a 62-bit seed (DropSeed); the seed comes from a generator re-seeded from the shared (exact_seed, step),
+    so ranks whose own RNG state differs (torch.manual_seed(seed + rank)) still agree, and consecutive steps differ."""
+    import types
+    import torch
+    from nafae_amd.model import DropSeed, default_args
+    from nafae_amd.train import shared_word_dropout_generator
+    args = default_args(dropout_rate=0.1)
+    seeds = []
+    for rank in range(3):
+        torch.manual_seed(1234 + rank)                      # the usual per-rank seeding
+        model = types.SimpleNamespace(word_ebd=types.SimpleNamespace())
+        torch.rand(rank + 1)                                # ranks have consumed different amounts of their default streams
+        per_step = []
+        for step in range(3):
+            per_step.append(DropSeed(0.1, shared_word_dropout_generator(model, args)).seed)
+        seeds.append(per_step)
+        local = DropSeed(0.1).seed                          # a rank-local draw (visual side) is NOT shared
+        seeds[-1].append(local)
+    assert seeds[0][:3] == seeds[1][:3] == seeds[2][:3]
+    assert len(set(seeds[0][:3])) == 3
+    assert len({s[3] for s in seeds}) == 3
+    args2 = default_args(dropout_rate=0.1)
+    args2.exact_seed = 7
+    m2 = types.SimpleNamespace(word_ebd=types.SimpleNamespace())
+    assert DropSeed(0.1, shared_word_dropout_generator(m2, args2)).seed != seeds[0][0]
