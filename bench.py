@@ -161,7 +161,7 @@ def cpu_baseline():
 
 
 # ------------------------------------------------------------------------------------------------ sim + loss alone
-def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20):
+def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
     """The similarity + loss part alone: synthetic V, W = tanh(N(0,1)) of the workload's shape; the
     sim+max forward, and forward + loss tail + similarity backward.  Each is captured into a hipGraph of `iters` back-to-back
     passes and replayed between two HIP events on the launch stream, so the per-pass time is device time (kernel + the
@@ -212,7 +212,10 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20):
     by_f = 4.0 * D * (R + Q) + 12.0 * F * Q                       # forward algorithmic bytes
     by_fb = by_f + 4.0 * D * (R + Q) + 4.0 * D * F * Q            # + dense dV, dW and the arg-max row re-reads
     fl = 2.0 * R * Q * D
-    return {"R": R, "Q": Q, "pairs": R * Q, "live_query_columns": live, "timing": "hipGraph of %d back-to-back passes, best of 3" % iters,
+    traffic, src = pmc_traffic(pmc_key) if pmc_key else (None, None)
+    return {"R": R, "Q": Q, "fwd_traffic": traffic,
+            "fwd_traffic_source": ("static: %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/sim_only.py at this "
+                                   "shape, FETCH_SIZE x2; not read in this run)" % src) if traffic else None, "pairs": R * Q, "live_query_columns": live, "timing": "hipGraph of %d back-to-back passes, best of 3" % iters,
             "fwd_ms": round(t_f, 5), "fwd_pairs_per_s": round(R * Q / (t_f * 1e-3), 1),
             "fwd_algorithmic_bytes": by_f, "fwd_GBps": round(by_f / (t_f * 1e-3) / 1e9, 1),
             "fwd_hbm_frac": round(by_f / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -236,6 +239,8 @@ def launch_ranks(n, argv):
     """Parent of a self-launched N-GPU run.  Never touches the GPU: torch.cuda.device_count() does not initialise it."""
     import torch
     have = torch.cuda.device_count()
+    if "--test-shared-gpu" in argv and have >= 1:
+        have = n                                     # test mode: the ranks share the visible GPU(s), gloo collectives
     if have < n:
         sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to time fewer ranks than asked\n"
                          % (n, have))
@@ -271,14 +276,18 @@ def run_rank(a):
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: timing the %d rank(s) that exist\n" % (a.gpus, world, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
+    ndev = torch.cuda.device_count()
+    if a.test_shared_gpu:
+        local_rank = local_rank % max(ndev, 1)
+    if local_rank >= ndev:
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     distributed = world > 1
+    backend = "gloo" if a.test_shared_gpu else "nccl"       # nccl = RCCL on ROCm; gloo only for the shared-GPU launcher test
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from nafae_amd import ops
     from nafae_amd.config import cfg, cfg_from_file, reset_cfg
@@ -336,7 +345,7 @@ def run_rank(a):
         prof = ops.profile_summary()
         ops.profile_reset(enable=False)
         if distributed:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         res = {"dtype": prec, "value": round(world * F * steps / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
@@ -386,7 +395,7 @@ def run_rank(a):
                                    "VGG16 random-init, full train step" % (workload.upper(), F, Na, Ns, Nb, Ne),
                        "frames_per_gpu": F, "proposals_per_frame": Nb, "queries_per_segment": Ne,
                        "parallelism": ("dp%d" % world) + ("-exact-global-batch" if exact else ""),
-                       "rccl_world_size": world if distributed else 1,
+                       "rccl_world_size": world if distributed else 1, "collective_backend": backend if distributed else None,
                        "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
                        "step_pipeline": head["step_pipeline"]},
             "loss": head["loss"],
@@ -398,16 +407,17 @@ def run_rank(a):
             out["modes"] = siblings
         if world == 1:
             # the similarity kernel alone at this workload's shape, and at C5 (the HBM-roofline configuration)
-            so = sim_loss_only(Na, Ns, Nb, Ne, dev)
-            out["roofline_sim"] = {"kernel": "sim_max (stand-alone, this workload's shape and entity-length histogram)",
+            so = sim_loss_only(Na, Ns, Nb, Ne, dev, pmc_key="sim_%s_hist" % workload)
+            out["roofline_sim"] = {"kernel": "sim_part_kernel + sim_finish_kernel (nafae_sim_max_fwd_ws, stand-alone, this workload's shape and entity-length histogram)",
                                    "bound": "hbm", "achieved": so["fwd_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": so["fwd_hbm_frac"], "avg_ms": so["fwd_ms"], "algorithmic_bytes": so["fwd_algorithmic_bytes"],
-                                   "traffic": None, "in_step_avg_ms": head.get("stage_ms", {}).get("sim_max")}
+                                   "traffic": so["fwd_traffic"], "traffic_source": so["fwd_traffic_source"],
+                                   "in_step_avg_ms": head.get("stage_ms", {}).get("sim_max")}
             out["sim_loss_only"] = so
             c5 = WORKLOADS["c5"]
             out["sim_loss_c5"] = {
-                "histogram_lengths": sim_loss_only(*c5, dev),
-                "all_slots_live": sim_loss_only(*c5, dev, lens=[c5[3]] * c5[0]),
+                "histogram_lengths": sim_loss_only(*c5, dev, pmc_key="sim_c5_hist"),
+                "all_slots_live": sim_loss_only(*c5, dev, lens=[c5[3]] * c5[0], pmc_key="sim_c5_dense"),
                 "note": "C5 per-GPU shape R=19200 x Q=512, clustering on.  'histogram_lengths' draws the entity counts from the "
                         "YouCookII train-split histogram like every other workload (most of the Ne=64 slots are padding, whose "
                         "S_ columns are 0 by definition, model.py:551); 'all_slots_live' is the dense worst case."}
@@ -439,6 +449,10 @@ def main():
                     help="N > 1: 'replica' = per-GPU minibatch of whole segments, local loss, averaged gradients (default, "
                          "BASELINE.json's DP); 'exact' = ONE global batch of N x the segments, frames sharded over the GPUs, "
                          "S_max all-gathered, summed partial gradients (equals a 1-GPU step on the global batch)")
+    ap.add_argument("--test-shared-gpu", action="store_true",
+                    help="TEST ONLY: let the N ranks share the visible GPU(s) (LOCAL_RANK modulo device count) with gloo collectives "
+                         "staged through host memory, so that the launcher and the data-parallel step can be exercised end to "
+                         "end on a one-GPU box; the numbers it prints are meaningless as throughput")
     ap.add_argument("--precision", default=os.environ.get("NAFAE_PRECISION"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the HEADLINE run (default f32, what BASELINE config C2 names): exact fp32 MFMA | "
                          "split-bf16 (fp32-accurate to ~1e-5) | bf16.  The other modes are reported under `modes`.")

@@ -46,3 +46,23 @@ def test_self_launch_two_ranks_share_one_gpu_is_not_attempted():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1",
                                                                      "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert r.returncode != 0 and "LOCAL_RANK 1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_self_launched_two_ranks_run_the_dp_step_end_to_end():
+    """`python bench.py --gpus 2` starts two ranks by itself; in the shared-GPU test mode both use the one visible GPU and
+    gloo, so the whole path -- launcher, process group, per-rank C4 batches, gradient all-reduce of the 8.8 MB flat buffer,
+    max-over-ranks timing, rank 0's single JSON line -- runs for real."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    r = _run(["--gpus", "2", "--test-shared-gpu", "--steps", "2", "--warmup", "1", "--no-other-precisions", "--precision", "bf16x3",
+              "--workload", "c2"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world_size"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["grad_allreduce_bytes"] == 2201600 * 4 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["steps"] == 2
