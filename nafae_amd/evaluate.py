@@ -64,10 +64,16 @@ def _summary(match, count):
 
 def phrase_accuracy(recs, dets, class_list, verbose=False):
     """Per (frame, query class): counted once if the class has a gt box in the frame; matched if any of its gt boxes
-    overlaps the grounded box with IoU >= that box's threshold.  Returns the macro (class-mean) accuracy."""
+    overlaps the grounded box with IoU >= that box's threshold.  Returns the macro (class-mean) accuracy.
+
+    Bug-for-bug with youcook_eval.py:185-227: the reference increments `class_match_count[class_ind]` with the `class_ind`
+    left over from the label most recently INSERTED into its per-frame dict, not the index of the label that matched -- so
+    when a frame carries a repeated entity label interleaved with other labels (A, B, A) a later match of A is booked on B.
+    The total (micro accuracy) is unaffected, the printed macro accuracy is; tests/golden/eval_dup.npz pins that case."""
     cells, num_imgs = _group_by_frame(dets)
     match = np.zeros(len(class_list), dtype=int)
     count = np.zeros(len(class_list), dtype=int)
+    class_ind = 0
     for img_id in range(num_imgs):
         if cells[img_id] is None:
             continue
@@ -79,11 +85,12 @@ def phrase_accuracy(recs, dets, class_list, verbose=False):
                     continue
                 if obj_label not in state:
                     state[obj_label] = 0
-                    count[class_list.index(gt_label)] += 1
+                    class_ind = class_list.index(gt_label)
+                    count[class_ind] += 1
                 elif state[obj_label] == 1:
                     continue
                 if _iou_ge(obj_box, gt_box, thr):
-                    match[class_list.index(gt_label)] += 1
+                    match[class_ind] += 1                # (stale index when the label was inserted earlier: see docstring)
                     state[obj_label] = 1
     macro, micro = _summary(match, count)
     if verbose:

@@ -122,3 +122,18 @@ def test_detector_matches_reference():
     np.testing.assert_allclose(roi_scores.numpy(), g["roi_scores"], rtol=1e-6)
     np.testing.assert_allclose(pooled[:, ::37].numpy(), g["pooled_sub"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(fc7.numpy(), g["fc7"], rtol=1e-4, atol=1e-4)
+
+
+def test_phrase_accuracy_repeated_label_matches_reference(golden_dir):
+    """the reference books a match on the class index of the label most recently inserted; a frame with a repeated
+    entity label (bowl, egg, bowl) exposes it.  tests/golden/eval_dup.npz = the reference's own outputs on such frames."""
+    import os
+    import numpy as np
+    from nafae_amd import evaluate as E
+    g = np.load(os.path.join(golden_dir, "eval_dup.npz"))
+    classes = [str(c) for c in g["classes"]]
+    recs = [{'label': str(l).split('|'), 'bbox': list(b), 'thr': [0.5] * len(b), 'img_ids': [i] * len(b)}
+            for i, (l, b) in enumerate(zip(g["rec_lab"], g["rec_box"]))]
+    dets = [g["det_img"].tolist(), [str(x) for x in g["det_lab"]], list(g["det_box"]), g["det_conf"].tolist()]
+    assert abs(E.phrase_accuracy(recs, dets, classes) - float(g["phrase_acc"])) < 1e-12
+    assert abs(E.box_accuracy(recs, dets, classes) - float(g["box_acc"])) < 1e-12
