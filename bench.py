@@ -302,7 +302,7 @@ def run_rank(a):
     exact = a.dp_mode == "exact"
     Na_model = Na * world if exact else Na          # exact mode: ONE batch of world*Na segments, every rank sees all queries
     args = default_args(batch_size=Na_model, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
-    model, opt, crit, reducer = setup_training(args, device=dev, seed=1234, distributed=distributed)
+    model, opt, crit, reducer = setup_training(args, device=dev, seed=1234, distributed=distributed, grad_exchange=a.grad_exchange)
     if exact:
         batch = shard_frames(make_batch(Na_model, Ns, Ne, seed=1234, device=dev), rank, world)
     else:
@@ -397,6 +397,7 @@ def run_rank(a):
                        "parallelism": ("dp%d" % world) + ("-exact-global-batch" if exact else ""),
                        "rccl_world_size": world if distributed else 1, "collective_backend": backend if distributed else None,
                        "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
+                       "grad_exchange": a.grad_exchange if distributed else None,
                        "step_pipeline": head["step_pipeline"]},
             "loss": head["loss"],
         }
@@ -449,6 +450,9 @@ def main():
                     help="N > 1: 'replica' = per-GPU minibatch of whole segments, local loss, averaged gradients (default, "
                          "BASELINE.json's DP); 'exact' = ONE global batch of N x the segments, frames sharded over the GPUs, "
                          "S_max all-gathered, summed partial gradients (equals a 1-GPU step on the global batch)")
+    ap.add_argument("--grad-exchange", default="allreduce", choices=["allreduce", "direct"],
+                    help="N > 1: one RCCL all-reduce of the flat gradient buffer (default), or the one-shot reduce-scatter + all-gather "
+                         "over the point-to-point xGMI mesh (all-to-all of the shards, fixed-order local sum, all-gather)")
     ap.add_argument("--test-shared-gpu", action="store_true",
                     help="TEST ONLY: let the N ranks share the visible GPU(s) (LOCAL_RANK modulo device count) with gloo collectives "
                          "staged through host memory, so that the launcher and the data-parallel step can be exercised end to "

@@ -297,7 +297,7 @@ def eval_step(model, batch):
     return margin_loss, D, D_sim, rois
 
 
-def setup_training(args, device='cuda', seed=1234, distributed=False):
+def setup_training(args, device='cuda', seed=1234, distributed=False, grad_exchange="allreduce"):
     model = build_model(args, device=device, seed=seed)
     if distributed:
         from .parallel import broadcast_parameters
@@ -306,7 +306,7 @@ def setup_training(args, device='cuda', seed=1234, distributed=False):
     model.DVSA.init_train()
     model.fasterRCNN.eval()                      # model.py:671-673
     # gradients always live in one flat buffer (all-reduced when world > 1); the optimiser step is the fused HIP one
-    reducer = GradAllReducer(trainable_parameters(model))
+    reducer = GradAllReducer(trainable_parameters(model), mode=grad_exchange)
     optimizer = FusedClipAdam(reducer, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip)
     criterion = torch.nn.L1Loss()
     return model, optimizer, criterion, reducer

@@ -166,3 +166,40 @@ def test_exact_mode_exchange_world2(tmp_path):
         assert torch.allclose(o["dV"], Vr.grad[r * k:(r + 1) * k], atol=1e-6)       # own frames only
         assert torch.allclose(o["dW"], Wr.grad, atol=1e-6)                           # summed partials
     assert rs[1]["dV"][:Nb].abs().sum() >= 0 and not torch.equal(rs[0]["dV"], rs[1]["dV"])
+
+
+def _direct_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nafae_amd.parallel import GradAllReducer, broadcast_parameters, trainable_parameters
+    torch.manual_seed(5 + rank)
+    res = {}
+    for mode in ("allreduce", "direct"):
+        m = _Toy()
+        broadcast_parameters(m, src=0)
+        red = GradAllReducer(trainable_parameters(m), mode=mode)
+        g = torch.Generator().manual_seed(40 + rank)
+        x, gl = torch.randn(10, 12, generator=g), torch.randn(5, 6, generator=g)
+        red.zero_grad()
+        _loss(m, x, gl).backward()
+        local = red.flat.clone()
+        red.allreduce()
+        res[mode] = (local, red.flat.clone())
+    torch.save(res, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_reduce_scatter_allgather_equals_allreduce(tmp_path):
+    """The one-shot exchange (all-to-all of the shards, fixed-order local sum, all-gather; flat buffer padded to a multiple of
+    the world size) leaves the mean of the local gradients on every rank, like the all-reduce; world 3 so that padding is used."""
+    world = 3
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_direct_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rs = [torch.load(out % r) for r in range(world)]
+    for mode in ("direct", "allreduce"):                    # (each mode ran on its own freshly initialised toy model)
+        mean_local = sum(r[mode][0] for r in rs) / world
+        for r in rs:
+            assert torch.allclose(r[mode][1], mean_local, rtol=1e-6, atol=1e-7), mode
+            assert torch.equal(r[mode][1], rs[0][mode][1]), mode                # replicas bit-identical
