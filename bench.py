@@ -96,13 +96,16 @@ def cpu_baseline():
     # thread count: torch's CPU convolutions get SLOWER when a many-core host is oversubscribed (256 threads on the GPU box:
     # 2.1 s/frame against 0.5 s/frame on 8 cores), so pick the fastest of a few counts on one frame and report it as `cores`
     best_t, threads = None, cores
-    for n in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
+    for n in sorted({min(cores, c) for c in (8, 16, 24, 32, 48, 64, cores)}):
         torch.set_num_threads(n)
         with torch.no_grad():
-            OD.vgg16_features(im[:1], sd)
-            t0 = time.perf_counter()
-            OD.vgg16_features(im[:1], sd)
-            dt = time.perf_counter() - t0
+            OD.vgg16_features(im, sd)
+            dt = None
+            for _ in range(2):                      # best of two on the whole C1 batch (one-frame timings are too noisy)
+                t0 = time.perf_counter()
+                OD.vgg16_features(im, sd)
+                d1 = time.perf_counter() - t0
+                dt = d1 if dt is None or d1 < dt else dt
         if best_t is None or dt < best_t:
             best_t, threads = dt, n
     torch.set_num_threads(threads)
@@ -152,7 +155,7 @@ def cpu_baseline():
     t_sim = statistics.median(ts[1:])
     return {"value": round(nf / med["total"], 4), "unit": "frames/s", "cores": threads, "host_cores": cores, "kind": "port",
             "sample": "config C1 exactly: %d frames 224x224, %d proposals/frame, %d query slots, one forward + loss; 1 warm-up + %d "
-                      "timed runs, torch CPU fp32 + C NMS/ROI-Align, %d threads (fastest of 8/16/32/64/all on this host)" % (nf, Nb, Ne, n_runs, threads),
+                      "timed runs, torch CPU fp32 + C NMS/ROI-Align, %d threads (fastest of 8/16/24/32/48/64/all on this host)" % (nf, Nb, Ne, n_runs, threads),
             "median_s": round(med["total"], 4), "min_s": round(mn["total"], 4), "frames_per_s_best": round(nf / mn["total"], 4),
             "stages_median_ms": {k: round(1e3 * v, 2) for k, v in med.items() if k != "total"},
             "stages_min_ms": {k: round(1e3 * v, 2) for k, v in mn.items() if k != "total"},
@@ -182,7 +185,7 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
 
     def full():
         S_max, D_ind = fwd()
-        loss, dS, _ = ops.loss_fwd_bwd(S_max, D_ind, V, lens_t, Na, Ns, Nb, Ne, 10.0, 4.13, True, workspace=ws)
+        loss, dS, _ = ops.loss_fwd_bwd(S_max, D_ind, V, lens_t, Na, Ns, Nb, Ne, 10.0, 4.13, True, workspace=ws, lens=lens)
         return ops.sim_bwd(dS, D_ind, V, W, lens_t, Na, Ns, Nb, Ne, True, ws)
 
     def timeit(fn):

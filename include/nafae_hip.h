@@ -252,6 +252,14 @@ int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V,
                        int Na, int Ns, int Nb, int Ne, int D, float Delta, float vis_lam, int train,
                        float *loss_out, float *dS, void *workspace, void *stream);
 
+/* The same with an UPPER BOUND on the number of live query slots (sum_a min(max(ent_len[a],0),Ne); -1 = unknown -> Na*Ne): the
+ * ranking term then runs entirely out of LDS on the compacted live slots (a masked slot adds exactly +0 everywhere).  A bound
+ * that is too small is reported as a NaN loss, never silently truncated.  nafae_loss_fwd_bwd == this with -1.  Both leave the
+ * compact list of live slots in `workspace` for nafae_sim_bwd.  */
+int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float *V, const int32_t *ent_len,
+                          int Na, int Ns, int Nb, int Ne, int D, float Delta, float vis_lam, int train, int max_live_cols,
+                          float *loss_out, float *dS, void *workspace, void *stream);
+
 /* Backward of the similarity: dV [R,D] (dense, arg-max rows + clustering rows), dW [Q,D].
  * If pre_scale != NULL the VisEbd tail is fused: dV is multiplied elementwise by pre_scale [R,D]
  * (= (1 - V^2) * dropout_mask * dropout_scale, the tanh/dropout backward of model.py:627-628).

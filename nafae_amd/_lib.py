@@ -52,6 +52,7 @@ SIGNATURES = {
     "nafae_sim_max_fwd_ws": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P]),
     "nafae_loss_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "nafae_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, P, P, P]),
+    "nafae_loss_fwd_bwd_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, P]),
     "nafae_sim_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "nafae_sim_max_fwd_frames": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "nafae_sim_bwd_frames": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),

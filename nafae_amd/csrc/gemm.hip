@@ -415,7 +415,8 @@ inline int launched() { return hipGetLastError() == hipSuccess ? NAFAE_OK : NAFA
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // fp32 tile kernels: double-buffered LDS (2 workgroups per CU) or the single-buffer variant (3 per CU); NAFAE_F32_SB=0/1
-// selects in the experiments build, the default is set below from the measured A/B (scripts/f32_ab.py)
+// selects in the experiments build, the default is set below from the measured A/B (scripts/f32_ab.py).  Also tried:
+// 4 workgroups per CU by capping the kernel at 128 registers -- 68 B/lane of scratch spills, fc6 16.9 ms vs 12.8: not adopted.
 constexpr bool F32_CONV_SMALL_DEFAULT = false;
 constexpr bool F32_SB_DEFAULT = true;    // measured: fc6 -3.2 %, conv layers -4.4 ... -5.6 %, bit-identical results
 inline bool f32_single_buffer() {

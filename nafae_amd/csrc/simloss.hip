@@ -139,6 +139,7 @@ struct LossWs {
   size_t part_sum, part_cnt;    // [Na*Ne]
   size_t cidx;                  // [Na*Ne*Ns] int32
   size_t dgc;                   // [Na*Ne*Ns*D]
+  size_t live;                  // int32 [4 + Q]: [0] = number of live query slots L, [4 + j] = query index of live slot j
   size_t total;
 };
 
@@ -165,6 +166,7 @@ __host__ __device__ inline LossWs loss_ws(int Na, int Ns, int Nb, int Ne, int D)
   w.part_cnt = take(Q);
   w.cidx = take(Q * Ns);
   w.dgc = take(Q * Ns * D);
+  w.live = take(Q + 4);
   w.total = o;
   (void)Nb;
   return w;
@@ -182,6 +184,16 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float *__restrict
   int *amin = reinterpret_cast<int *>(ws + L.amin), *amax = reinterpret_cast<int *>(ws + L.amax);
   float *Sf = ws + L.Sf, *dSf = ws + L.dSf, *fs = ws + L.fs, *cs1 = ws + L.cs1, *rs2 = ws + L.rs2;
   float *scal = ws + L.scal;
+  if (tid == 0) {               // live query slots, ascending (what sim_bwd_dv scans instead of all Q columns)
+    int *live = reinterpret_cast<int *>(ws + L.live);
+    int n = 0;
+    for (int a = 0; a < Na; a++) {
+      int l = ent_len[a];
+      l = l < 0 ? 0 : (l > Ne ? Ne : l);
+      for (int en = 0; en < l; en++) live[4 + n++] = a * Ne + en;
+    }
+    live[0] = n;
+  }
 
   // A: per (a, q): min / max over the Ns frames of segment a, first-occurrence indices (model.py:587)
   for (int i = tid; i < Na * Q; i += nt) {
@@ -291,6 +303,186 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float *__restrict
   }
 }
 
+// The same ranking term with everything on chip: only the L LIVE query slots (e < len_a) carry information -- a masked
+// column of S_max is identically 0 and adds +0 to every sum below -- so the kernel compacts them (prefix scan of ent_len),
+// copies S_max[:, live] into LDS once (F*L floats: 4 KB at C5 with histogram lengths) and runs all phases out of LDS instead
+// of re-reading S_max from L2 in every phase (six dependent global round trips per entry in the kernel above: 70 us at C5).
+// Same arithmetic, same summation order over the live slots.  dS is written for every (frame, slot): 0 for masked ones.
+// Lcap = the host's upper bound on L (LDS is sized with it); L > Lcap is reported as NaN loss, never silently truncated.
+__global__ __launch_bounds__(1024) void loss_tail_lds_kernel(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len,
+                                                             int Na, int Ns, int Ne, float Delta, float *__restrict__ dS,
+                                                             float *__restrict__ ws, LossWs L, int Lcap) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Q = Na * Ne, F = Na * Ns;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float *Sl = sm;                                   // [F][Lcap]
+  float *mn = Sl + (size_t)F * Lcap, *mx = mn + Na * Lcap;
+  int *amin = reinterpret_cast<int *>(mx + Na * Lcap), *amax = amin + Na * Lcap;
+  float *Sf = reinterpret_cast<float *>(amax + Na * Lcap), *dSf = Sf + Na * Ns * Na;
+  float *fs = dSf + Na * Ns * Na, *cs1 = fs + Na * Ns, *rs2 = cs1 + Na * Ns;
+  int *prefix = reinterpret_cast<int *>(rs2 + Na * Ns);     // [Na + 1]
+  int *qlist = prefix + Na + 1;                              // [Lcap]
+  int *colmap = qlist + Lcap;                                // [Q]: live index of a query slot, or -1
+  float *scal = ws + L.scal;
+
+  if (tid < 64) {               // exclusive prefix of the clamped entity counts (one wave)
+    int carry = 0;
+    for (int base = 0; base < Na; base += 64) {
+      const int a = base + tid;
+      int x = a < Na ? ent_len[a] : 0;
+      x = x < 0 ? 0 : (x > Ne ? Ne : x);
+      int incl = x;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (tid >= o) incl += y;
+      }
+      if (a < Na) prefix[a] = carry + incl - x;
+      carry += __shfl(incl, 63);
+    }
+    if (tid == 0) prefix[Na] = carry;
+  }
+  __syncthreads();
+  const int Lc = prefix[Na];
+  if (Lc > Lcap) {              // the caller's bound was too small: fail loudly
+    if (tid == 0) scal[0] = NAN;
+    return;
+  }
+  for (int q = tid; q < Q; q += nt) {
+    const int a = q / Ne, en = q - a * Ne;
+    const int l = prefix[a + 1] - prefix[a];
+    const int j = en < l ? prefix[a] + en : -1;
+    colmap[q] = j;
+    if (j >= 0) qlist[j] = q;
+  }
+  __syncthreads();
+  {
+    int *live = reinterpret_cast<int *>(ws + L.live);
+    if (tid == 0) live[0] = Lc;
+    for (int j = tid; j < Lc; j += nt) live[4 + j] = qlist[j];
+  }
+  for (int i = tid; i < F * Lc; i += nt) {
+    const int f = i / Lc, j = i - f * Lc;
+    Sl[f * Lcap + j] = Sm[(size_t)f * Q + qlist[j]];
+  }
+  __syncthreads();
+  // A: per (a, live slot): min / max over the Ns frames of segment a, first-occurrence indices (model.py:587)
+  for (int i = tid; i < Na * Lc; i += nt) {
+    const int a = i / Lc, j = i - a * Lc;
+    float lo = INFINITY, hi = -INFINITY;
+    int ilo = 0, ihi = 0;
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sl[(a * Ns + s) * Lcap + j];
+      if (v < lo) {
+        lo = v;
+        ilo = s;
+      }
+      if (v > hi) {
+        hi = v;
+        ihi = s;
+      }
+    }
+    mn[a * Lcap + j] = lo;
+    mx[a * Lcap + j] = hi;
+    amin[a * Lcap + j] = ilo;
+    amax[a * Lcap + j] = ihi;
+    ws[L.mn + (size_t)a * Q + qlist[j]] = lo;      // the clustering kernel reads its own-segment entries
+    ws[L.mx + (size_t)a * Q + qlist[j]] = hi;
+  }
+  __syncthreads();
+  // B: Sf[a,s,j] = sum_e S*att / max(len_j,1)   (model.py:588-592); masked slots add exactly +0
+  for (int i = tid; i < Na * Ns * Na; i += nt) {
+    const int j = i % Na;
+    const int as = i / Na;
+    const int a = as / Ns;
+    float acc = 0.f;
+    for (int c = prefix[j]; c < prefix[j + 1]; c++) {
+      const float v = Sl[as * Lcap + c];
+      const float lo = mn[a * Lcap + c], hi = mx[a * Lcap + c];
+      acc += v * ((v - lo) / (hi - lo + EPS));
+    }
+    const int l = ent_len[j];
+    Sf[i] = acc / (float)(l == 0 ? 1 : l);
+  }
+  __syncthreads();
+  // C: frame_score (model.py:603) and the hinge-active counts its backward needs
+  for (int i = tid; i < Na * Ns; i += nt) {
+    const int a = i / Ns, s = i - a * Ns;
+    const float diag = Sf[(a * Ns + s) * Na + a];
+    float t1 = 0.f, t2 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k = 0; k < Na; k++) {
+      const float u1 = Sf[(k * Ns + s) * Na + a] - diag + Delta;
+      const float u2 = Sf[(a * Ns + s) * Na + k] - diag + Delta;
+      if (u1 > 0.f) {
+        t1 += u1;
+        c1 += 1.f;
+      }
+      if (u2 > 0.f) {
+        t2 += u2;
+        c2 += 1.f;
+      }
+    }
+    fs[i] = t1 / (float)Na + t2 / (float)Na;
+    cs1[i] = c1;
+    rs2[i] = c2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < Na * Ns; i++) acc += fs[i];
+    scal[0] = acc / (float)(Na * Ns);
+  }
+  if (dS == nullptr) return;
+  // E: d(10 * mean fs) / dSf
+  const float cN = 10.0f / (float)(Na * Ns) / (float)Na;
+  for (int i = tid; i < Na * Ns * Na; i += nt) {
+    const int j = i % Na;
+    const int as = i / Na;
+    const int a = as / Ns, s = as - a * Ns;
+    const float v = Sf[i];
+    const float g1 = (v - Sf[(j * Ns + s) * Na + j] + Delta > 0.f) ? 1.f : 0.f;
+    const float g2 = (v - Sf[(a * Ns + s) * Na + a] + Delta > 0.f) ? 1.f : 0.f;
+    float g = cN * (g1 + g2);
+    if (a == j) g -= cN * (cs1[a * Ns + s] + rs2[a * Ns + s]);
+    dSf[i] = g;
+  }
+  __syncthreads();
+  // F: back through S*att with the min / max paths (model.py:587-588), live slots
+  for (int i = tid; i < Na * Lc; i += nt) {
+    const int a = i / Lc, c = i - a * Lc;
+    const int q = qlist[c];
+    const int j = q / Ne;
+    const int l = ent_len[j];
+    const float inv_div = 1.0f / (float)(l == 0 ? 1 : l);
+    const float lo = mn[a * Lcap + c], hi = mx[a * Lcap + c];
+    const float den = hi - lo + EPS;
+    float gmn = 0.f, gmx = 0.f;
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sl[(a * Ns + s) * Lcap + c];
+      const float dT = dSf[(a * Ns + s) * Na + j] * inv_div;
+      gmn += dT * v * (v - hi - EPS) / (den * den);
+      gmx -= dT * v * (v - lo) / (den * den);
+    }
+    const int ilo = amin[a * Lcap + c], ihi = amax[a * Lcap + c];
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sl[(a * Ns + s) * Lcap + c];
+      const float dT = dSf[(a * Ns + s) * Na + j] * inv_div;
+      float g = dT * ((v - lo) / den + v / den);
+      if (s == ilo) g += gmn;
+      if (s == ihi) g += gmx;
+      dS[((size_t)a * Ns + s) * Q + q] = g;
+    }
+  }
+  // masked slots: exactly 0 (model.py:551 zero-fills the column, so no gradient flows)
+  for (int i = tid; i < F * Q; i += nt)
+    if (colmap[i % Q] < 0) dS[i] = 0.f;
+}
+
+inline size_t loss_tail_lds_bytes(int Na, int Ns, int Ne, int Lcap) {
+  const size_t F = (size_t)Na * Ns, Q = (size_t)Na * Ne;
+  return 4 * (F * Lcap + 4 * (size_t)Na * Lcap + 2 * (size_t)Na * Ns * Na + 3 * F + (Na + 1) + Lcap + Q) + 16;
+}
+
 // ------------------------------------------------------------------------------------------------ clustering term
 __device__ __forceinline__ float block_sum(float v, float *red) {
   // 256 threads; result broadcast to all
@@ -303,7 +495,10 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// grid Na*Ne, block 256.  Dynamic LDS: g[Ns][D] raw gathered rows, G[Ns][D] normalised * sn.
+// grid Na*Ne, block 256.  Dynamic LDS: g[Ns][D] raw gathered rows, G[Ns][D] normalised * sn, tot[D] = sum_s G[s].
+// All Ns gathered rows are requested in ONE pass (independent 16-B loads, one barrier) and the per-row reductions (norm,
+// g . dG) are wave reductions -- a wave owns rows w, w+4, ... -- instead of Ns sequential block reductions with a global
+// round trip each (the first version: 36 us, most of it that serialised gather).
 __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
                                                       const float *__restrict__ V,
                                                       const int32_t *__restrict__ ent_len, int Na, int Ns, int Ne,
@@ -312,10 +507,10 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
   __shared__ float red[4];
   __shared__ float s_sn[64], s_nrm[64], s_dot[64];
   __shared__ int s_idx[64];
-  float *g = sm, *G = sm + (size_t)Ns * D;
+  float *g = sm, *G = sm + (size_t)Ns * D, *tot = G + (size_t)Ns * D;
   const int ae = blockIdx.x, a = ae / Ne, en = ae - a * Ne;
   const int Q = Na * Ne, q = a * Ne + en;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float *part_sum = ws + L.part_sum, *part_cnt = ws + L.part_cnt;
   int *cidx = reinterpret_cast<int *>(ws + L.cidx) + (size_t)ae * Ns;
   float *dgc = ws + L.dgc + (size_t)ae * Ns * D;
@@ -336,26 +531,32 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
     cidx[s] = ix;
   }
   __syncthreads();
-  for (int s = 0; s < Ns; s++) {
+  const int d4n = D >> 2;
+  for (int i = tid; i < Ns * d4n; i += 256) {
+    const int s = i / d4n, d4 = i - s * d4n;
+    *reinterpret_cast<f32x4 *>(&g[s * D + d4 * 4]) = *reinterpret_cast<const f32x4 *>(V + (size_t)s_idx[s] * D + d4 * 4);
+  }
+  __syncthreads();
+  for (int s = wave; s < Ns; s += 4) {
     float acc = 0.f;
-    for (int d = tid; d < D; d += 256) {
-      const float v = V[(size_t)s_idx[s] * D + d];
-      g[s * D + d] = v;
-      acc += v * v;
-    }
-    acc = block_sum(acc, red);
-    if (tid == 0) s_nrm[s] = sqrtf(acc);
+    for (int d = lane; d < D; d += 64) acc += g[s * D + d] * g[s * D + d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s_nrm[s] = sqrtf(acc);
   }
   __syncthreads();
-  for (int s = 0; s < Ns; s++) {
-    const float inv = 1.0f / (s_nrm[s] + EPS);  // (g / (norm + EPS)) * sn   (model.py:570-571)
-    for (int d = tid; d < D; d += 256) G[s * D + d] = (g[s * D + d] / (s_nrm[s] + EPS)) * s_sn[s];
-    (void)inv;
+  for (int i = tid; i < Ns * D; i += 256) {
+    const int s = i / D;
+    G[i] = (g[i] / (s_nrm[s] + EPS)) * s_sn[s];  // (g / (norm + EPS)) * sn   (model.py:570-571)
   }
   __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    float t = 0.f;
+    for (int s2 = 0; s2 < Ns; s2++) t += G[s2 * D + d];
+    tot[d] = t;
+  }
   // gram: 1 - G_s . G_s' for s != s' (model.py:574-575); sum and count of non-zeros (model.py:576)
   float lsum = 0.f, lcnt = 0.f;
-  const int wave = tid >> 6, lane = tid & 63;
   for (int p = wave; p < Ns * Ns; p += 4) {
     const int s1 = p / Ns, s2 = p - s1 * Ns;
     if (s1 == s2) continue;
@@ -371,52 +572,52 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
   }
   // (lane 0 of each wave holds its partials; everyone else 0)
   lsum = block_sum(lsum, red);
-  lcnt = block_sum(lcnt, red);
+  lcnt = block_sum(lcnt, red);       // (its barriers also publish tot[])
   if (tid == 0) {
     part_sum[ae] = lsum;
     part_cnt[ae] = lcnt;
   }
   // gradient wrt the gathered rows, unscaled by 10*vis_lam/dem: dG_s = -2 (sum_s' G_s' - G_s)
-  for (int s = 0; s < Ns; s++) {
+  for (int s = wave; s < Ns; s += 4) {
     float acc = 0.f;
-    for (int d = tid; d < D; d += 256) {
-      float tot = 0.f;
-      for (int s2 = 0; s2 < Ns; s2++) tot += G[s2 * D + d];
-      const float dG = -2.0f * (tot - G[s * D + d]);
-      acc += g[s * D + d] * dG;
-    }
-    acc = block_sum(acc, red);
-    if (tid == 0) s_dot[s] = acc;
+    for (int d = lane; d < D; d += 64) acc += g[s * D + d] * (-2.0f * (tot[d] - G[s * D + d]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s_dot[s] = acc;
   }
   __syncthreads();
-  for (int s = 0; s < Ns; s++) {
+  for (int i = tid; i < Ns * D; i += 256) {
+    const int s = i / D, d = i - s * D;
     const float n = s_nrm[s], ne = n + EPS, sn = s_sn[s];
     // u = g/(n+EPS), G = sn*u;  dg = sn * ( dG/(n+EPS) - g * (g.dG) / (n * (n+EPS)^2) )
     const float k2 = s_dot[s] / (n * ne * ne);
-    for (int d = tid; d < D; d += 256) {
-      float tot = 0.f;
-      for (int s2 = 0; s2 < Ns; s2++) tot += G[s2 * D + d];
-      const float dG = -2.0f * (tot - G[s * D + d]);
-      dgc[(size_t)s * D + d] = sn * (dG / ne - g[s * D + d] * k2);
-    }
+    const float dG = -2.0f * (tot[d] - G[i]);
+    dgc[i] = sn * (dG / ne - g[i] * k2);
   }
 }
 
-__global__ void loss_final_kernel(float *__restrict__ ws, LossWs L, int Na, int Ne, float vis_lam, int train,
-                                  float *__restrict__ loss_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void loss_final_kernel(float *__restrict__ ws, LossWs L, int Na, int Ne, float vis_lam, int train,
+                                                        float *__restrict__ loss_out) {
+  // one wave: lane-strided partial sums in a fixed order, then a fixed shuffle tree (deterministic)
+  const int lane = threadIdx.x;
   float *scal = ws + L.scal;
   const float rank = scal[0];
   float vis = 0.f, dem = 0.f, cscale = 0.f;
   if (train) {
     float sum = 0.f;
-    for (int i = 0; i < Na * Ne; i++) {
+    for (int i = lane; i < Na * Ne; i += 64) {
       sum += ws[L.part_sum + i];
       dem += ws[L.part_cnt + i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sum += __shfl_xor(sum, o);
+      dem += __shfl_xor(dem, o);
     }
     vis = sum / dem;  // dem == 0 -> NaN/Inf exactly like the reference (model.py:577)
     cscale = 10.0f * vis_lam / dem;
   }
+  if (lane != 0) return;
   scal[1] = cscale;
   scal[2] = vis;
   scal[3] = dem;
@@ -443,11 +644,17 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
   f32x4 acc[MAXCH];
 #pragma unroll
   for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int qb = 0; qb < Q; qb += 64) {
-    const int q = qb + lane;
+  // only live query slots can carry gradient (dS of a masked slot is exactly 0): scan the compact list the loss tail left
+  // in the workspace instead of all Q columns (C5: 17 of 512)
+  const int *live = ws ? reinterpret_cast<const int *>(ws + L.live) : nullptr;
+  const int nq = live ? live[0] : Q;
+  for (int qb = 0; qb < nq; qb += 64) {
+    const int j = qb + lane;
     bool hit = false;
     float ds = 0.f;
-    if (q < Q) {
+    int q = 0;
+    if (j < nq) {
+      q = live ? live[4 + j] : j;
       ds = dS[(size_t)f * Q + q];
       hit = ((int)D_ind[(size_t)f * Q + q] == b) && ds != 0.f;
     }
@@ -456,7 +663,7 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
       const int i = __ffsll((long long)m) - 1;
       m &= m - 1;
       const float w = __shfl(ds, i);
-      const float *wr = Wm + (size_t)(qb + i) * D;
+      const float *wr = Wm + (size_t)__shfl(q, i) * D;
 #pragma unroll
       for (int c = 0; c < MAXCH; c++) {
         const int d = lane * 4 + c * 256;
@@ -501,31 +708,59 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
   }
 }
 
-// one wave per query column q
+// one WORKGROUP per query column q: its 4 waves take the frames f = w, w+4, ... four at a time (the arg-max row gathers of
+// four frames are in flight together), and the four partial rows are added in wave order through LDS -- a fixed order.
+// (The first version walked the F frames of a column serially in one wave: F dependent L2 round trips, 63 us at C5.)
 __global__ __launch_bounds__(256) void sim_bwd_dw_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
-                                                         const float *__restrict__ V, int F, int Nb, int Q, int D,
-                                                         const float *__restrict__ grad_scale,
-                                                         float *__restrict__ dW) {
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= Q) return;
+                                                         const float *__restrict__ V, const int32_t *__restrict__ ent_len,
+                                                         int F, int Nb, int Ne, int Q, int D,
+                                                         const float *__restrict__ grad_scale, float *__restrict__ dW) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x;
+  const int a = q / Ne, en = q - a * Ne;
+  if (en >= ent_len[a]) {                        // masked slot: dS is 0 for every frame
+    for (int d = threadIdx.x * 4; d < D; d += 1024) *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   f32x4 acc[MAXCH];
 #pragma unroll
   for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int f = 0; f < F; f++) {
-    const float ds = dS[(size_t)f * Q + q];
-    if (ds == 0.f) continue;
-    const float *vr = V + ((size_t)f * Nb + (int)D_ind[(size_t)f * Q + q]) * D;
+  for (int f0 = wave; f0 < F; f0 += 16) {
+    float ds[4];
+    const float *vr[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int f = f0 + 4 * u;
+      ds[u] = f < F ? dS[(size_t)f * Q + q] : 0.f;
+      const int ix = f < F ? (int)D_ind[(size_t)f * Q + q] : 0;
+      vr[u] = V + ((size_t)(f < F ? f : 0) * Nb + ix) * D;
+    }
+    // all four rows are requested before the first is used; a frame with ds == 0 (inactive hinge, or beyond F) adds +-0
 #pragma unroll
     for (int c = 0; c < MAXCH; c++) {
       const int d = lane * 4 + c * 256;
-      if (d < D) acc[c] += ds * *reinterpret_cast<const f32x4 *>(vr + d);
+      if (d < D) {
+        f32x4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = *reinterpret_cast<const f32x4 *>(vr[u] + d);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[c] += ds[u] * r[u];
+      }
     }
   }
 #pragma unroll
   for (int c = 0; c < MAXCH; c++) {
     const int d = lane * 4 + c * 256;
-    if (d < D) *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = grad_scale ? acc[c] * grad_scale[0] : acc[c];
+    if (d < D) *reinterpret_cast<f32x4 *>(&red[wave * D + d]) = acc[c];
+  }
+  __syncthreads();
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    f32x4 t = *reinterpret_cast<const f32x4 *>(&red[d]);
+    t += *reinterpret_cast<const f32x4 *>(&red[D + d]);
+    t += *reinterpret_cast<const f32x4 *>(&red[2 * D + d]);
+    t += *reinterpret_cast<const f32x4 *>(&red[3 * D + d]);
+    *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = grad_scale ? t * grad_scale[0] : t;
   }
 }
 
@@ -822,18 +1057,30 @@ int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D) {
   return (int64_t)(loss_ws(Na, Ns, Nb, Ne, D).total * sizeof(float));
 }
 
-int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V, const int32_t *ent_len, int Na,
-                       int Ns, int Nb, int Ne, int D, float Delta, float vis_lam, int train, float *loss_out,
-                       float *dS, void *workspace, void *stream) {
+int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float *V, const int32_t *ent_len, int Na,
+                          int Ns, int Nb, int Ne, int D, float Delta, float vis_lam, int train, int max_live_cols,
+                          float *loss_out, float *dS, void *workspace, void *stream) {
   if (!S_max || !D_ind || !ent_len || !loss_out || !workspace) return NAFAE_EINVAL;
   if (Na <= 0 || Ns <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
   if (train && !V) return NAFAE_EINVAL;
   const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
   float *ws = reinterpret_cast<float *>(workspace);
-  hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
+  const int Q = Na * Ne;
+  int Lcap = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
+  if (Lcap < 1) Lcap = 1;
+  const size_t tail_lds = loss_tail_lds_bytes(Na, Ns, Ne, Lcap);
+  if (tail_lds <= 150 * 1024) {     // everything on chip (see loss_tail_lds_kernel); else the global-memory version
+    if (tail_lds > 64 * 1024 &&
+        nafae::allow_dynamic_lds(reinterpret_cast<const void *>(loss_tail_lds_kernel), 150 * 1024) != NAFAE_OK)
+      return NAFAE_ELAUNCH;
+    hipLaunchKernelGGL(loss_tail_lds_kernel, dim3(1), dim3(1024), tail_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws,
+                       L, Lcap);
+  } else {
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
+  }
   if (train) {
     if (Ns > 64) return NAFAE_ELIMIT;
-    const size_t lds = (size_t)2 * Ns * D * sizeof(float);
+    const size_t lds = (size_t)(2 * Ns + 1) * D * sizeof(float);
     if (lds > 64 * 1024) {
       if (lds > 144 * 1024) return NAFAE_ELIMIT;
       if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(cluster_kernel), 144 * 1024) != NAFAE_OK) return NAFAE_ELAUNCH;
@@ -843,6 +1090,13 @@ int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V,
   }
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, S(stream), ws, L, Na, Ne, vis_lam, train, loss_out);
   return launched();
+}
+
+int nafae_loss_fwd_bwd(const float *S_max, const int64_t *D_ind, const float *V, const int32_t *ent_len, int Na,
+                       int Ns, int Nb, int Ne, int D, float Delta, float vis_lam, int train, float *loss_out,
+                       float *dS, void *workspace, void *stream) {
+  return nafae_loss_fwd_bwd_ex(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, D, Delta, vis_lam, train, -1, loss_out, dS, workspace,
+                               stream);
 }
 
 int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, const float *W, const int32_t *ent_len,
@@ -856,7 +1110,8 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
   const int Q = Na * Ne, R = F * Nb;
   hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, cluster_rows,
                      Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
-  hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3((Q + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, V, F, Nb, Q, D, grad_scale, dW);
+  hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3(Q), dim3(256), (size_t)4 * D * sizeof(float), S(stream), dS, D_ind, V, ent_len, F, Nb,
+                     Ne, Q, D, grad_scale, dW);
   return launched();
 }
 

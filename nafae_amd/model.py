@@ -190,7 +190,7 @@ class _DVSAFn(torch.autograd.Function):
         need = V.requires_grad or W.requires_grad
         with ops.timed("loss_tail"):
             loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train,
-                                                need_grad=need)
+                                                need_grad=need, lens=lens)
         if need:
             ctx.save_for_backward(V, W, ent_len, D_ind, dS, ws)
         ctx.dims = (Na, Ns, Nb, Ne, train)

@@ -522,17 +522,19 @@ def loss_workspace(Na, Ns, Nb, Ne, D, device):
     return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
 
 
-def loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=True, workspace=None):
-    """-> (loss_out f32[4] = margin_loss, mean frame_score, vis_loss, dem; dS [F,Q] or None; workspace)."""
+def loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=True, workspace=None, lens=None):
+    """-> (loss_out f32[4] = margin_loss, mean frame_score, vis_loss, dem; dS [F,Q] or None; workspace).
+    `lens`: the host-side entity_length list, if available (sizes the on-chip ranking-term kernel for the live slots)."""
     _chk(S_max); _chk(D_ind, torch.int64); _chk(V); _chk(ent_len, torch.int32)
     D = V.shape[1]
     if workspace is None:
         workspace = loss_workspace(Na, Ns, Nb, Ne, D, S_max.device)
     loss_out = torch.empty(4, device=S_max.device, dtype=torch.float32)
     dS = torch.empty_like(S_max) if need_grad else None
-    _rc(_lib.lib().nafae_loss_fwd_bwd(_p(S_max), _p(D_ind), _p(V), _p(ent_len), Na, Ns, Nb, Ne, D, float(Delta),
-                                      float(vis_lam), int(bool(train)), _p(loss_out), _p(dS), _p(workspace), _stream()),
-        "nafae_loss_fwd_bwd")
+    live = _live_cols(lens, Ne)
+    _rc(_lib.lib().nafae_loss_fwd_bwd_ex(_p(S_max), _p(D_ind), _p(V), _p(ent_len), Na, Ns, Nb, Ne, D, float(Delta),
+                                         float(vis_lam), int(bool(train)), -1 if live is None else live, _p(loss_out), _p(dS),
+                                         _p(workspace), _stream()), "nafae_loss_fwd_bwd_ex")
     return loss_out, dS, workspace
 
 

@@ -180,7 +180,8 @@ class _FrameShardedDVSAFn(torch.autograd.Function):
         if train:
             broadcast_rows(V0, 0, group)
         need = V.requires_grad or W.requires_grad
-        loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, V0, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=need)
+        loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, V0, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=need,
+                                            lens=lens)
         if need:
             ctx.save_for_backward(V, W, ent_len, D_loc, dS[rank * Fl:(rank + 1) * Fl].contiguous(), ws)
         ctx.dims = (Na, Ns, Nb, Ne, bool(train) and rank == 0)

@@ -56,7 +56,7 @@ class CpuKernels:
         return S_max.contiguous(), D_ind.contiguous()
 
     @staticmethod
-    def loss_fwd_bwd(S_max, D_ind, V0, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=True):
+    def loss_fwd_bwd(S_max, D_ind, V0, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, need_grad=True, lens=None):
         lens = [int(x) for x in ent_len]
         with torch.enable_grad():        # (called from inside an autograd.Function.forward, where grad mode is off)
             S = S_max.detach().clone().requires_grad_(True)
