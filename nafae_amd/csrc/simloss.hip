@@ -494,23 +494,36 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// any number of waves (<= 16), fixed order
+__device__ __forceinline__ float block_sum_n(float v, float *red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int k = 0; k < nw; k++) t += red[k];
+  return t;
+}
 
-// grid Na*Ne, block 256.  Dynamic LDS: g[Ns][D] raw gathered rows, G[Ns][D] normalised * sn, tot[D] = sum_s G[s].
+// grid Na*Ne, block 512 (8 waves: one per frame row at Ns = 8).  Dynamic LDS: g[Ns][D] raw gathered rows, G[Ns][D]
+// normalised * sn, tot[D] = sum_s G[s].
 // All Ns gathered rows are requested in ONE pass (independent 16-B loads, one barrier) and the per-row reductions (norm,
 // g . dG) are wave reductions -- a wave owns rows w, w+4, ... -- instead of Ns sequential block reductions with a global
 // round trip each (the first version: 36 us, most of it that serialised gather).
-__global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
+__global__ __launch_bounds__(512) void cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
                                                       const float *__restrict__ V,
                                                       const int32_t *__restrict__ ent_len, int Na, int Ns, int Ne,
                                                       int D, float *__restrict__ ws, LossWs L) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  __shared__ float red[4];
+  __shared__ float red[16];
   __shared__ float s_sn[64], s_nrm[64], s_dot[64];
   __shared__ int s_idx[64];
   float *g = sm, *G = sm + (size_t)Ns * D, *tot = G + (size_t)Ns * D;
   const int ae = blockIdx.x, a = ae / Ne, en = ae - a * Ne;
   const int Q = Na * Ne, q = a * Ne + en;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nt = blockDim.x, nw = nt >> 6;
   float *part_sum = ws + L.part_sum, *part_cnt = ws + L.part_cnt;
   int *cidx = reinterpret_cast<int *>(ws + L.cidx) + (size_t)ae * Ns;
   float *dgc = ws + L.dgc + (size_t)ae * Ns * D;
@@ -519,11 +532,11 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
       part_sum[ae] = 0.f;
       part_cnt[ae] = 0.f;
     }
-    for (int s = tid; s < Ns; s += 256) cidx[s] = -1;
+    for (int s = tid; s < Ns; s += nt) cidx[s] = -1;
     return;
   }
   const float lo = ws[L.mn + a * Q + q], hi = ws[L.mx + a * Q + q];
-  for (int s = tid; s < Ns; s += 256) {
+  for (int s = tid; s < Ns; s += nt) {
     const size_t o = ((size_t)a * Ns + s) * Q + q;
     s_sn[s] = (Sm[o] - lo) / (hi - lo + EPS);  // model.py:567 (no grad)
     const int ix = (int)D_ind[o];              // in [0, Nb): indexes V WITHOUT a frame offset (model.py:562-569)
@@ -532,12 +545,12 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
   }
   __syncthreads();
   const int d4n = D >> 2;
-  for (int i = tid; i < Ns * d4n; i += 256) {
+  for (int i = tid; i < Ns * d4n; i += nt) {
     const int s = i / d4n, d4 = i - s * d4n;
     *reinterpret_cast<f32x4 *>(&g[s * D + d4 * 4]) = *reinterpret_cast<const f32x4 *>(V + (size_t)s_idx[s] * D + d4 * 4);
   }
   __syncthreads();
-  for (int s = wave; s < Ns; s += 4) {
+  for (int s = wave; s < Ns; s += nw) {
     float acc = 0.f;
     for (int d = lane; d < D; d += 64) acc += g[s * D + d] * g[s * D + d];
 #pragma unroll
@@ -545,19 +558,19 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
     if (lane == 0) s_nrm[s] = sqrtf(acc);
   }
   __syncthreads();
-  for (int i = tid; i < Ns * D; i += 256) {
+  for (int i = tid; i < Ns * D; i += nt) {
     const int s = i / D;
     G[i] = (g[i] / (s_nrm[s] + EPS)) * s_sn[s];  // (g / (norm + EPS)) * sn   (model.py:570-571)
   }
   __syncthreads();
-  for (int d = tid; d < D; d += 256) {
+  for (int d = tid; d < D; d += nt) {
     float t = 0.f;
     for (int s2 = 0; s2 < Ns; s2++) t += G[s2 * D + d];
     tot[d] = t;
   }
   // gram: 1 - G_s . G_s' for s != s' (model.py:574-575); sum and count of non-zeros (model.py:576)
   float lsum = 0.f, lcnt = 0.f;
-  for (int p = wave; p < Ns * Ns; p += 4) {
+  for (int p = wave; p < Ns * Ns; p += nw) {
     const int s1 = p / Ns, s2 = p - s1 * Ns;
     if (s1 == s2) continue;
     float acc = 0.f;
@@ -571,14 +584,14 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
     }
   }
   // (lane 0 of each wave holds its partials; everyone else 0)
-  lsum = block_sum(lsum, red);
-  lcnt = block_sum(lcnt, red);       // (its barriers also publish tot[])
+  lsum = block_sum_n(lsum, red);
+  lcnt = block_sum_n(lcnt, red);       // (its barriers also publish tot[])
   if (tid == 0) {
     part_sum[ae] = lsum;
     part_cnt[ae] = lcnt;
   }
   // gradient wrt the gathered rows, unscaled by 10*vis_lam/dem: dG_s = -2 (sum_s' G_s' - G_s)
-  for (int s = wave; s < Ns; s += 4) {
+  for (int s = wave; s < Ns; s += nw) {
     float acc = 0.f;
     for (int d = lane; d < D; d += 64) acc += g[s * D + d] * (-2.0f * (tot[d] - G[s * D + d]));
 #pragma unroll
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(256) void cluster_kernel(const float *__restrict__ 
     if (lane == 0) s_dot[s] = acc;
   }
   __syncthreads();
-  for (int i = tid; i < Ns * D; i += 256) {
+  for (int i = tid; i < Ns * D; i += nt) {
     const int s = i / D, d = i - s * D;
     const float n = s_nrm[s], ne = n + EPS, sn = s_sn[s];
     // u = g/(n+EPS), G = sn*u;  dg = sn * ( dG/(n+EPS) - g * (g.dG) / (n * (n+EPS)^2) )
@@ -677,14 +690,19 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
   if (train && r < Nb) {  // clustering gradient lands on rows [0, Nb) only (reference quirk)
     const int *cidx = reinterpret_cast<const int *>(ws + L.cidx);
     const float cscale = ws[L.scal + 1];
-    for (int tb = 0; tb < n_centries; tb += 64) {
-      const int t = tb + lane;
-      const bool hit = t < n_centries && cidx[t] == r;
+    // entries t = (slot q, frame s) of live slots only: q*Ns + s (masked slots hold cidx = -1 and no gradient)
+    const int Nsc = n_centries / Q;
+    const int ne = live ? nq * Nsc : n_centries;
+    for (int tb = 0; tb < ne; tb += 64) {
+      const int e = tb + lane;
+      int t = -1;
+      if (e < ne) t = live ? live[4 + e / Nsc] * Nsc + e % Nsc : e;
+      const bool hit = t >= 0 && cidx[t] == r;
       unsigned long long m = __ballot(hit);
       while (m) {
         const int i = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const float *gr = ws + L.dgc + (size_t)(tb + i) * D;
+        const float *gr = ws + L.dgc + (size_t)__shfl(t, i) * D;
 #pragma unroll
         for (int c = 0; c < MAXCH; c++) {
           const int d = lane * 4 + c * 256;
@@ -1085,7 +1103,7 @@ int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float 
       if (lds > 144 * 1024) return NAFAE_ELIMIT;
       if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(cluster_kernel), 144 * 1024) != NAFAE_OK) return NAFAE_ELAUNCH;
     }
-    hipLaunchKernelGGL(cluster_kernel, dim3(Na * Ne), dim3(256), lds, S(stream), S_max, D_ind, V, ent_len, Na, Ns, Ne, D,
+    hipLaunchKernelGGL(cluster_kernel, dim3(Na * Ne), dim3(512), lds, S(stream), S_max, D_ind, V, ent_len, Na, Ns, Ne, D,
                        ws, L);
   }
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, S(stream), ws, L, Na, Ne, vis_lam, train, loss_out);
