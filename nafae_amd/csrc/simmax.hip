@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "hip_util.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -211,12 +213,14 @@ __global__ __launch_bounds__(512) void sim_part_kernel(const float *__restrict__
       vsrc[j] = V + ((size_t)f * Nb + row) * D + (size_t)c0 * 32 + slot * 4;
     }
   };
-  auto dma_chunk = [&](int ci) {         // chunk ci of this wave's k-range -> ring slot ci % NB
+  auto dma_piece = [&](int ci, int j) {  // 8 rows x 128 B of chunk ci of this wave's k-range -> ring slot ci % NB
     unsigned char *dst = ring + (size_t)(ci % NB) * CHUNK_BYTES;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc[j] + (size_t)ci * 32),
+                                     (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+  };
+  auto dma_chunk = [&](int ci) {
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc[j] + (size_t)ci * 32),
-                                       (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+    for (int j = 0; j < 4; j++) dma_piece(ci, j);
   };
   const int rho0 = sg * RPW;
   set_rows(rho0);
@@ -286,33 +290,50 @@ __global__ __launch_bounds__(512) void sim_part_kernel(const float *__restrict__
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
-    for (int ci = 0; ci < cpw; ci++) {
-      // chunk ci has landed once at most the (NB-1) younger chunks' DMAs are outstanding; near the end fewer are younger
-      if (ci + NB - 1 < cpw) wait_vm<4 * (NB - 1)>(); else wait_vm<0>();
+    // One chunk; MORE (a refill exists) and the wait count are compile-time -- two copies of the body, no runtime branch
+    // between the fragment reads and the MFMAs (see sim_tile_kernel).
+    auto chunk = [&](int ci, auto more_tag, auto wait_tag) {
+      constexpr bool MORE = decltype(more_tag)::value;
+      wait_vm<decltype(wait_tag)::value>();
       const unsigned char *ap = ring + (size_t)(ci % NB) * CHUNK_BYTES + lr * 128;
-      bf16x8 ahi[2], alo[2];
+      f32x4 x[4];
 #pragma unroll
       for (int t = 0; t < 2; t++) {
         const int s0 = 4 * t + 2 * h;
-        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(ap + ((s0 ^ aswz) << 4));
-        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(ap + (((s0 + 1) ^ aswz) << 4));
-        split8(x0, x1, ahi[t], alo[t]);
+        x[2 * t] = *reinterpret_cast<const f32x4 *>(ap + ((s0 ^ aswz) << 4));
+        x[2 * t + 1] = *reinterpret_cast<const f32x4 *>(ap + (((s0 + 1) ^ aswz) << 4));
       }
-      // the fragments are in registers: the slot can be refilled (the DMA is ordered behind these reads by lgkmcnt(0))
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (ci + NB < cpw) dma_chunk(ci + NB);
-      if (active) {
+      bf16x8 bhi[2], blo[2];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const unsigned char *bp = bbase + (size_t)((c0 + ci) * 2 + t) * (4 * NC * 16);
-          const bf16x8 bhi = *reinterpret_cast<const bf16x8 *>(bp);
-          const bf16x8 blo = *reinterpret_cast<const bf16x8 *>(bp + NC * 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], bhi, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], blo, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], bhi, acc, 0, 0, 0);
-        }
+      for (int t = 0; t < 2; t++) {
+        const unsigned char *bp = bbase + (size_t)((c0 + ci) * 2 + t) * (4 * NC * 16);
+        bhi[t] = *reinterpret_cast<const bf16x8 *>(bp);
+        blo[t] = *reinterpret_cast<const bf16x8 *>(bp + NC * 16);
       }
-    }
+      bf16x8 ahi[2], alo[2];
+      split8(x[0], x[1], ahi[0], alo[0]);
+      split8(x[2], x[3], ahi[1], alo[1]);
+      // the fragments are in registers (the MFMAs below wait for them): the slot can be refilled, one staging instruction
+      // per MFMA so that its issue cost overlaps queued matrix work
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], bhi[t], acc, 0, 0, 0);
+        if (MORE) dma_piece(ci + NB, 2 * t);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], blo[t], acc, 0, 0, 0);
+        if (MORE) dma_piece(ci + NB, 2 * t + 1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], bhi[t], acc, 0, 0, 0);
+      }
+    };
+    using T = std::true_type;
+    using Fl = std::false_type;
+    // (an inactive wave -- row block beyond the batch -- runs the same code on clamped rows; its result is dropped)
+    const int nmain = cpw - NB > 0 ? cpw - NB : 0;          // chunks that still have a refill
+    int ci = 0;
+    for (; ci < nmain; ci++) chunk(ci, T{}, std::integral_constant<int, 4 * (NB - 1)>{});
+    // no refill any more: chunk ci is done once the (cpw - 1 - ci) younger chunks are all that is outstanding; waiting for
+    // everything is at most NB - 1 chunks early
+    for (; ci < cpw; ci++) chunk(ci, Fl{}, std::integral_constant<int, 0>{});
     STAMP(4);
 
     if (KS > 1) {          // sum the k-splits of a row block in a fixed order (ks = 1, 2, ... onto ks = 0)
@@ -365,6 +386,190 @@ __global__ __launch_bounds__(512) void sim_part_kernel(const float *__restrict__
       if (h == 0 && c < Ql) part[(size_t)rb * Qpad + c] = pack_part(n1, k1, n2, k2);
     }
     STAMP(6);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- dense path
+// More than 64 live query slots (C5 with every slot live: 512): one 32-column group per workgroup would stream V 16 times and
+// repeat the fp32 -> bf16 hi/lo split of every V fragment for each of them (VALU-bound).  Here a workgroup owns 128 rows x 128
+// live columns: the split of an A fragment is amortised over 4 column blocks (24 MFMAs per 32-k chunk and wave), V is re-read
+// Q/128 times, and BOTH operands arrive by LDS-DMA in one ring of NB chunks -- W is converted once per call into bf16 hi/lo
+// planes in fragment order by sim_wprep_kernel (the k-loop must not contain ordinary global loads: beside outstanding LDS-DMA
+// the compiler waits vmcnt(0) at their first use and drains the ring), so a chunk of W is a linear 16 KB copy.
+constexpr int TILE_COLS = 128;
+constexpr int WCHUNK_BYTES = 2 * 2 * 2 * TILE_COLS * 16;   // [k-step][half][plane][column][16 B] = 16 KB per 32 k
+
+// grid (nchunks, G128); writes wprep[(cg * nchunks + ci) * 16 KB ...] and, once, the live-column count into hdr[0]
+__global__ __launch_bounds__(256) void sim_wprep_kernel(const float *__restrict__ Wm, const int32_t *__restrict__ ent_len, int Na,
+                                                        int Ne, int D, unsigned char *__restrict__ wprep, int *__restrict__ hdr) {
+  __shared__ int prefix[NA_MAX + 1];
+  __shared__ int qmap[TILE_COLS];
+  build_prefix(ent_len, Na, Ne, prefix);
+  __syncthreads();
+  const int Ql = prefix[Na];
+  const int ci = blockIdx.x, cg = blockIdx.y, nchunks = gridDim.x;
+  if (ci == 0 && cg == 0 && threadIdx.x == 0) hdr[0] = Ql;
+  if (threadIdx.x < TILE_COLS) {
+    const int c = cg * TILE_COLS + threadIdx.x;
+    int q = -1;
+    if (c < Ql) {
+      const int a = find_seg(prefix, Na, c);
+      q = a * Ne + (c - prefix[a]);
+    }
+    qmap[threadIdx.x] = q;
+  }
+  __syncthreads();
+  unsigned char *dst = wprep + ((size_t)cg * nchunks + ci) * WCHUNK_BYTES;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int idx = threadIdx.x + 256 * u;        // 128 columns x 8 float4 of this chunk
+    const int cl = idx >> 3, k4 = idx & 7;
+    const int q = qmap[cl];
+    f32x4 w = {0.f, 0.f, 0.f, 0.f};
+    if (q >= 0) w = *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + ci * 32 + k4 * 4);
+    bf16x4 whi, wlo;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const __bf16 t = (__bf16)w[e];
+      whi[e] = t;
+      wlo[e] = (__bf16)(w[e] - (float)t);
+    }
+    const int k = k4 * 4;                         // 0..28 inside the chunk: k-step t = k >> 4, half = (k >> 3) & 1
+    const int off = ((((k >> 3) * 2) * TILE_COLS) + cl) * 16 + (k & 4) * 2;
+    *reinterpret_cast<bf16x4 *>(dst + off) = whi;
+    *reinterpret_cast<bf16x4 *>(dst + off + TILE_COLS * 16) = wlo;
+  }
+}
+
+// grid: ceil(NRG / 8) * 8 * G128 workgroups of NWT waves; NRG = row groups of NWT row blocks (32 * NWT proposals).
+// LDS: NB x (16 KB of W + NWT x 4 KB of V).  NWT = 8 (two waves per SIMD): with one wave per SIMD nothing hides the latency of
+// the 20 fragment reads per chunk (ablation: the loop took the same 60 us with the MFMAs and the DMAs removed).
+template <int NB, int NWT>
+__global__ __launch_bounds__(64 * NWT) void sim_tile_kernel(const float *__restrict__ V, const unsigned char *__restrict__ wprep,
+                                                       const int *__restrict__ hdr, int F, int Nb, int D, int nrb, int G,
+                                                       int Qpad, f32x4 *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+  constexpr int WP = 16 / NWT;           // 1 KB pieces of a W chunk per wave
+  constexpr int PP = 4 + WP;             // staging instructions per chunk and wave
+  const int TRB = F * nrb, NRG = (TRB + NWT - 1) / NWT;
+  const int blk8 = blockIdx.x >> 3;
+  const int rho = (blk8 / G) * 8 + (blockIdx.x & 7);
+  const int g = blk8 % G;
+  if (rho >= NRG) return;
+  const int Ql = hdr[0];
+  if (g * TILE_COLS >= Ql) return;
+  const int nchunks = D >> 5;
+  unsigned char *wring = smem;                                        // [NB][16 KB]
+  unsigned char *vring = smem + (size_t)NB * WCHUNK_BYTES + (size_t)wave * NB * CHUNK_BYTES;
+
+  const int rb = rho * NWT + wave;
+  const bool active = rb < TRB;
+  const int rbc = active ? rb : TRB - 1;
+  const int f = rbc / nrb, b0 = (rbc - f * nrb) * 32;
+  const float *vsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int rl = 8 * j + (lane >> 3);
+    int row = b0 + rl;
+    row = row < Nb ? row : Nb - 1;
+    vsrc[j] = V + ((size_t)f * Nb + row) * D + ((lane & 7) ^ ((rl >> 1) & 7)) * 4;
+  }
+  const unsigned char *wsrc = wprep + (size_t)g * nchunks * WCHUNK_BYTES + (size_t)wave * (WP * 1024) + lane * 16;
+  // piece p of chunk ci: p = 0..3 this wave's V rows (8 rows x 128 B each), p = 4.. this wave's share of the W chunk
+  auto dma_piece = [&](int ci, int p) {
+    const int slot = ci % NB;
+    if (p < 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc[p] + (size_t)ci * 32),
+                                       (__attribute__((address_space(3))) void *)(vring + (size_t)slot * CHUNK_BYTES + p * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)ci * WCHUNK_BYTES + (p - 4) * 1024),
+                                       (__attribute__((address_space(3))) void *)(wring + (size_t)slot * WCHUNK_BYTES + wave * (WP * 1024) + (p - 4) * 1024),
+                                       16, 0, 0);
+  };
+  for (int ci = 0; ci < NB - 1 && ci < nchunks; ci++) {
+#pragma unroll
+    for (int p = 0; p < PP; p++) dma_piece(ci, p);
+  }
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+  const int aswz = (lr >> 1) & 7;
+  // One chunk.  MORE / the wait count are compile-time (two copies of the body: steady state and tail), and there is no
+  // branch between the fragment reads and the MFMAs: with runtime conditions in here hipcc cut the unrolled body into one
+  // basic block per column block, each "2 ds_read_b128 -> lgkmcnt(0) -> 3 MFMAs" serialised on the LDS latency (measured:
+  // 2 600 cycles per chunk, the same with the MFMAs removed).  All 8 B fragments of a k-step are requested before its MFMAs.
+  auto chunk = [&](int ci, auto more_tag, auto wait_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    wait_vm<decltype(wait_tag)::value>();
+    __builtin_amdgcn_s_barrier();        // everyone's share of W(ci) has landed; everyone is done reading slot (ci - 1) % NB
+    const unsigned char *ap = vring + (size_t)(ci % NB) * CHUNK_BYTES + lr * 128;
+    const unsigned char *wp = wring + (size_t)(ci % NB) * WCHUNK_BYTES + (size_t)(h * 2 * TILE_COLS + lr) * 16;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int s0 = 4 * t + 2 * h;
+      const f32x4 x0 = *reinterpret_cast<const f32x4 *>(ap + ((s0 ^ aswz) << 4));
+      const f32x4 x1 = *reinterpret_cast<const f32x4 *>(ap + (((s0 + 1) ^ aswz) << 4));
+      const unsigned char *bp = wp + (size_t)t * (4 * TILE_COLS * 16);
+      bf16x8 bhi[4], blo[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; cb++) {
+        bhi[cb] = *reinterpret_cast<const bf16x8 *>(bp + cb * 512);
+        blo[cb] = *reinterpret_cast<const bf16x8 *>(bp + TILE_COLS * 16 + cb * 512);
+      }
+      bf16x8 ahi, alo;
+      split8(x0, x1, ahi, alo);
+#pragma unroll
+      for (int cb = 0; cb < 4; cb++) {
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[cb], acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[cb], acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[cb], acc[cb], 0, 0, 0);
+        // the staging instructions of chunk ci + NB - 1 go out one per MFMA group (each costs 60-185 issue cycles)
+        if (MORE && t * 4 + cb < PP) dma_piece(ci + NB - 1, t * 4 + cb);
+      }
+    }
+  };
+  using T = std::true_type;
+  using Fl = std::false_type;
+  // issued before iteration ci: chunks 0 .. ci + NB - 2, so (NB - 2) chunks are younger than ci while they all exist
+  const int nmain = nchunks - (NB - 1) > 0 ? nchunks - (NB - 1) : 0;
+  int ci = 0;
+  for (; ci < nmain; ci++) chunk(ci, T{}, std::integral_constant<int, PP * (NB - 2)>{});
+  for (; ci < nchunks; ci++) chunk(ci, Fl{}, std::integral_constant<int, 0>{});
+  if (!active) return;
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++) {
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int i1 = 0, i2 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = acc[cb][r];
+      if (row < Nb) {
+        if (v > m1) {
+          m2 = m1; i2 = i1; m1 = v; i1 = row;
+        } else if (v > m2) {
+          m2 = v; i2 = row;
+        }
+      }
+    }
+    const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+    const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
+    float n1, n2;
+    int k1, k2;
+    if (better(o1, j1, m1, i1)) {
+      n1 = o1; k1 = j1;
+      if (better(m1, i1, o2, j2)) { n2 = m1; k2 = i1; } else { n2 = o2; k2 = j2; }
+    } else {
+      n1 = m1; k1 = i1;
+      if (better(m2, i2, o1, j1)) { n2 = m2; k2 = i2; } else { n2 = o1; k2 = j1; }
+    }
+    const int c = g * TILE_COLS + cb * 32 + lr;
+    if (h == 0 && c < Ql) part[(size_t)rb * Qpad + c] = pack_part(n1, k1, n2, k2);
   }
 }
 
@@ -470,7 +675,8 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict
 }
 
 struct Plan {
-  int ok, NCB, NC, G, KS, RBW, RPW, NW, NB, scratch, nrb, TRB, NRG, NSG, Qpad, Qh;
+  int ok, dense, NCB, NC, G, KS, RBW, RPW, NW, NB, scratch, nrb, TRB, NRG, NSG, Qpad, Qh;
+  int64_t wprep_off;     // dense path: byte offset of the converted-W area (after the partials); header int right before it
   size_t lds;
   int64_t ws_bytes;
 };
@@ -483,12 +689,25 @@ inline Plan make_plan(int F, int Nb, int Na, int Ne, int D, int max_live) {
   p.Qh = Qh;
   p.ok = (D % 32 == 0) && D <= 512 && Na <= NA_MAX && F >= 1 && Nb >= 1 && Nb <= 2048;   // (Nb: <= 64 row blocks per frame)
   if (!p.ok) return p;
-  p.NCB = 1;
-  p.NC = 32;
-  p.G = (Qh + p.NC - 1) / p.NC;
   p.nrb = (Nb + 31) / 32;
   p.TRB = F * p.nrb;
   const int nchunks = D / 32;
+  if (Qh > 64) {          // dense path: 128-column tiles, W pre-converted (sim_wprep_kernel + sim_tile_kernel)
+    p.dense = 1;
+    p.G = (Qh + TILE_COLS - 1) / TILE_COLS;
+    p.Qpad = p.G * TILE_COLS;
+    p.NW = 4;
+    p.NRG = (p.TRB + p.NW - 1) / p.NW;
+    p.NB = 2;
+    p.lds = (size_t)p.NB * (WCHUNK_BYTES + p.NW * CHUNK_BYTES);
+    const int64_t parts = (int64_t)p.TRB * p.Qpad * 16;
+    p.wprep_off = ((parts + 255) / 256) * 256 + 256;
+    p.ws_bytes = p.wprep_off + (int64_t)p.G * nchunks * WCHUNK_BYTES;
+    return p;
+  }
+  p.NCB = 1;
+  p.NC = 32;
+  p.G = (Qh + p.NC - 1) / p.NC;
   // One workgroup fits per CU (W planes + rings ~ 156 KB of LDS).  K is split over the waves of a workgroup only while
   // 4-wave workgroups of whole row blocks would leave CUs without any workgroup (fewer than 1024 row blocks x column
   // groups); workgroups have 8 waves (two per SIMD, 2-chunk rings) once every CU gets at least 8 waves of work anyway,
@@ -538,9 +757,9 @@ int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D) {
   if (F <= 0 || Nb <= 0 || Na <= 0 || Ne <= 0 || D <= 0) return NAFAE_EINVAL;
   const Plan p = make_plan(F, Nb, Na, Ne, D, -1);
   if (!p.ok) return 0;                   // the fallback kernel needs none
-  // the all-live plan is the largest (ws = TRB * Qpad * 16 with Qpad = Q rounded up to a column group)
-  const int64_t q64 = ((int64_t)Na * Ne + 63) / 64 * 64;
-  return (int64_t)p.TRB * q64 * 16;
+  // the all-live plan is the largest: partials for Q rounded up to a 128-column tile + the converted W + header
+  const int64_t q128 = ((int64_t)Na * Ne + 127) / 128 * 128;
+  return (int64_t)p.TRB * q128 * 16 + 1024 + q128 * D * 4;
 }
 
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
@@ -552,6 +771,26 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
   if (!p.ok) return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
   if (!workspace || workspace_bytes < p.ws_bytes) return NAFAE_EINVAL;
   if ((long)F * Na * Ne > (1L << 31) - 256) return NAFAE_ELIMIT;
+  if (p.dense) {
+    unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
+    int *hdr = reinterpret_cast<int *>(wsb + p.wprep_off - 256);
+    unsigned char *wprep = wsb + p.wprep_off;
+    f32x4 *part = reinterpret_cast<f32x4 *>(workspace);
+    hipStream_t st = as_stream(stream);
+    const int nchunks = D / 32;
+    hipLaunchKernelGGL(sim_wprep_kernel, dim3(nchunks, p.G), dim3(256), 0, st, W, ent_len, Na, Ne, D, wprep, hdr);
+    const void *tk = reinterpret_cast<const void *>(sim_tile_kernel<2, 4>);
+    if (p.lds > 64 * 1024) {
+      const int rc = allow_dynamic_lds(tk, 160 * 1024);
+      if (rc != NAFAE_OK) return rc;
+    }
+    const int grid = ((p.NRG + 7) / 8) * 8 * p.G;
+    hipLaunchKernelGGL((sim_tile_kernel<2, 4>), dim3(grid), dim3(256), p.lds, st, V, wprep, hdr, F, Nb, D, p.nrb, p.G, p.Qpad, part);
+    const long items = (long)F * p.Qh;
+    hipLaunchKernelGGL(sim_finish_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, part, V, W, ent_len, F, Nb, Na, Ne, D,
+                       p.nrb, p.Qpad, p.Qh, S_max, D_ind);
+    return launch_status();
+  }
   const void *kern = p.NB == 2 ? reinterpret_cast<const void *>(sim_part_kernel<2>)
                                : reinterpret_cast<const void *>(sim_part_kernel<5>);
   if (p.lds > 64 * 1024) {
