@@ -257,7 +257,14 @@ def launch_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            # rank 0 is done: the others finish within seconds -- or, if rank 0 died, hang in a collective: stop exactly them
+            rcs.append(p.wait(timeout=120 if rcs[0] == 0 else 10))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
