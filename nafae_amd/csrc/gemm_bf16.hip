@@ -424,60 +424,72 @@ struct ConvRun {
   // st = 9*cc + tap; a row-offset group is 3 consecutive steps, so st0 and st1 are multiples of 3; the whole tile is
   // [0, 9*Cin/32).  begin() points the lane at its staging chunks and issues the prologue loads; step() runs one
   // barrier-to-barrier step and accumulates into e.acc.
-  const __bf16 *xp[NXC], *wp[NWC];
-  int xpix[NXC];
-  bool wok[NWC];
+  // Per-lane staging descriptors.  A source address is  base + 32-bit byte offset;  in the I32 layout the base is the tensor
+  // itself (uniform: the plane / slot part lives in the offset) and chunk i+1 of a lane is the same (plane, slot) 64 rows
+  // further down, so ONE descriptor per side serves all chunks; the separate-plane layout keeps a per-lane base per chunk.
+  // Run pixels outside [0, M) and weight rows at or beyond Cout are CLAMPED to the nearest valid row rather than redirected
+  // to a zero page: such a pixel is only ever read through a masked tap (the fragment mask zeroes it in registers) and such a
+  // weight row only feeds output channels that are never stored.  That keeps the address arithmetic of a staging instruction
+  // at med3 + mad (the 64-bit compare / select form cost ~25 VALU instructions and 12 registers per instruction).
+  static constexpr int NXS = IL ? 1 : NXC, NWS = IL ? 1 : NWC;
+  const char *xbase[NXS], *wbase[NWS];
+  unsigned xlane[NXS], wlane[NWS];
+  int xpix[NXS], wrow[NWS];
+  int nrem;   // Cout - n0
   unsigned tapmask[NJ];
-  int st0, st1, M, W, CinS, dbg;
+  int st0, st1, M, W, CinS, K9S, wave, pbase;
   __bf16 *xbuf, *wbuf;
 
   __device__ __forceinline__ void issue_x(int i, int grp) const {  // chunk i of the run for group grp = (cc, dy)
     const int cc = grp / 3, dy = grp - cc * 3 - 1;
-    const long pix = (long)xpix[i] + (long)dy * W;
-    const __bf16 *src = (pix >= 0 && pix < M && dbg != 1) ? xp[i] + pix * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
-    char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + (threadIdx.x >> 6) * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+    const int k = IL ? 0 : i;
+    int pix = xpix[k] + (IL ? 64 * i : 0) + dy * W;
+    pix = min(max(pix, 0), M - 1) - pbase;   // (pbase: first pixel any chunk of this tile can touch, so the byte offset is small)
+    const unsigned off = (unsigned)pix * (unsigned)(CinS * 2) + xlane[k] + (unsigned)(cc * L::KTS * 2);
+    char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xbase[k] + off),
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   }
   __device__ __forceinline__ void issue_w(int i, int st) const {  // chunk i of the weight tile for step st = (cc, tap)
     const int cc = st / 9, tap = st - cc * 9;
-    const __bf16 *src = (wok[i] && dbg == 0) ? wp[i] + tap * CinS + cc * L::KTS : reinterpret_cast<const __bf16 *>(nafae_zero_page);
-    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + (threadIdx.x >> 6) * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+    const int k = IL ? 0 : i;
+    const int row = min(wrow[k] + (IL ? 64 * i : 0), nrem - 1);
+    const unsigned off = (unsigned)row * (unsigned)(K9S * 2) + wlane[k] + (unsigned)((tap * CinS + cc * L::KTS) * 2);
+    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wbase[k] + off),
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   }
 
   __device__ __forceinline__ void begin(const E &e, __bf16 *smem16, const ConvArgs &a, int m0, int n0, int s0, int s1) {
     const __bf16 *Xhi = a.Xhi, *Xlo = a.Xlo, *Whi = a.Whi, *Wlo = a.Wlo;
     const int H = a.H, Cout = a.Cout;
-    if (IL) {
-      Xlo = Xhi + BKH;
-      Wlo = Whi + BKH;
-    }
     W = a.W;
-    dbg = a.dbg;
-    CinS = a.Cin * L::RS;  // elements per pixel row / per weight tap (both planes when interleaved)
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    CinS = a.Cin * L::RS;      // elements per pixel row / per weight tap (both planes when interleaved)
+    K9S = 9 * a.Cin * L::RS;   // elements per weight row
     xbuf = smem16;
     wbuf = smem16 + 2 * XRUN;
     M = a.F * H * W;
     st0 = s0;
     st1 = s1;
-    const int K9 = 9 * a.Cin;
+    nrem = Cout - n0;
+    pbase = max(m0 - ROFF - W, 0);
     // activation-run chunks of this lane: run row -> pixel (p0 - ROFF + row) + dy*W
 #pragma unroll
-    for (int i = 0; i < NXC; i++) {
+    for (int i = 0; i < NXS; i++) {
       int plane, row, slot;
       L::template decode<RR>(threadIdx.x + NT16 * i, row, plane, slot);
       xpix[i] = m0 - ROFF + row;
-      xp[i] = (plane ? Xlo : Xhi) + slot * 8;
+      xbase[i] = reinterpret_cast<const char *>(IL ? Xhi : (plane ? Xlo : Xhi)) + (size_t)pbase * CinS * sizeof(__bf16);
+      xlane[i] = (unsigned)(((IL ? plane * BKH : 0) + slot * 8) * sizeof(__bf16));
     }
 #pragma unroll
-    for (int i = 0; i < NWC; i++) {
+    for (int i = 0; i < NWS; i++) {
       int plane, row, slot;
       L::template decode<BW>(threadIdx.x + NT16 * i, row, plane, slot);
-      const int n = n0 + row;
-      wok[i] = n < Cout;
-      wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
+      wrow[i] = row;
+      wbase[i] = reinterpret_cast<const char *>(IL ? Whi : (plane ? Wlo : Whi)) + (size_t)n0 * K9S * sizeof(__bf16);
+      wlane[i] = (unsigned)(((IL ? plane * BKH : 0) + slot * 8) * sizeof(__bf16));
     }
     // which taps of this lane's output pixels are inside the image
 #pragma unroll
@@ -505,36 +517,38 @@ struct ConvRun {
       }
   }
 
-  __device__ __forceinline__ void step(E &e, int st) {
-    const int g1 = st1 / 3;
-    // everything issued after W(st) may stay in flight: that is what step st-1 issued (only when DIST == 2)
-    if (DIST == 1 || st + 1 >= st1) {
+  // One barrier-to-barrier step: channel chunk cc = grp / 3, row offset dy = grp % 3 - 1, column offset dx = S - 1.
+  // Whether the next run / the next weight tile is due and how many DMAs may stay in flight depends only on (S, LAST =
+  // last group of the segment), so all of it is resolved at compile time: a runtime `if` around a staging instruction
+  // cuts the MFMA body into basic blocks, each entered through s_waitcnt lgkmcnt(0) with three MFMAs inside (that was the
+  // shape of this loop before; same finding as on the similarity kernels).
+  template <int S, bool LAST>
+  __device__ __forceinline__ void step_ct(E &e, int grp) {
+    constexpr bool DO_X = S == 0 && !LAST;            // stage the run of the next group
+    constexpr bool DO_W = !(LAST && S + DIST >= 3);   // stage the weight tile DIST steps ahead
+    // W(st) must have landed; what the previous step issued (DIST == 2 only) may stay in flight
+    if (DIST == 1 || (LAST && S == 2))
       wait_vmcnt<0>();
-    } else {
-      const int sp = st - 1;
-      const bool run_prev = sp >= st0 && (sp % 3 == 0) && (sp / 3 + 1 < g1);
-      if (run_prev)
-        wait_vmcnt<NWC + NXC>();
-      else
-        wait_vmcnt<NWC>();
-    }
+    else if (!LAST && S == 1)
+      wait_vmcnt<NWC + NXC>();
+    else
+      wait_vmcnt<NWC>();
     __builtin_amdgcn_s_barrier();
-    const int grp = st / 3;
-    const int tap = st - (st / 9) * 9;
-    const int dx = tap - (tap / 3) * 3 - 1;
-    const bool do_x = (st % 3 == 0) && (grp + 1 < g1);
-    const bool do_w = st + DIST < st1;
-    // staging instructions of this step, handed out between MFMA groups: first the next run, then the next weight tile
-    auto between = [&](int g) {
-      if (g < NXC) {
-        if (do_x) issue_x(g, grp + 1);
-      } else if (g - NXC < NWC) {
-        if (do_w) issue_w(g - NXC, st + DIST);
+    const int cc = grp / 3, dyi = grp - cc * 3;
+    const int tap = 3 * dyi + S, st = 3 * grp + S;
+    constexpr int dx = S - 1;
+    constexpr int NOPS = (DO_X ? NXC : 0) + (DO_W ? NWC : 0);
+    auto op = [&](int k) {  // staging instruction k of this step: first the next run, then the next weight tile
+      if (DO_X && k < NXC) {
+        issue_x(k, grp + 1);
+      } else {
+        const int w = k - (DO_X ? NXC : 0);
+        if (DO_W && w < NWC) issue_w(w, st + DIST);
       }
     };
-    if (NXC + NWC > NGRP) {
+    if (NOPS > NGRP) {
 #pragma unroll
-      for (int g = NGRP; g < NXC + NWC; g++) between(g);
+      for (int k = NGRP; k < NOPS; k++) op(k);
     }
     const __bf16 *sX = xbuf + (size_t)(grp & 1) * XRUN;
     const __bf16 *sW = wbuf + (size_t)(st % NSTW) * WST;
@@ -564,12 +578,69 @@ struct ConvRun {
         for (int j = 0; j < NJ; j++) {
           e.mma(i, j, wa, xa[j]);
           const int g = s * NI * NJ + i * NJ + j;
-          if (g < NGRP) between(g);
+          if (g < NGRP && g < NOPS) op(g);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keeps the live fragment set at one k-step's xa + one wa (the scheduler otherwise
+                                             // hoists the next k-step's 16 reads over 128 accumulator registers and spills)
       }
     }
   }
+  template <bool LAST>
+  __device__ __forceinline__ void group(E &e, int grp) {
+    step_ct<0, LAST>(e, grp);
+    step_ct<1, LAST>(e, grp);
+    step_ct<2, LAST>(e, grp);
+  }
 };
+
+// The work of one workgroup: units [u0, u1) of the launch's (tile, row-offset group) list, tile-major (ngrp = 3 * Cin/32 units
+// per tile).  A share that is exactly one tile is the plain one-tile-per-workgroup kernel; shares cut at arbitrary units are
+// the stream-K schedule below.  Segments = the pieces of a share that lie inside one tile.  A tile wholly inside the share is
+// finished here (epilogue); for a cut tile the fp32 partial accumulators go to `scratch` (slot 2w for the workgroup's first
+// segment, 2w+1 for its last).  Kept as ONE loop nest with run-time bounds for both kernels: with the straight-line
+// begin / loop / epilogue form the compiler computes the epilogue's per-lane addresses ahead of the loop and spills
+// loop-carried values to make room for them.
+template <class R, bool SPLITOUT>
+__device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, const ConvArgs &a, long u0, long u1, int ngrp, int tiles_n,
+                                          const float *__restrict__ bias, int relu, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                                          __bf16 *__restrict__ Clo, float *__restrict__ scratch) {
+  using E = typename R::E;
+  constexpr int NACC4 = E::NI * E::NJ * E::NG;   // float4 pieces of the accumulator per lane
+  R r;
+  for (long u = u0; u < u1;) {
+    const int t = (int)(u / ngrp);
+    const int ga = (int)(u - (long)t * ngrp);
+    const int gb = (u1 - u) < (long)(ngrp - ga) ? ga + (int)(u1 - u) : ngrp;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;   // the n-tiles of one pixel run back to back: its halo stays in L2
+    const int m0 = tm * R::E::BXT, n0 = tn * R::E::BWT;
+    if (u != u0) {
+      wait_vmcnt<0>();
+      __syncthreads();                                   // every wave is done with the previous segment's LDS buffers
+      e.zero_acc();
+    }
+    r.begin(e, smem16, a, m0, n0, 3 * ga, 3 * gb);
+    for (int grp = ga; grp + 1 < gb; grp++) r.template group<false>(e, grp);
+    r.template group<true>(e, gb - 1);
+    if (ga == 0 && gb == ngrp) {
+      epilogue<E, SPLITOUT>(e, m0, n0, a.F * a.H * a.W, a.Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo,
+                            a.Cout);
+    } else {
+      f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < E::NI; i++)
+#pragma unroll
+        for (int j = 0; j < E::NJ; j++)
+#pragma unroll
+          for (int g = 0; g < E::NG; g++) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
+            dst[(size_t)((i * E::NJ + j) * E::NG + g) * NT16] = v;
+          }
+    }
+    u += gb - ga;
+  }
+}
 
 template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool S16, bool PAIR = false>
 __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
@@ -583,13 +654,10 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
   e.init();
   int tm, tn;
   tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BX, n0 = tn * BW;
-  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout, (relu >> 8) & 3};
-  const int nst = 9 * (Cin / BKH);
-  R r;
-  r.begin(e, smem16, a, m0, n0, 0, nst);
-  for (int st = 0; st < nst; st++) r.step(e, st);
-  epilogue<E, SPLIT && !PAIR>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout, 0};
+  const int ngrp = 3 * (Cin / BKH);
+  const long u0 = (long)(tm * tiles_n + tn) * ngrp;   // exactly one tile
+  run_share<R, SPLIT && !PAIR>(e, smem16, a, u0, u0 + ngrp, ngrp, tiles_n, bias, relu, Cf, Chi, Clo, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv, stream-K
@@ -613,60 +681,11 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi,
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   E e;
   e.init();
-  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout, (relu >> 8) & 3};
+  const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout, 0};
   const int ngrp = 3 * (Cin / BKH);
   const long U = (long)tiles_m * tiles_n * ngrp;
   const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
-  constexpr int NACC4 = E::NI * E::NJ * E::NG;   // float4 pieces of the accumulator per lane
-  if (u0 >= u1) return;
-  // ONE flat loop over the steps of this workgroup's share (the matrix body must appear once in the code: nested
-  // segment / step loops get unswitched into seven copies of it and spill); `st` is the step inside the current tile
-  R r;
-  long u = u0;          // first unit of the current segment
-  int st = 0, m0 = 0, n0 = 0;
-  bool fresh = true;    // the next iteration opens a segment
-  const long nsteps = 3 * (u1 - u0);
-  for (long it = 0; it < nsteps; it++) {
-    if (fresh) {
-      const int t = (int)(u / ngrp), ga = (int)(u - (long)t * ngrp);
-      const int gb = (u1 - u) < (long)(ngrp - ga) ? ga + (int)(u1 - u) : ngrp;
-      const int tm = t / tiles_n, tn = t - tm * tiles_n;   // the n-tiles of one pixel run back to back: its halo stays in L2
-      m0 = tm * BX;
-      n0 = tn * BW;
-      if (it) {
-        wait_vmcnt<0>();
-        __syncthreads();                                   // every wave is done with the previous segment's LDS buffers
-        e.zero_acc();
-      }
-      st = 3 * ga;
-      r.begin(e, smem16, a, m0, n0, 3 * ga, 3 * gb);
-      fresh = false;
-    }
-    r.step(e, st);
-    st++;
-    if (st == r.st1) {                                     // segment complete
-      const int ga = r.st0 / 3, gb = r.st1 / 3;
-      if (ga == 0 && gb == ngrp) {
-        epilogue<E, SPLIT && !PAIR>(e, m0, n0, F * H * W, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo,
-                                    Cout);
-      } else {
-        f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < E::NI; i++)
-#pragma unroll
-          for (int j = 0; j < E::NJ; j++)
-#pragma unroll
-            for (int g = 0; g < E::NG; g++) {
-              f32x4 v;
-#pragma unroll
-              for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
-              dst[(size_t)((i * E::NJ + j) * E::NG + g) * NT16] = v;
-            }
-      }
-      u += gb - ga;
-      fresh = true;
-    }
-  }
+  run_share<R, SPLIT && !PAIR>(e, smem16, a, u0, u1, ngrp, tiles_n, bias, relu, Cf, Chi, Clo, scratch);
 }
 
 // One workgroup per share boundary w (between workgroups w-1 and w of the kernel above).  The boundary that is the FIRST
@@ -871,8 +890,8 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
   E e;
   e.init();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cpt = Cin / BKH, ngrp = 3 * cpt, CinS = 2 * Cin, K9S = 18 * Cin;
-  const __bf16 *zero = reinterpret_cast<const __bf16 *>(nafae_zero_page);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int cpt = Cin / BKH, CinS = 2 * Cin, K9S = 18 * Cin;
   // staging: chunk c = tid + 512 i sits in LDS row (tid >> 3) + 64 i; its (plane, k-slot) does not depend on i
   const int row0 = threadIdx.x >> 3;
   const int lsw = (threadIdx.x & 7) ^ ((row0 >> 1) & 7);
@@ -901,20 +920,28 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
   // staging instructions are handed out ONE AT A TIME between the MFMA clusters of a group (issued in a burst behind the
   // barrier they keep both waves of a SIMD off the matrix pipe for ~80 cycles each): slots 0-2 = the three weight taps of
   // the next group, slots 3-8 = the six chunks of the next patch
+  // (addresses are formed unconditionally and SELECTED against the zero page, with & rather than && between the bounds tests:
+  // an `ok ? address : zero` whose address arm is expensive, or a short-circuit test, compiles to a branch around the staging
+  // instruction, and every such branch cuts the group's MFMA body into basic blocks of three MFMAs behind s_waitcnt lgkmcnt(0))
+  const char *Xb = reinterpret_cast<const char *>(X), *Wb = reinterpret_cast<const char *>(Wt);
+  const uintptr_t zaddr = reinterpret_cast<uintptr_t>(nafae_zero_page);
   auto issue_patch_one = [&](const Tile &tl, int cc, int buf, int i) {   // chunk i of an 18 x 18 x 32-channel patch -> xbuf[buf]
-    char *dst = reinterpret_cast<char *>(xbuf + (size_t)buf * XB) + (wave * 64) * 16;
+    char *dst = reinterpret_cast<char *>(xbuf + (size_t)buf * XB) + (wave_s * 64) * 16;
     const int pr = row0 + 64 * i;
     const int py = pr / PP, px = pr - py * PP;
     const int y = tl.y0 - 1 + py, x = tl.x0 - 1 + px;
-    const bool ok = pr < PP * PP && y >= 0 && y < H && x >= 0 && x < W && !(relu & 512);   // (bit 9: timing experiment)
-    const __bf16 *src = ok ? X + (((long)tl.f * H + y) * W + x) * CinS + cc * 2 * BKH + soff : zero;
+    const bool ok = (pr < PP * PP) & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+    const int yb = max(tl.y0 - 1, 0);                        // first image row the patch can touch: offsets relative to it stay small
+    const char *base = Xb + ((size_t)(tl.f * H + yb) * W) * CinS * sizeof(__bf16);
+    const unsigned off = (unsigned)((y - yb) * W + x) * (unsigned)(CinS * 2) + (unsigned)(cc * 4 * BKH + soff * 2);
+    const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(base) + off : zaddr;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)(dst + NT16 * i * 16), 16, 0, 0);
   };
   auto issue_w_one = [&](const Tile &tl, int cc, int dy, int half, int t) {   // tap t of a group -> ring stage half * 3 + t
-    const __bf16 *wsrc = (relu & 512) ? zero - (dy * 3 + t) * CinS : Wt + (long)(tl.n0 + row0) * K9S + cc * 2 * BKH + soff;
-    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(half * 3 + t) * WS) + (wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (dy * 3 + t) * CinS),
+    const unsigned off = (unsigned)(tl.n0 + row0) * (unsigned)(K9S * 2) + (unsigned)((cc * 2 * BKH + soff + (dy * 3 + t) * CinS) * 2);
+    char *dst = reinterpret_cast<char *>(wbuf + (size_t)(half * 3 + t) * WS) + (wave_s * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Wb + off),
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   };
 
@@ -923,61 +950,77 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
   for (int i = 0; i < NPC; i++) issue_patch_one(cur, 0, 0, i);
 #pragma unroll
   for (int t = 0; t < 3; t++) issue_w_one(cur, 0, 0, 0, t);
-  int younger = 0;   // vector-memory ops issued after the loads the next group needs (they may stay in flight)
   int gpar = 0;      // parity of the running group count (weight ring half)
   int ppar = 0;      // parity of the running patch count (patch buffer)
   constexpr int TROW = 128 + 16;                       // epilogue transpose: LDS bytes per pixel (32 ch x (hi, lo) + pad)
   static_assert(8 * 32 * TROW <= XB * 2, "the transposition fits one patch buffer");
+  // One row-offset group (dy = DY - 1): barrier, 3 taps x 2 k-steps x 2 channel halves = 12 clusters of 3 MFMAs, with the
+  // staging instructions handed out between the clusters.  What a group stages is fixed by (DY, FINAL = last channel chunk of
+  // the workgroup's last tile) and resolved at compile time: slots 0-2 = the next group's weight taps (not after the very last
+  // group), slots 3-8 = the next patch (first group of a patch only; 3 groups to land).
+  auto group = [&](auto dy_tag, auto final_tag, const Tile &cur, const Tile &nxt, int cc, bool last_cc, bool after_store) {
+    constexpr int DY = decltype(dy_tag)::value;
+    constexpr bool FINAL = decltype(final_tag)::value;
+    constexpr bool DO_W = !(DY == 2 && FINAL), DO_P = DY == 0 && !FINAL;
+    // vector-memory ops younger than the loads this group needs may stay in flight: the patch chunks the previous group
+    // staged behind its weight taps, or the previous tile's epilogue stores
+    if (DY == 1 && !FINAL) {
+      wait_vmcnt<NPC>();
+    } else if (DY == 0 && after_store) {
+      wait_vmcnt<NSTORE>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();   // this group's taps and patch are in LDS for everyone; everyone is done with the previous group
+    const bool w_next_tile = DY == 2 && last_cc;
+    const Tile &wt = w_next_tile ? nxt : cur;
+    const int wcc = DY < 2 ? cc : (last_cc ? 0 : cc + 1), wdy = DY < 2 ? DY + 1 : 0;
+    const Tile &pt = last_cc ? nxt : cur;
+    const int pcc = last_cc ? 0 : cc + 1;
+    const __bf16 *xb = xbuf + (size_t)ppar * XB;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const __bf16 *wb = wbuf + (size_t)(gpar * 3 + t) * WS;
+      const int pr = prow0 + DY * PP + t;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int sl = 2 * s + h;
+        bf16x8 xa[2], wa[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) xa[p] = *reinterpret_cast<const bf16x8 *>(&xb[E::L::template frag<PROWS>(pr, p, sl)]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+          for (int p = 0; p < 2; p++)
+            wa[p] = *reinterpret_cast<const bf16x8 *>(&wb[E::L::template frag<64>(i * 32 + (lane & 31), p, sl)]);
+          e.mma(i, 0, wa, xa);
+          const int slot = (t * 2 + s) * 2 + i;      // 12 clusters per group, 9 staging slots
+          if (slot < 3) {
+            if (DO_W) issue_w_one(wt, wcc, wdy, gpar ^ 1, slot);
+          } else if (slot - 3 < NPC) {
+            if (DO_P) issue_patch_one(pt, pcc, ppar ^ 1, slot - 3);
+          }
+        }
+      }
+    }
+    gpar ^= 1;
+  };
+  using D0 = std::integral_constant<int, 0>;
+  using D1 = std::integral_constant<int, 1>;
+  using D2 = std::integral_constant<int, 2>;
   for (int k = 0; k < nmine; k++) {
     const bool last_tile = k + 1 == nmine;
     const Tile nxt = last_tile ? cur : tile_of(k + 1);
     for (int cc = 0; cc < cpt; cc++) {
-      const bool last_cc = cc + 1 == cpt;
-      for (int dy = 0; dy < 3; dy++) {
-        if (younger == NPC)
-          wait_vmcnt<NPC>();
-        else if (younger == NSTORE)
-          wait_vmcnt<NSTORE>();
-        else
-          wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // this group's taps and patch are in LDS for everyone; everyone is done with the previous group
-        // what this group stages: the next group's taps (they are what the next wait is for: issued first), and -- at the
-        // first group of a patch, when the other patch buffer has just become free -- the next patch (3 groups to land)
-        const bool w_next_tile = dy == 2 && last_cc;
-        const bool do_w = !(w_next_tile && last_tile);
-        const Tile &wt = w_next_tile ? nxt : cur;
-        const int wcc = dy < 2 ? cc : (last_cc ? 0 : cc + 1), wdy = dy < 2 ? dy + 1 : 0;
-        const bool do_p = dy == 0 && !(last_cc && last_tile);
-        const Tile &pt = last_cc ? nxt : cur;
-        const int pcc = last_cc ? 0 : cc + 1;
-        younger = do_p ? NPC : 0;
-        const __bf16 *xb = xbuf + (size_t)ppar * XB;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-          const __bf16 *wb = wbuf + (size_t)(gpar * 3 + t) * WS;
-          const int pr = prow0 + dy * PP + t;
-#pragma unroll
-          for (int s = 0; s < 2; s++) {
-            const int sl = 2 * s + h;
-            bf16x8 xa[2], wa[2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) xa[p] = *reinterpret_cast<const bf16x8 *>(&xb[E::L::template frag<PROWS>(pr, p, sl)]);
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-#pragma unroll
-              for (int p = 0; p < 2; p++)
-                wa[p] = *reinterpret_cast<const bf16x8 *>(&wb[E::L::template frag<64>(i * 32 + (lane & 31), p, sl)]);
-              e.mma(i, 0, wa, xa);
-              const int slot = (t * 2 + s) * 2 + i;      // 12 clusters per group, 9 staging slots
-              if (slot < 3) {
-                if (do_w) issue_w_one(wt, wcc, wdy, gpar ^ 1, slot);
-              } else if (slot - 3 < NPC) {
-                if (do_p) issue_patch_one(pt, pcc, ppar ^ 1, slot - 3);
-              }
-            }
-          }
-        }
-        gpar ^= 1;
+      const bool last_cc = cc + 1 == cpt, after_store = cc == 0 && k > 0;
+      if (last_cc && last_tile) {
+        group(D0{}, std::true_type{}, cur, nxt, cc, last_cc, after_store);
+        group(D1{}, std::true_type{}, cur, nxt, cc, last_cc, after_store);
+        group(D2{}, std::true_type{}, cur, nxt, cc, last_cc, after_store);
+      } else {
+        group(D0{}, std::false_type{}, cur, nxt, cc, last_cc, after_store);
+        group(D1{}, std::false_type{}, cur, nxt, cc, last_cc, after_store);
+        group(D2{}, std::false_type{}, cur, nxt, cc, last_cc, after_store);
       }
       ppar ^= 1;
     }
@@ -1028,7 +1071,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
         for (int it = 0; it < NIT; it++) {
           const int qd = it * 64 + lane, px = qd >> 3, part = qd & 7;
           const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
-          if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + out_pix(px) * rowp + part * 16) = d;
+          *reinterpret_cast<bf16x8 *>(obase + out_pix(px) * rowp + part * 16) = d;
         }
       } else {
         const long rowb = (long)2 * Cout * sizeof(__bf16);           // bytes per output pixel (interleaved planes)
@@ -1055,12 +1098,11 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
           for (int it = 0; it < NIT; it++) {
             const int qd = it * 64 + lane, px = qd >> 3, part = qd & 7;   // 8 pieces of 16 B per pixel
             const bf16x8 d = *reinterpret_cast<const bf16x8 *>(tb + px * TROW + part * 16);
-            if (!(relu & 256)) *reinterpret_cast<bf16x8 *>(obase + out_pix(px) * rowb + part * 16) = d;   // (bit 8: timing experiment)
+            *reinterpret_cast<bf16x8 *>(obase + out_pix(px) * rowb + part * 16) = d;
           }
         }
       }
       e.zero_acc();
-      younger = (relu & 256) ? 0 : NSTORE;
     }
     cur = nxt;
   }

@@ -27,13 +27,6 @@ for (name, H, Cin, Cout, pool) in (("conv1_2", 224, 64, 64, True), ("conv2_1", 1
     n = 3 if name == "conv5_x" else 1
     tot += n * ms
     line = "%s %d->%d @%d: %.3f ms x%d  %.0f TF mfma (%.0f%% of 2.5 PF)" % (name, Cin, Cout, H, ms, n, fl / ms / 1e9, fl / ms / 1e9 / 25)
-    if Cout == 64:
-        line += "  [no stores %.3f, zero-page loads %.3f, both %.3f]" % (timeit(lambda: ops.conv3x3_bf16(xp, wp, cb, _dbg=1)),
-                                                                          timeit(lambda: ops.conv3x3_bf16(xp, wp, cb, _dbg=2)),
-                                                                          timeit(lambda: ops.conv3x3_bf16(xp, wp, cb, _dbg=3)))
-    if Cout > 64:   # timing experiments: staging loads served by one cached zero line (all / weights only)
-        line += "  [zero-page loads %.3f, weights only %.3f]" % (timeit(lambda: ops.conv3x3_bf16(xp, wp, cb, _dbg=1)),
-                                                                 timeit(lambda: ops.conv3x3_bf16(xp, wp, cb, _dbg=2)))
     if pool:
         _, y = ops.conv3x3_bf16(xp, wp, cb)
         mp = timeit(lambda: ops.maxpool2x2_bf16(y))
