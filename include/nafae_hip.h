@@ -119,6 +119,15 @@ int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias
 int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float *out, int F, int H, int W,
                        int Cin, int Cout, int relu, void *stream);
 
+/* The same conv on the stream-K schedule when the layer's tile count quantises badly on the device (gemm.hip: the 28^2 and
+ * 14^2 VGG layers idle 12-23 % of the CUs with one tile per workgroup): pass a workspace of nafae_conv3x3_workspace_bytes()
+ * bytes (0 = the layer does not need one; the plain kernel then runs, as it does for workspace == NULL).  Deterministic; a tile
+ * cut by the schedule sums its K range as two or three fp32 chains instead of one, so results can differ from
+ * nafae_conv3x3_relu in the last bit, and WHICH tiles are cut depends on F.  */
+int64_t nafae_conv3x3_workspace_bytes(int F, int H, int W, int Cin, int Cout);
+int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, float *out, int F, int H, int W,
+                          int Cin, int Cout, int relu, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* 2x2 stride-2 max-pool on NHWC.  H, W even; C % 4 == 0.  (RCNN_base pools, vgg16_rpn.py:38.)  */
 int nafae_maxpool2x2(const float *in, float *out, int F, int H, int W, int C, void *stream);
 

@@ -68,6 +68,42 @@ struct TileLayout {
   static constexpr int RS = IL ? 2 : 1;           // row-stride multiplier (a row holds both planes)
 };
 
+// One LDS-DMA: 16 bytes per lane from the per-lane global address `src` to LDS byte (lds_dst + 16 * lane), lds_dst uniform.
+// Issued through inline assembly rather than __builtin_amdgcn_global_load_lds: while a DMA that the compiler knows about is
+// outstanding, its s_waitcnt insertion treats every LDS read conservatively and emits lgkmcnt(0) -- never a counted wait -- so a
+// fragment prefetched for the NEXT group of MFMAs is waited for together with the current one (every lgkmcnt in the DMA kernels
+// was 0).  Hidden from it, the DMAs cost no LDS-read ordering; correctness rests on the explicit vmcnt waits and barriers that
+// the pipelines place anyway.  (The compiler's own vmcnt arithmetic for ordinary loads then under-counts what is outstanding,
+// which only ever makes its waits stricter: vector-memory operations retire in order.)  NAFAE_ASM_DMA=0 restores the builtin.
+#ifndef NAFAE_ASM_DMA
+#define NAFAE_ASM_DMA 1
+#endif
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16(const void *src, void *lds_dst) {
+#if NAFAE_ASM_DMA
+  const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "m0");
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)lds_dst,
+                                   16, 0, 0);
+#endif
+}
+// same with a uniform base and a 32-bit per-lane byte offset (the SGPR-base form of the instruction: one address register)
+__device__ __forceinline__ void lds_dma16(const void *base, unsigned off, void *lds_dst) {
+#if NAFAE_ASM_DMA
+  const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(lds_dst));
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+  const unsigned bh = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)), bl = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned long long bs = ((unsigned long long)bh << 32) | bl;   // (the builtin returns int: widen as unsigned)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(off), "s"(bs) : "m0");
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(static_cast<const char *>(base) + off),
+                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+#endif
+}
+#pragma clang diagnostic pop
+
 __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
   hi = (__bf16)v;
   lo = (__bf16)(v - (float)hi);

@@ -191,6 +191,176 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 conv, stream-K schedule.  The tile kernel above runs one 128 x 128 tile per workgroup, three workgroups per CU, so a
+// layer's time steps at whole tiles per CU: 512 -> 512 at 28^2 is 1568 tiles = 6.125 per CU (the CUs with 7 set the time:
+// 12.5 % idle), the 14^2 layers 392 tiles = 1.53 per CU (23 % idle).  Here the launch is the list of (tile, k-tile) units,
+// tile-major, and G workgroups each take an equal CONTIGUOUS share.  A tile wholly inside a share is finished there; a tile
+// cut by a share boundary gets fp32 partial accumulators in `scratch` (slot 2w for the first segment of workgroup w, 2w+1 for
+// its last) and conv_sk_fixup_kernel -- the kernel boundary is the only synchronisation -- adds them in workgroup order and
+// runs the epilogue.  Deterministic (the order is fixed by the share arithmetic); a cut tile's K sum is split into two or three
+// fp32 chains instead of one, so the last bit differs from the tile kernel's.  Single LDS buffer as above.
+// ------------------------------------------------------------------------------------------------
+// Workgroups per CU the stream-K kernel is compiled and launched for.  At 3 (the tile kernel's occupancy, 168 registers) the
+// segment loop spills its staging registers inside the k loop and the 56^2 layers come out 4-9 % SLOWER than the tile kernel;
+// at 2 (256 registers, no spills) measured against the tile kernel at C2: 28^2 layers -8 ... -9 %, 14^2 layers -19 %, 56^2 -1 %.
+#ifndef NAFAE_F32_SK_WPE
+#define NAFAE_F32_SK_WPE 2
+#endif
+template <class E>
+__device__ __forceinline__ void conv_epilogue(const E &e, int m0, int n0, int M, int Cout, const float *__restrict__ bias, int relu,
+                                              float *__restrict__ out) {
+#pragma unroll
+  for (int j = 0; j < E::TN; j++) {
+    const int n = n0 + e.acc_col(j);
+    if (n >= Cout) continue;
+    const float bv = bias[n];
+#pragma unroll
+    for (int i = 0; i < E::TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + e.acc_row(i, r);
+        if (m < M) {
+          float v = e.acc[i][j][r] + bv;
+          out[(size_t)m * Cout + n] = (relu && v < 0.f) ? 0.f : v;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_F32_SK_WPE, NAFAE_F32_SK_WPE))) void conv3x3_sk_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, float *__restrict__ out, int F, int H,
+                                                              int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n,
+                                                              float *__restrict__ scratch) {
+  using E = Engine<BM, BN, WM, WN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  E e;
+  e.init();
+  const int M = F * H * W;
+  const int cpt = Cin / BK, nk = 9 * cpt, K = 9 * Cin;
+  const long U = (long)tiles_m * tiles_n * nk;
+  const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
+  constexpr int NACC4 = E::TM * E::TN * 4;
+  for (long u = u0; u < u1;) {
+    const int t = (int)(u / nk);
+    const int ka = (int)(u - (long)t * nk);
+    const int kb = (u1 - u) < (long)(nk - ka) ? ka + (int)(u1 - u) : nk;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (u != u0) {
+      __syncthreads();   // every wave is done with the previous segment's LDS tile
+      e.zero_acc();
+    }
+    // per-lane staging descriptors, compact (this kernel runs at the register cap of its occupancy): pixel (y, x) packed in one
+    // register, 32-bit element offsets from the tensor bases instead of pointers (inputs < 2^31 elements: checked by the launcher)
+    int pyx[E::NA];
+    unsigned oa[E::NA], ob[E::NB];
+    unsigned vmask = 0;   // bit i: A row i valid, bit 8 + i: B row i valid
+#pragma unroll
+    for (int i = 0; i < E::NA; i++) {
+      const int m = m0 + e.srow + 32 * i;
+      const bool v = m < M;
+      const int mm = v ? m : 0;
+      pyx[i] = (((mm / W) % H) << 16) | (mm % W);
+      oa[i] = (unsigned)mm * (unsigned)Cin + e.slot * 4;
+      vmask |= (v ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < E::NB; i++) {
+      const int n = n0 + e.srow + 32 * i;
+      const bool v = n < Cout;
+      ob[i] = (unsigned)(v ? n : 0) * (unsigned)K + e.slot * 4;
+      vmask |= (v ? 1u : 0u) << (8 + i);
+    }
+    f32x4 ra[E::NA], rb[E::NB];
+    auto fetch = [&](int kt) {
+      const int tap = kt / cpt;
+      const int cc = kt - tap * cpt;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int aoff = (dy * W + dx) * Cin + cc * BK;
+#pragma unroll
+      for (int i = 0; i < E::NA; i++) {
+        const int yy = (pyx[i] >> 16) + dy, xx = (pyx[i] & 0xffff) + dx;
+        const bool ok = ((vmask >> i) & 1u) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        ra[i] = ldg4(in + (size_t)(oa[i] + (unsigned)aoff), ok);
+      }
+#pragma unroll
+      for (int i = 0; i < E::NB; i++) rb[i] = ldg4(w + (size_t)(ob[i] + (unsigned)(kt * BK)), (vmask >> (8 + i)) & 1u);
+    };
+    fetch(ka);
+    e.store_stage(smem, ra, rb);
+    __syncthreads();
+    for (int kt = ka; kt < kb; kt++) {
+      if (kt + 1 < kb) fetch(kt + 1);
+      e.compute(smem);
+      __syncthreads();
+      if (kt + 1 < kb) e.store_stage(smem, ra, rb);
+      __syncthreads();
+    }
+    // (opaque copies of the lane coordinates: the epilogue's per-lane addresses are loop-invariant, and computed ahead of the
+    // segment loop they would stay live across the matrix body, which has no registers to spare at three workgroups per CU)
+    const int lane0 = e.lane;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(e.lane), "+v"(tid));
+    if (ka == 0 && kb == nk) {
+      conv_epilogue(e, m0, n0, M, Cout, bias, relu, out);
+    } else {
+      f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NTHREADS + tid;
+#pragma unroll
+      for (int i = 0; i < E::TM; i++)
+#pragma unroll
+        for (int j = 0; j < E::TN; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = e.acc[i][j][4 * q + c];
+            dst[(size_t)((i * E::TN + j) * 4 + q) * NTHREADS] = v;
+          }
+    }
+    e.lane = lane0;
+    u += kb - ka;
+  }
+}
+
+// One workgroup per share boundary w (between workgroups w-1 and w of the kernel above).  The FIRST boundary strictly inside a
+// tile owns it: it adds the contributors' partials in workgroup order and writes the tile.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void conv_sk_fixup_f32_kernel(const float *__restrict__ scratch, const float *__restrict__ bias,
+                                                                     float *__restrict__ out, int M, int Cout, int relu, int tiles_m,
+                                                                     int tiles_n, int nk, int G) {
+  using E = Engine<BM, BN, WM, WN>;
+  const int w = blockIdx.x + 1;
+  const long U = (long)tiles_m * tiles_n * nk;
+  const long b = U * w / G;
+  const int t = (int)(b / nk);
+  const long t0 = (long)t * nk, t1 = t0 + nk;
+  if (b == t0) return;                       // the boundary lies on a tile edge
+  if (U * (w - 1) / G > t0) return;          // an earlier boundary lies strictly inside this tile and owns it
+  E e;
+  e.init();
+  constexpr int NACC4 = E::TM * E::TN * 4;
+  for (int c = w - 1; c < G; c++) {
+    const long c0 = U * c / G;
+    if (c0 >= t1) break;
+    if (U * (c + 1) / G == c0) continue;       // an empty share (fewer units than workgroups) wrote nothing
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NTHREADS + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < E::TM; i++)
+#pragma unroll
+      for (int j = 0; j < E::TN; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const f32x4 v = src[(size_t)((i * E::TN + j) * 4 + q) * NTHREADS];
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) e.acc[i][j][4 * q + cc] += v[cc];
+        }
+  }
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  conv_epilogue(e, tm * BM, tn * BN, M, Cout, bias, relu, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // C[M,N] = alpha * A[K,M]^T B[K,N] (+C).  LDS tiles are [32 k][BM] / [32 k][BN] (the HBM layout); each MFMA
 // operand is one ds_read_b32 per lane (consecutive lanes -> consecutive m: conflict-free).
 // ------------------------------------------------------------------------------------------------
@@ -538,8 +708,40 @@ int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias
   return launched();
 }
 
+namespace {
+inline int sk_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+// stream-K pays when the CUs that hold one more tile than the average idle the others for more than ~5 % of the launch
+inline bool f32_sk_pays(long tiles, int cus) {
+  const long per = (tiles + cus - 1) / cus;
+  return (double)(per * cus - tiles) / (double)(per * cus) > 0.05;
+}
+constexpr int F32_SK_WG_PER_CU = NAFAE_F32_SK_WPE;   // workgroups per CU the stream-K kernel is compiled for (its register cap)
+}  // namespace
+
+int64_t nafae_conv3x3_workspace_bytes(int F, int H, int W, int Cin, int Cout) {
+  if (F <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (long)F * H * W >= (1L << 31)) return NAFAE_EINVAL;
+  if (Cout <= 64 || Cin % 32) return 0;
+  const long tiles = (((long)F * H * W + 127) / 128) * ((Cout + 127) / 128);
+  if (!f32_sk_pays(tiles, sk_num_cus())) return 0;
+  return (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * sizeof(float);
+}
+
 int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float *out, int F, int H, int W, int Cin,
                        int Cout, int relu, void *stream) {
+  return nafae_conv3x3_relu_ws(in, w, bias, out, F, H, W, Cin, Cout, relu, nullptr, 0, stream);
+}
+
+int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, float *out, int F, int H, int W, int Cin,
+                          int Cout, int relu, void *workspace, int64_t workspace_bytes, void *stream) {
   if (!in || !w || !bias || !out || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
   if (Cin % 32 || Cout % 4 || !aligned16(in) || !aligned16(w)) return NAFAE_EINVAL;
   if ((long)F * H * W >= (1L << 31) / 1) return NAFAE_ELIMIT;
@@ -548,12 +750,22 @@ int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float
   const long t128 = (long)(((long)F * H * W + 127) / 128) * ((Cout + 127) / 128);
   const char *sm = nafae::experiment_env("NAFAE_F32_CONV_SMALL");
   const bool small_ok = sm ? sm[0] == '1' : F32_CONV_SMALL_DEFAULT;
-  if (Cout <= 64)
+  if (Cout <= 64) {
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
-  else if (small_ok && t128 < 2 * 256)
+  } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) &&
+             workspace_bytes >= (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float)) {
+    using E = Engine<128, 128, 2, 2>;
+    const int M = F * H * W, tiles_m = (M + 127) / 128, tiles_n = (Cout + 127) / 128, G = F32_SK_WG_PER_CU * sk_num_cus();
+    hipLaunchKernelGGL((conv3x3_sk_kernel<128, 128, 2, 2>), dim3(G), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias, out, F,
+                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace);
+    if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
+    hipLaunchKernelGGL((conv_sk_fixup_f32_kernel<128, 128, 2, 2>), dim3(G - 1), dim3(NTHREADS), 0, S(stream), (const float *)workspace, bias,
+                       out, M, Cout, relu, tiles_m, tiles_n, 9 * (Cin / 32), G);
+  } else if (small_ok && t128 < 2 * 256) {
     launch_conv<64, 64, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
-  else
+  } else {
     launch_conv<128, 128, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
+  }
   return launched();
 }
 

@@ -252,6 +252,18 @@ __global__ __launch_bounds__(NT16) void conv3x3_bf16_kernel(const __bf16 *__rest
 // undone by the swizzled fragment read.  Zero fill (ragged rows, K tail, conv halo) comes from a zero page.
 __device__ __attribute__((aligned(64))) const unsigned int nafae_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+// Timing experiments on the conv loops (scripts/conv_variants.sh builds one library per value; results are wrong for any value
+// but 0): 1 = no barrier, 2 = no tap masks, 4 = no staging DMAs inside the loop, 8 = no LDS fragment reads, 16 = LDS reads
+// issued but never waited for (the MFMAs take their operands from unrelated registers).
+#ifndef NAFAE_CONV_EXP
+#define NAFAE_CONV_EXP 0
+#endif
+constexpr int CONV_EXP = NAFAE_CONV_EXP;
+#ifndef NAFAE_CONV_FENCE
+#define NAFAE_CONV_FENCE 1
+#endif
+constexpr bool CONV_SCHED_FENCE = NAFAE_CONV_FENCE;
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -346,6 +358,8 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
       src = gp[i] + (size_t)kt * kstep;   // (CONV weights: kt = tap*cpt + cc, K-contiguous, so the same step applies)
     }
     if (!v) src = zero;
+    // (the builtin, not lds_dma16: this kernel keeps two 64-bit descriptors in scratch whose reload the compiler waits for with
+    // a vmcnt it can only count correctly when it knows about the DMAs)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)(sbase + (NT16 * i + wave * 64) * 16), 16, 0, 0);
   };
@@ -447,8 +461,10 @@ struct ConvRun {
     pix = min(max(pix, 0), M - 1) - pbase;   // (pbase: first pixel any chunk of this tile can touch, so the byte offset is small)
     const unsigned off = (unsigned)pix * (unsigned)(CinS * 2) + xlane[k] + (unsigned)(cc * L::KTS * 2);
     char *dst = reinterpret_cast<char *>(xbuf + (size_t)(grp & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xbase[k] + off),
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    if (IL)
+      lds_dma16(xbase[k], off, dst);
+    else
+      lds_dma16(xbase[k] + off, dst);
   }
   __device__ __forceinline__ void issue_w(int i, int st) const {  // chunk i of the weight tile for step st = (cc, tap)
     const int cc = st / 9, tap = st - cc * 9;
@@ -456,8 +472,10 @@ struct ConvRun {
     const int row = min(wrow[k] + (IL ? 64 * i : 0), nrem - 1);
     const unsigned off = (unsigned)row * (unsigned)(K9S * 2) + wlane[k] + (unsigned)((tap * CinS + cc * L::KTS) * 2);
     char *dst = reinterpret_cast<char *>(wbuf + (size_t)(st % NSTW) * WST) + (NT16 * i + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wbase[k] + off),
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    if (IL)
+      lds_dma16(wbase[k], off, dst);
+    else
+      lds_dma16(wbase[k] + off, dst);
   }
 
   __device__ __forceinline__ void begin(const E &e, __bf16 *smem16, const ConvArgs &a, int m0, int n0, int s0, int s1) {
@@ -526,24 +544,38 @@ struct ConvRun {
   __device__ __forceinline__ void step_ct(E &e, int grp) {
     constexpr bool DO_X = S == 0 && !LAST;            // stage the run of the next group
     constexpr bool DO_W = !(LAST && S + DIST >= 3);   // stage the weight tile DIST steps ahead
-    // W(st) must have landed; what the previous step issued (DIST == 2 only) may stay in flight
-    if (DIST == 1 || (LAST && S == 2))
-      wait_vmcnt<0>();
-    else if (!LAST && S == 1)
-      wait_vmcnt<NWC + NXC>();
-    else
-      wait_vmcnt<NWC>();
-    __builtin_amdgcn_s_barrier();
+    // Staging order inside a step: the weight tile first (it is what the NEXT barrier waits for), then the run (due three
+    // steps later).  Vector-memory ops retire in order, so the wait before the barrier names how many YOUNGER ops than W(st)
+    // may stay in flight:
+    //   DIST == 1 (W(st) issued by step st-1):  S == 1 -> the run issued behind it by step S == 0;  otherwise nothing
+    //   DIST == 2 (W(st) issued by step st-2):  what steps st-2 (after W(st)) and st-1 issued
+    if (DIST == 1) {
+      if (S == 1 && !LAST)
+        wait_vmcnt<NXC>();
+      else
+        wait_vmcnt<0>();
+    } else if (LAST) {
+      if (S == 2)
+        wait_vmcnt<0>();
+      else
+        wait_vmcnt<NWC>();
+    } else {
+      if (S == 0)
+        wait_vmcnt<NWC>();
+      else
+        wait_vmcnt<NWC + NXC>();
+    }
+    if (!(CONV_EXP & 1)) __builtin_amdgcn_s_barrier();
     const int cc = grp / 3, dyi = grp - cc * 3;
     const int tap = 3 * dyi + S, st = 3 * grp + S;
     constexpr int dx = S - 1;
-    constexpr int NOPS = (DO_X ? NXC : 0) + (DO_W ? NWC : 0);
-    auto op = [&](int k) {  // staging instruction k of this step: first the next run, then the next weight tile
-      if (DO_X && k < NXC) {
-        issue_x(k, grp + 1);
+    constexpr int NOPS = (CONV_EXP & 4) ? 0 : (DO_X ? NXC : 0) + (DO_W ? NWC : 0);
+    auto op = [&](int k) {  // staging instruction k of this step: first the next weight tile, then the next run
+      if (DO_W && k < NWC) {
+        issue_w(k, st + DIST);
       } else {
-        const int w = k - (DO_X ? NXC : 0);
-        if (DO_W && w < NWC) issue_w(w, st + DIST);
+        const int x = k - (DO_W ? NWC : 0);
+        if (DO_X && x < NXC) issue_x(x, grp + 1);
       }
     };
     if (NOPS > NGRP) {
@@ -553,36 +585,80 @@ struct ConvRun {
     const __bf16 *sX = xbuf + (size_t)(grp & 1) * XRUN;
     const __bf16 *sW = wbuf + (size_t)(st % NSTW) * WST;
     const int fr = e.frow();
-#pragma unroll
-    for (int s = 0; s < E::KSTEPS; s++) {
+    // The step is a software pipeline over UNITS = (k-step s, pixel tile j): a unit is the NI x (1..3) MFMAs that one activation
+    // fragment pair feeds.  The fragment reads of unit u+1 are issued before the MFMAs of unit u and each unit waits (counted
+    // lgkmcnt, placed by the compiler) only for its own operands; the scheduling fences pin that order.  Left to itself the
+    // scheduler reads a whole k-step, drains lgkmcnt(0) in front of the tap masks and only then starts the matrix pipe, four
+    // to five times per step: with no LDS reads at all the same loop runs 23 % faster (scripts/conv_variants.sh, variant 8).
+    constexpr int NU = E::KSTEPS * NJ;
+    bf16x8 wa[2][NI][PL], xa[2][PL];
+    auto read_w = [&](int buf, int s) {
       const int sl = e.fslot(s);
-      bf16x8 xa[NJ][PL];
 #pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        const int rrow = e.wx * (TX * 32) + j * MS + fr + ROFF + dx;
-        const bool on = (tapmask[j] >> tap) & 1u;
+      for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int p = 0; p < PL; p++) {
-          bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, sl)]);
-          const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-          xa[j][p] = on ? v : z;
+          if (CONV_EXP & 8) {
+            asm volatile("" : "=v"(wa[buf][i][p]));   // (timing experiment: no LDS read)
+          } else if (CONV_EXP & 16) {                  // (timing experiment: the read is issued but nothing waits for it)
+            bf16x8 t;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"((unsigned)reinterpret_cast<uintptr_t>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * MS + fr, p, sl)])));
+            asm volatile("" : "=v"(wa[buf][i][p]));
+          } else {
+            wa[buf][i][p] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * MS + fr, p, sl)]);
+          }
+        }
+    };
+    auto read_x = [&](int buf, int s, int j) {
+      const int sl = e.fslot(s);
+      const int rrow = e.wx * (TX * 32) + j * MS + fr + ROFF + dx;
+#pragma unroll
+      for (int p = 0; p < PL; p++) {
+        if (CONV_EXP & 8) {
+          asm volatile("" : "=v"(xa[buf][p]));
+        } else if (CONV_EXP & 16) {
+          bf16x8 t;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"((unsigned)reinterpret_cast<uintptr_t>(&sX[L::template frag<RR>(rrow, p, sl)])));
+          asm volatile("" : "=v"(xa[buf][p]));
+        } else {
+          xa[buf][p] = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, sl)]);
         }
       }
+    };
+    read_w(0, 0);
+    read_x(0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < NI; i++) {
-        bf16x8 wa[PL];
-#pragma unroll
-        for (int p = 0; p < PL; p++)
-          wa[p] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * MS + fr, p, sl)]);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          e.mma(i, j, wa, xa[j]);
-          const int g = s * NI * NJ + i * NJ + j;
-          if (g < NGRP && g < NOPS) op(g);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keeps the live fragment set at one k-step's xa + one wa (the scheduler otherwise
-                                             // hoists the next k-step's 16 reads over 128 accumulator registers and spills)
+    for (int u = 0; u < NU; u++) {
+      const int s = u / NJ, j = u - s * NJ;
+      if (u + 1 < NU) {
+        const int s1 = (u + 1) / NJ, j1 = (u + 1) - s1 * NJ;
+        if (s1 != s) read_w(s1 & 1, s1);
+        read_x((u + 1) & 1, s1, j1);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool on = ((tapmask[j] >> tap) & 1u) || (CONV_EXP & 2);
+      bf16x8 x[PL];
+#pragma unroll
+      for (int p = 0; p < PL; p++) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        x[p] = on ? xa[u & 1][p] : z;
+      }
+      // product terms, small cross terms first; the NI accumulator tiles of a term back to back (independent MFMAs)
+      constexpr int NT = PAIR ? 2 : (SPLIT ? 3 : 1);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int pw = PAIR ? (t ? PL - 1 : 0) : (SPLIT && t == 0 ? PL - 1 : 0);
+        const int px = PAIR ? (t ? PL - 1 : 0) : (SPLIT && t == 1 ? PL - 1 : 0);
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+          e.acc[i][j] = mfma_bf16(wa[s & 1][i][pw], x[px], e.acc[i][j]);
+          if (t == NT - 1) {
+            const int g = u * NI + i;   // NU * NI = NGRP staging slots per step
+            if (g < NGRP && g < NOPS) op(g);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   template <bool LAST>
@@ -935,14 +1011,12 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
     const char *base = Xb + ((size_t)(tl.f * H + yb) * W) * CinS * sizeof(__bf16);
     const unsigned off = (unsigned)((y - yb) * W + x) * (unsigned)(CinS * 2) + (unsigned)(cc * 4 * BKH + soff * 2);
     const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(base) + off : zaddr;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)(dst + NT16 * i * 16), 16, 0, 0);
+    lds_dma16(reinterpret_cast<const void *>(src), dst + NT16 * i * 16);
   };
   auto issue_w_one = [&](const Tile &tl, int cc, int dy, int half, int t) {   // tap t of a group -> ring stage half * 3 + t
     const unsigned off = (unsigned)(tl.n0 + row0) * (unsigned)(K9S * 2) + (unsigned)((cc * 2 * BKH + soff + (dy * 3 + t) * CinS) * 2);
     char *dst = reinterpret_cast<char *>(wbuf + (size_t)(half * 3 + t) * WS) + (wave_s * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Wb + off),
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    lds_dma16(Wb, off, dst);
   };
 
   Tile cur = tile_of(0);
@@ -971,7 +1045,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
     } else {
       wait_vmcnt<0>();
     }
-    __builtin_amdgcn_s_barrier();   // this group's taps and patch are in LDS for everyone; everyone is done with the previous group
+    if (!(CONV_EXP & 1)) __builtin_amdgcn_s_barrier();   // this group's taps and patch are in LDS for everyone; everyone is done with the previous group
     const bool w_next_tile = DY == 2 && last_cc;
     const Tile &wt = w_next_tile ? nxt : cur;
     const int wcc = DY < 2 ? cc : (last_cc ? 0 : cc + 1), wdy = DY < 2 ? DY + 1 : 0;
@@ -987,18 +1061,27 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
         const int sl = 2 * s + h;
         bf16x8 xa[2], wa[2];
 #pragma unroll
-        for (int p = 0; p < 2; p++) xa[p] = *reinterpret_cast<const bf16x8 *>(&xb[E::L::template frag<PROWS>(pr, p, sl)]);
+        for (int p = 0; p < 2; p++) {
+          if (CONV_EXP & 8)
+            asm volatile("" : "=v"(xa[p]));   // (timing experiment: no LDS read)
+          else
+            xa[p] = *reinterpret_cast<const bf16x8 *>(&xb[E::L::template frag<PROWS>(pr, p, sl)]);
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++) {
 #pragma unroll
-          for (int p = 0; p < 2; p++)
-            wa[p] = *reinterpret_cast<const bf16x8 *>(&wb[E::L::template frag<64>(i * 32 + (lane & 31), p, sl)]);
+          for (int p = 0; p < 2; p++) {
+            if (CONV_EXP & 8)
+              asm volatile("" : "=v"(wa[p]));
+            else
+              wa[p] = *reinterpret_cast<const bf16x8 *>(&wb[E::L::template frag<64>(i * 32 + (lane & 31), p, sl)]);
+          }
           e.mma(i, 0, wa, xa);
           const int slot = (t * 2 + s) * 2 + i;      // 12 clusters per group, 9 staging slots
           if (slot < 3) {
-            if (DO_W) issue_w_one(wt, wcc, wdy, gpar ^ 1, slot);
+            if (DO_W && !(CONV_EXP & 4)) issue_w_one(wt, wcc, wdy, gpar ^ 1, slot);
           } else if (slot - 3 < NPC) {
-            if (DO_P) issue_patch_one(pt, pcc, ppar ^ 1, slot - 3);
+            if (DO_P && !(CONV_EXP & 4)) issue_patch_one(pt, pcc, ppar ^ 1, slot - 3);
           }
         }
       }

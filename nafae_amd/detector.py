@@ -179,7 +179,7 @@ class _fasterRCNN(nn.Module):
                 x = ops.maxpool2x2(x)
             else:
                 w, b = P['convs'][li]
-                x = ops.conv3x3_relu(x, w, b, relu=True)
+                x = ops.conv3x3_relu(x, w, b, relu=True, use_workspace=self.conv_stream_k)
                 li += 1
         return x
 
@@ -231,7 +231,7 @@ class _fasterRCNN(nn.Module):
             x, _ = ops.conv3x3_bf16(base_feat, P['rpn_w_h'], P['rpn_b'], relu=True, want_f32=True, want_planes=False,
                                     use_workspace=self.conv_stream_k)
         else:
-            x = ops.conv3x3_relu(base_feat, P['rpn_w'], P['rpn_b'], relu=True)
+            x = ops.conv3x3_relu(base_feat, P['rpn_w'], P['rpn_b'], relu=True, use_workspace=self.conv_stream_k)
         head = ops.gemm_nt(x.view(F * h * w, 512), P['head_w'], P['head_b'])
         scores, boxes = ops.rpn_decode(head, P['anchors'], im_info.contiguous().float(), F, h, w, A, r.feat_stride)
         order = ops.sort_desc(scores)

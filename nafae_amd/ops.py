@@ -141,16 +141,19 @@ def conv1_3x3_relu(x_nchw, w27, bias):
     return out
 
 
-def conv3x3_relu(x_nhwc, w_ohwi, bias, relu=True):
-    """x [F,H,W,Cin], w [Cout,3,3,Cin] -> [F,H,W,Cout]."""
+def conv3x3_relu(x_nhwc, w_ohwi, bias, relu=True, use_workspace=True):
+    """x [F,H,W,Cin], w [Cout,3,3,Cin] -> [F,H,W,Cout].
+    use_workspace=False forces the one-tile-per-workgroup schedule (results independent of F in the last bit; tests / A-B)."""
     _chk(x_nhwc); _chk(w_ohwi); _chk(bias)
     F, H, W, Cin = x_nhwc.shape
     Cout = w_ohwi.shape[0]
     if w_ohwi.numel() != Cout * 9 * Cin:
         raise NafaeOpError("conv3x3: weight shape mismatch")
     out = torch.empty(F, H, W, Cout, device=x_nhwc.device, dtype=torch.float32)
-    _rc(_lib.lib().nafae_conv3x3_relu(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)),
-                                      _stream()), "nafae_conv3x3_relu")
+    nws = int(_lib.lib().nafae_conv3x3_workspace_bytes(F, H, W, Cin, Cout)) if use_workspace else 0
+    ws = _conv_workspace(nws, x_nhwc.device) if nws > 0 else None
+    _rc(_lib.lib().nafae_conv3x3_relu_ws(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)),
+                                         _p(ws), max(nws, 0), _stream()), "nafae_conv3x3_relu_ws")
     return out
 
 

@@ -97,6 +97,29 @@ def test_conv3x3(ops, Fr, H, W, Cin, Cout, relu):
     assert relerr(out, ref) < TOL
 
 
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout", [(64, 14, 14, 64, 512),    # 392 tiles on 768 workgroups: shares shorter than a tile (3 contributors)
+                                             (33, 28, 28, 32, 260),    # ragged Cout, ragged last pixel tile, 609 tiles
+                                             (16, 28, 28, 96, 512),    # 392 tiles
+                                             (70, 14, 14, 32, 128)])   # 108 tiles: fewer tiles than CUs
+def test_conv3x3_stream_k(ops, Fr, H, W, Cin, Cout):
+    """fp32 stream-K schedule (nafae_conv3x3_relu_ws, gemm.hip) against the one-tile-per-workgroup kernel and against fp64:
+    same values up to the fp32 rounding of a K sum split in two or three chains, deterministic from call to call."""
+    import nafae_amd._lib as L
+    nws = int(L.lib().nafae_conv3x3_workspace_bytes(Fr, H, W, Cin, Cout))
+    assert nws > 0, "the case is meant to engage the stream-K schedule"
+    x = torch.relu(rnd(21, Fr, H, W, Cin))
+    w = rnd(22, Cout, 3, 3, Cin, std=0.05)
+    b = rnd(23, Cout, std=0.1)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    a = ops.conv3x3_relu(xd, wd, bd, relu=True, use_workspace=False)
+    s1 = ops.conv3x3_relu(xd, wd, bd, relu=True, use_workspace=True)
+    s2 = ops.conv3x3_relu(xd, wd, bd, relu=True, use_workspace=True)
+    assert torch.equal(s1, s2)
+    assert relerr(s1.cpu(), a.cpu()) < 1e-6
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    assert relerr(s1.cpu(), ref) < TOL
+
+
 def test_conv1(ops):
     x = torch.randint(0, 255, (3, 3, 20, 18), generator=torch.Generator().manual_seed(9)).float() - 127.5
     w = rnd(10, 64, 3, 3, 3, std=0.01)
