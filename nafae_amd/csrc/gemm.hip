@@ -751,8 +751,10 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
   const char *sm = nafae::experiment_env("NAFAE_F32_CONV_SMALL");
   const bool small_ok = sm ? sm[0] == '1' : F32_CONV_SMALL_DEFAULT;
   if (Cout <= 64) {
+    // (256 x 64 tiles -- the 64 MFMAs per wave and k-tile of the 128 x 128 kernel -- need 176 registers, two workgroups per CU
+    // instead of four: 64 -> 64 at 224^2 2.44 vs 2.25 ms, rejected)
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
-  } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) &&
+  } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) && (long)F * H * W * Cin < (1L << 32) &&   // (32-bit element offsets)
              workspace_bytes >= (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float)) {
     using E = Engine<128, 128, 2, 2>;
     const int M = F * H * W, tiles_m = (M + 127) / 128, tiles_n = (Cout + 127) / 128, G = F32_SK_WG_PER_CU * sk_num_cus();
