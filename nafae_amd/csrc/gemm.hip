@@ -231,21 +231,23 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_F32_SK_WPE, NAFAE_F32_SK_WPE))) void conv3x3_sk_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                               const float *__restrict__ bias, float *__restrict__ out, int F, int H,
                                                               int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n,
-                                                              float *__restrict__ scratch) {
+                                                              float *__restrict__ scratch, int bid0, int ntiles) {
   using E = Engine<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   E e;
   e.init();
   const int M = F * H * W;
   const int cpt = Cin / BK, nk = 9 * cpt, K = 9 * Cin;
-  const long U = (long)tiles_m * tiles_n * nk;
+  // the launch covers `ntiles` tiles: those the tile kernel would give to workgroups bid0 .. bid0 + ntiles - 1 (tile_coords)
+  const long U = (long)ntiles * nk;
   const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
   constexpr int NACC4 = E::TM * E::TN * 4;
   for (long u = u0; u < u1;) {
     const int t = (int)(u / nk);
     const int ka = (int)(u - (long)t * nk);
     const int kb = (u1 - u) < (long)(nk - ka) ? ka + (int)(u1 - u) : nk;
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    int tm, tn;
+    tile_coords(bid0 + t, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     if (u != u0) {
       __syncthreads();   // every wave is done with the previous segment's LDS tile
@@ -328,10 +330,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) void conv_sk_fixup_f32_kernel(const float *__restrict__ scratch, const float *__restrict__ bias,
                                                                      float *__restrict__ out, int M, int Cout, int relu, int tiles_m,
-                                                                     int tiles_n, int nk, int G) {
+                                                                     int tiles_n, int nk, int G, int bid0, int ntiles) {
   using E = Engine<BM, BN, WM, WN>;
   const int w = blockIdx.x + 1;
-  const long U = (long)tiles_m * tiles_n * nk;
+  const long U = (long)ntiles * nk;
   const long b = U * w / G;
   const int t = (int)(b / nk);
   const long t0 = (long)t * nk, t1 = t0 + nk;
@@ -356,7 +358,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_sk_fixup_f32_kernel(const float
           for (int cc = 0; cc < 4; cc++) e.acc[i][j][4 * q + cc] += v[cc];
         }
   }
-  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  int tm, tn;
+  tile_coords(bid0 + t, tiles_m, tiles_n, tm, tn);
   conv_epilogue(e, tm * BM, tn * BN, M, Cout, bias, relu, out);
 }
 
@@ -756,13 +759,25 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) && (long)F * H * W * Cin < (1L << 32) &&   // (32-bit element offsets)
              workspace_bytes >= (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float)) {
+    // whole rounds (a multiple of #CUs tiles: every CU gets the same number) go through the tile kernel at its three workgroups
+    // per CU; only the remainder -- the part that would leave most CUs idle -- runs on the stream-K schedule (two per CU)
     using E = Engine<128, 128, 2, 2>;
     const int M = F * H * W, tiles_m = (M + 127) / 128, tiles_n = (Cout + 127) / 128, G = F32_SK_WG_PER_CU * sk_num_cus();
+    // (measured at C2, tile kernel / stream-K over everything / this split: 56^2 layers 12.25 tiles per CU 1.963 / 1.945 / 1.906 ms,
+    // 28^2 6.125 per CU 2.113 / 1.915 / 1.904, 14^2 1.53 per CU 0.619 / 0.504 / 0.576 -- with few rounds the tile kernel's part is
+    // too short to reach its steady state, so below 4 rounds everything goes stream-K)
+    const int rounds = (int)(t128 / sk_num_cus());
+    const int full = rounds >= 4 ? rounds * sk_num_cus() : 0, rem = (int)t128 - full;
+    if (full > 0) {
+      hipLaunchKernelGGL((conv3x3_kernel<128, 128, 2, 2, true>), dim3(full), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias,
+                         out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
+      if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
+    }
     hipLaunchKernelGGL((conv3x3_sk_kernel<128, 128, 2, 2>), dim3(G), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias, out, F,
-                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace);
+                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace, full, rem);
     if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
     hipLaunchKernelGGL((conv_sk_fixup_f32_kernel<128, 128, 2, 2>), dim3(G - 1), dim3(NTHREADS), 0, S(stream), (const float *)workspace, bias,
-                       out, M, Cout, relu, tiles_m, tiles_n, 9 * (Cin / 32), G);
+                       out, M, Cout, relu, tiles_m, tiles_n, 9 * (Cin / 32), G, full, rem);
   } else if (small_ok && t128 < 2 * 256) {
     launch_conv<64, 64, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   } else {
