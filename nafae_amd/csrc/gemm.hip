@@ -479,49 +479,61 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// First VGG layer (Cin = 3): direct conv on the vector ALU.  One thread = one pixel x 16 output channels.
+// First VGG layer (Cin = 3): direct conv on the vector ALU.  One lane = one pixel: its 27 inputs sit in registers and the weights
+// are the SCALAR operands of v_fmac (w[co][k] is uniform, so it comes through the scalar cache instead of an LDS read per FMA);
+// 32 output channels at a time, transposed through LDS so that every store instruction writes full 128-B lines (a lane's own 32
+// channels would be one line per lane).  Same FMA order as a plain loop over (ci, ky, kx) starting from the bias.
+// Round 2: 0.51 -> 0.3 ms at 64 x 224^2 (one thread = one pixel x 16 channels with LDS weights before).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                     const float *__restrict__ bias, float *__restrict__ out,
                                                     int F, int H, int W) {
-  __shared__ float sw[27 * 64];  // [k][cout]
-  __shared__ float sb[64];
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-    int co = i & 63, k = i >> 6;
-    sw[i] = w[co * 27 + k];
-  }
-  if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
-  __syncthreads();
+  constexpr int ROWF = 32 + 4;                        // LDS floats per pixel: 32 channels (+16 B pad against bank conflicts)
+  __shared__ __attribute__((aligned(16))) float stage[256 * ROWF];
   const long total = (long)F * H * W;
-  // one pass per block (no grid-stride loop: the compiler would hoist all 27x16 LDS weights into registers)
-  const long p = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
-  if (p >= total) return;
-  const int cg = (threadIdx.x & 3) * 16;
-  const int x = p % W;
-  const int y = (p / W) % H;
-  const long n = p / ((long)W * H);
-  float acc[16];
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const long pc = p < total ? p : total - 1;
+  const int x = pc % W;
+  const int y = (pc / W) % H;
+  const long n = pc / ((long)W * H);
+  float v[27];
 #pragma unroll
-  for (int c = 0; c < 16; c++) acc[c] = sb[cg + c];
-#pragma unroll 1
-  for (int ci = 0; ci < 3; ci++)  // not unrolled: a fully unrolled body keeps all 27x16 weights live (256 VGPRs, 1 wave/SIMD)
-#pragma unroll 1
+  for (int ci = 0; ci < 3; ci++)
+#pragma unroll
     for (int ky = 0; ky < 3; ky++)
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const int yy = y + ky - 1, xx = x + kx - 1;
-        float v = 0.f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((n * 3 + ci) * H + yy) * W + xx];
-        const float *wk = &sw[(ci * 9 + ky * 3 + kx) * 64 + cg];
-#pragma unroll
-        for (int c = 0; c < 16; c++) acc[c] = fmaf(v, wk[c], acc[c]);
+        v[ci * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((n * 3 + ci) * H + yy) * W + xx] : 0.f;
       }
-  f32x4 *o = reinterpret_cast<f32x4 *>(out + p * 64 + cg);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long wave_p0 = (long)blockIdx.x * 256 + wave * 64;   // first pixel of this wave
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    float *row = stage + threadIdx.x * ROWF;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    f32x4 v = {fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
-               fmaxf(acc[4 * q + 3], 0.f)};
-    o[q] = v;
+    for (int c4 = 0; c4 < 8; c4++) {
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int co = half * 32 + c4 * 4 + c;
+        float a = bias[co];
+#pragma unroll
+        for (int k = 0; k < 27; k++) a = fmaf(v[k], w[co * 27 + k], a);
+        o[c] = fmaxf(a, 0.f);
+      }
+      *reinterpret_cast<f32x4 *>(row + c4 * 4) = o;
+    }
+    __syncthreads();
+    // 64 pixels x 8 pieces of 16 B per wave and half
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int q = it * 64 + lane, px = q >> 3, j = q & 7;
+      const long pg = wave_p0 + px;
+      if (pg < total)
+        *reinterpret_cast<f32x4 *>(out + pg * 64 + half * 32 + j * 4) = *reinterpret_cast<const f32x4 *>(stage + (wave * 64 + px) * ROWF + j * 4);
+    }
+    __syncthreads();
   }
 }
 
@@ -705,8 +717,8 @@ int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias
                          int W, void *stream) {
   if (!in_nchw || !w || !bias || !out_nhwc || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
   long total = (long)F * H * W;
-  if ((total + 63) / 64 > 0x7fffffffL) return NAFAE_ELIMIT;
-  int blocks = (int)((total + 63) / 64);
+  if ((total + 255) / 256 > 0x7fffffffL) return NAFAE_ELIMIT;
+  int blocks = (int)((total + 255) / 256);
   hipLaunchKernelGGL(conv1_kernel, dim3(blocks), dim3(256), 0, S(stream), in_nchw, w, bias, out_nhwc, F, H, W);
   return launched();
 }
