@@ -186,6 +186,37 @@ def test_detector_c1_in_bf16_modes(ops, precision, tol):
         assert relerr(fc7.cpu(), OD.head_to_tail(pooled_t, sd)) < tol
 
 
+@pytest.mark.parametrize("F,H,Cin,Cout,pool", [(700, 112, 128, 256, False),    # raster-run kernel, stream-K: 4.5 GB of input planes
+                                                   (340, 224, 64, 64, True)])      # 2-D patch kernel with the fused pool: 4.4 GB
+def test_conv_inputs_beyond_4gib(F, H, Cin, Cout, pool):
+    """The staging DMAs address with 32-bit offsets from a per-tile base (gemm_bf16.hip, ConvRun::issue_x / the patch kernel's
+    issue_patch_one), so a layer input larger than 4 GiB must behave like a small one: the last frames of a > 4 GiB batch equal
+    the same frames convolved on their own (bit-for-bit with one tile per workgroup -- a frame's result does not depend on its
+    neighbours; the stream-K schedule, whose cut tiles depend on the batch, within its fp32-order tolerance)."""
+    from nafae_amd import ops
+    if torch.cuda.mem_get_info()[0] < 40 * 2 ** 30:
+        pytest.skip("needs 40 GB of free HBM")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.relu(torch.randn(F, H, H, Cin, device="cuda", generator=g))
+    assert x.numel() * 4 > 2 ** 32
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    xp, wp = ops.split_bf16(x, True, True), ops.split_bf16(w, True, True)
+    tail = ops.split_bf16(x[F - 3:].contiguous(), True, True)
+    del x
+    for use_ws in (False, True):
+        _, big = ops.conv3x3_bf16(xp, wp, b, relu=True, pool=pool, use_workspace=use_ws)
+        _, small = ops.conv3x3_bf16(tail, wp, b, relu=True, pool=pool, use_workspace=False)
+        got, want = ops.merge_bf16(big)[F - 3:], ops.merge_bf16(small)
+        del big, small
+        if use_ws:
+            assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        else:
+            assert torch.equal(got, want)
+        assert float(want.abs().max()) > 0
+        del got, want
+
+
 @pytest.mark.parametrize("F,H,Cin,Cout", [(64, 56, 64, 256), (64, 28, 256, 512), (24, 56, 64, 128), (5, 56, 32, 256), (33, 28, 64, 512)])
 def test_conv_stream_k_schedule(F, H, Cin, Cout):
     """Stream-K schedule of the run-reuse conv (tile counts that leave the last round mostly empty: 784 / 392 / 294 / 62 / 204
