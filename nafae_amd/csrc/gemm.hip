@@ -121,18 +121,25 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restri
   const int nk = 9 * cpt;
   const int K = 9 * Cin;
 
-  int py[E::NA], px[E::NA];
+  // Per staged activation row: its pixel's address and a 9-bit mask of the taps that fall inside the image (0 for a row beyond
+  // M).  The k-tile coordinates (tap, 32-channel chunk) of the NEXT fetch are carried incrementally: recomputed per k-tile
+  // (kt / cpt, four bounds compares per row) they were ~90 of the ~210 scalar + vector instructions a wave spends per k-tile
+  // next to its 32-64 MFMAs, and on this chip those instructions cost clock (PMC: the 64-channel layer holds 2.14 GHz, the
+  // 128-channel one 2.40 GHz, at 74 % / 78 % MFMA-busy).
   const float *pa[E::NA];
-  bool va[E::NA];
+  unsigned tmask[E::NA];
 #pragma unroll
   for (int i = 0; i < E::NA; i++) {
-    int m = m0 + e.srow + 32 * i;
-    va[i] = m < M;
-    int mm = va[i] ? m : 0;
-    int x = mm % W;
-    int y = (mm / W) % H;
-    px[i] = x;
-    py[i] = y;
+    const int m = m0 + e.srow + 32 * i;
+    const int mm = m < M ? m : 0;
+    const int x = mm % W, y = (mm / W) % H;
+    unsigned mk = 0;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
+    }
+    tmask[i] = m < M ? mk : 0u;
     pa[i] = in + (size_t)mm * Cin + e.slot * 4;
   }
   const float *pb[E::NB];
@@ -144,28 +151,28 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restri
     pb[i] = w + (size_t)(vb[i] ? n : 0) * K + e.slot * 4;
   }
   f32x4 ra[E::NA], rb[E::NB];
-  auto fetch = [&](int kt) {
-    const int tap = kt / cpt;
-    const int cc = kt - tap * cpt;
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    const int aoff = (dy * W + dx) * Cin + cc * BK;
+  int ftap = 0, fcc = 0;   // (tap, channel chunk) of the next k-tile to fetch
+  auto fetch = [&]() {
+    const int dy = ftap / 3 - 1, dx = ftap - (ftap / 3) * 3 - 1;
+    const int aoff = (dy * W + dx) * Cin + fcc * BK;
 #pragma unroll
-    for (int i = 0; i < E::NA; i++) {
-      const int yy = py[i] + dy, xx = px[i] + dx;
-      const bool ok = va[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      ra[i] = ldg4(pa[i] + aoff, ok);
+    for (int i = 0; i < E::NA; i++) ra[i] = ldg4(pa[i] + aoff, (tmask[i] >> ftap) & 1u);
+    const int boff = (ftap * cpt + fcc) * BK;
+#pragma unroll
+    for (int i = 0; i < E::NB; i++) rb[i] = ldg4(pb[i] + boff, vb[i]);
+    if (++fcc == cpt) {
+      fcc = 0;
+      ftap++;
     }
-#pragma unroll
-    for (int i = 0; i < E::NB; i++) rb[i] = ldg4(pb[i] + kt * BK, vb[i]);
   };
 
-  fetch(0);
+  fetch();
   e.store_stage(smem, ra, rb);
   __syncthreads();
   for (int kt = 0; kt < nk; kt++) {
     float *cur = SB ? smem : smem + (kt & 1) * E::STAGE;
     float *nxt = SB ? smem : smem + ((kt + 1) & 1) * E::STAGE;
-    if (kt + 1 < nk) fetch(kt + 1);
+    if (kt + 1 < nk) fetch();
     e.compute(cur);
     if (SB) __syncthreads();
     if (kt + 1 < nk) e.store_stage(nxt, ra, rb);
@@ -253,47 +260,51 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
       __syncthreads();   // every wave is done with the previous segment's LDS tile
       e.zero_acc();
     }
-    // per-lane staging descriptors, compact (this kernel runs at the register cap of its occupancy): pixel (y, x) packed in one
-    // register, 32-bit element offsets from the tensor bases instead of pointers (inputs < 2^31 elements: checked by the launcher)
-    int pyx[E::NA];
-    unsigned oa[E::NA], ob[E::NB];
-    unsigned vmask = 0;   // bit i: A row i valid, bit 8 + i: B row i valid
+    // per-lane staging descriptors as in the tile kernel (tap masks, incremental k-tile coordinates), with 32-bit element
+    // offsets from the tensor bases instead of pointers (inputs < 2^32 elements: checked by the launcher)
+    unsigned tmask[E::NA], oa[E::NA], ob[E::NB];
+    unsigned vbm = 0;     // bit i: B row i valid
 #pragma unroll
     for (int i = 0; i < E::NA; i++) {
       const int m = m0 + e.srow + 32 * i;
-      const bool v = m < M;
-      const int mm = v ? m : 0;
-      pyx[i] = (((mm / W) % H) << 16) | (mm % W);
+      const int mm = m < M ? m : 0;
+      const int x = mm % W, y = (mm / W) % H;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
+      }
+      tmask[i] = m < M ? mk : 0u;
       oa[i] = (unsigned)mm * (unsigned)Cin + e.slot * 4;
-      vmask |= (v ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < E::NB; i++) {
       const int n = n0 + e.srow + 32 * i;
       const bool v = n < Cout;
       ob[i] = (unsigned)(v ? n : 0) * (unsigned)K + e.slot * 4;
-      vmask |= (v ? 1u : 0u) << (8 + i);
+      vbm |= (v ? 1u : 0u) << i;
     }
     f32x4 ra[E::NA], rb[E::NB];
-    auto fetch = [&](int kt) {
-      const int tap = kt / cpt;
-      const int cc = kt - tap * cpt;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int aoff = (dy * W + dx) * Cin + cc * BK;
+    int ftap = ka / cpt, fcc = ka - ftap * cpt;   // (tap, channel chunk) of the next k-tile to fetch
+    auto fetch = [&]() {
+      const int dy = ftap / 3 - 1, dx = ftap - (ftap / 3) * 3 - 1;
+      const int aoff = (dy * W + dx) * Cin + fcc * BK;
 #pragma unroll
-      for (int i = 0; i < E::NA; i++) {
-        const int yy = (pyx[i] >> 16) + dy, xx = (pyx[i] & 0xffff) + dx;
-        const bool ok = ((vmask >> i) & 1u) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        ra[i] = ldg4(in + (size_t)(oa[i] + (unsigned)aoff), ok);
+      for (int i = 0; i < E::NA; i++) ra[i] = ldg4(in + (size_t)(oa[i] + (unsigned)aoff), (tmask[i] >> ftap) & 1u);
+      const unsigned boff = (unsigned)((ftap * cpt + fcc) * BK);
+#pragma unroll
+      for (int i = 0; i < E::NB; i++) rb[i] = ldg4(w + (size_t)(ob[i] + boff), (vbm >> i) & 1u);
+      if (++fcc == cpt) {
+        fcc = 0;
+        ftap++;
       }
-#pragma unroll
-      for (int i = 0; i < E::NB; i++) rb[i] = ldg4(w + (size_t)(ob[i] + (unsigned)(kt * BK)), (vmask >> (8 + i)) & 1u);
     };
-    fetch(ka);
+    fetch();
     e.store_stage(smem, ra, rb);
     __syncthreads();
     for (int kt = ka; kt < kb; kt++) {
-      if (kt + 1 < kb) fetch(kt + 1);
+      if (kt + 1 < kb) fetch();
       e.compute(smem);
       __syncthreads();
       if (kt + 1 < kb) e.store_stage(smem, ra, rb);
