@@ -26,13 +26,25 @@ __device__ __forceinline__ f32x4 ldg4(const float *p, bool ok) {
   return ok ? *reinterpret_cast<const f32x4 *>(p) : z;
 }
 
+// Buffer-addressed 16-byte load: resource r covers the whole tensor, `voff` is a per-lane BYTE offset and `soff` a uniform one.
+// A lane whose voff is BUF_OOB reads zeros (hardware range check) -- zero fill without exec masking, without clearing the
+// destination registers first and without a predicate per load.  BUF_OOB + soff must not wrap: tensors below 2 GiB only.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ldbuf4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[M,N] = act(alpha * A[M,K] B[N,K]^T + bias)
 // ------------------------------------------------------------------------------------------------
 // SB (single LDS buffer): the next k-tile waits in registers and is written into the ONE stage between two barriers, so a
 // workgroup holds 32 KB instead of 64 KB of LDS and three of them (12 waves, 3 per SIMD = the register limit) share a CU
 // instead of two: while one workgroup sits in its barrier / staging bubble, two others can feed the matrix pipe.
-template <int BM, int BN, int WM, int WN, bool SB = false>
+template <int BM, int BN, int WM, int WN, bool SB = false, bool FULL = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const float *__restrict__ A, int lda,
                                                            const float *__restrict__ B, int ldb,
                                                            float *__restrict__ C, int ldc,
@@ -63,7 +75,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const float *__restri
     pb[i] = B + (size_t)(vb[i] ? n : 0) * ldb + e.slot * 4;
   }
   f32x4 ra[E::NA], rb[E::NB];
+  // FULL (chosen by the launcher: M, N, K multiples of the tile and both operands below 4 GiB): every load is unconditional and
+  // addressed as uniform base (advanced per k-tile on the scalar unit) + a fixed 32-bit per-lane offset, so the k loop spends no
+  // vector instruction on addresses or predicates -- on this chip the instructions next to the MFMAs cost clock (see the conv).
+  unsigned oa[E::NA], ob[E::NB];
+#pragma unroll
+  for (int i = 0; i < E::NA; i++) oa[i] = (unsigned)(m0 + e.srow + 32 * i) * (unsigned)lda + e.slot * 4;
+#pragma unroll
+  for (int i = 0; i < E::NB; i++) ob[i] = (unsigned)(n0 + e.srow + 32 * i) * (unsigned)ldb + e.slot * 4;
   auto fetch = [&](int kt) {
+    if (FULL) {
+      const float *Ak = A + (size_t)kt * BK, *Bk = B + (size_t)kt * BK;
+#pragma unroll
+      for (int i = 0; i < E::NA; i++) ra[i] = *reinterpret_cast<const f32x4 *>(Ak + oa[i]);
+#pragma unroll
+      for (int i = 0; i < E::NB; i++) rb[i] = *reinterpret_cast<const f32x4 *>(Bk + ob[i]);
+      return;
+    }
     const int k = kt * BK + e.slot * 4;
     const bool kin = k < K;
 #pragma unroll
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv, pad 1, stride 1, NHWC, as implicit GEMM.  k-tile kt <-> (tap = kt / (Cin/32), 32 channels).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool SB = false>
+template <int BM, int BN, int WM, int WN, bool SB = false, bool BUF = false>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restrict__ in,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ bias,
@@ -152,14 +180,30 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restri
   }
   f32x4 ra[E::NA], rb[E::NB];
   int ftap = 0, fcc = 0;   // (tap, channel chunk) of the next k-tile to fetch
+  // BUF (launcher: both tensors below 2 GiB): buffer-addressed loads, zero fill by the hardware range check (ldbuf4)
+  const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(in, BUF ? (size_t)M * Cin * sizeof(float) : 0);
+  const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(w, BUF ? (size_t)Cout * K * sizeof(float) : 0);
+  unsigned oa[E::NA], ob[E::NB];   // byte offsets of the rows (BUF)
+#pragma unroll
+  for (int i = 0; i < E::NA; i++) oa[i] = (unsigned)((const char *)pa[i] - (const char *)in);
+#pragma unroll
+  for (int i = 0; i < E::NB; i++) ob[i] = vb[i] ? (unsigned)((const char *)pb[i] - (const char *)w) : BUF_OOB;
   auto fetch = [&]() {
     const int dy = ftap / 3 - 1, dx = ftap - (ftap / 3) * 3 - 1;
     const int aoff = (dy * W + dx) * Cin + fcc * BK;
-#pragma unroll
-    for (int i = 0; i < E::NA; i++) ra[i] = ldg4(pa[i] + aoff, (tmask[i] >> ftap) & 1u);
     const int boff = (ftap * cpt + fcc) * BK;
+    if (BUF) {
 #pragma unroll
-    for (int i = 0; i < E::NB; i++) rb[i] = ldg4(pb[i] + boff, vb[i]);
+      for (int i = 0; i < E::NA; i++)
+        ra[i] = ldbuf4(ra_rsrc, ((tmask[i] >> ftap) & 1u) ? oa[i] + (unsigned)(aoff * 4) : BUF_OOB, 0);
+#pragma unroll
+      for (int i = 0; i < E::NB; i++) rb[i] = ldbuf4(rb_rsrc, ob[i], (unsigned)(boff * 4));
+    } else {
+#pragma unroll
+      for (int i = 0; i < E::NA; i++) ra[i] = ldg4(pa[i] + aoff, (tmask[i] >> ftap) & 1u);
+#pragma unroll
+      for (int i = 0; i < E::NB; i++) rb[i] = ldg4(pb[i] + boff, vb[i]);
+    }
     if (++fcc == cpt) {
       fcc = 0;
       ftap++;
@@ -249,6 +293,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
   const long U = (long)ntiles * nk;
   const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
   constexpr int NACC4 = E::TM * E::TN * 4;
+  const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(in, (size_t)M * Cin * sizeof(float));   // (both tensors < 2 GiB: launcher)
+  const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(w, (size_t)Cout * K * sizeof(float));
   for (long u = u0; u < u1;) {
     const int t = (int)(u / nk);
     const int ka = (int)(u - (long)t * nk);
@@ -291,10 +337,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
       const int dy = ftap / 3 - 1, dx = ftap - (ftap / 3) * 3 - 1;
       const int aoff = (dy * W + dx) * Cin + fcc * BK;
 #pragma unroll
-      for (int i = 0; i < E::NA; i++) ra[i] = ldg4(in + (size_t)(oa[i] + (unsigned)aoff), (tmask[i] >> ftap) & 1u);
+      for (int i = 0; i < E::NA; i++)
+        ra[i] = ldbuf4(ra_rsrc, ((tmask[i] >> ftap) & 1u) ? (oa[i] + (unsigned)aoff) * 4u : BUF_OOB, 0);
       const unsigned boff = (unsigned)((ftap * cpt + fcc) * BK);
 #pragma unroll
-      for (int i = 0; i < E::NB; i++) rb[i] = ldg4(w + (size_t)(ob[i] + boff), (vbm >> i) & 1u);
+      for (int i = 0; i < E::NB; i++) rb[i] = ldbuf4(rb_rsrc, ((vbm >> i) & 1u) ? ob[i] * 4u : BUF_OOB, boff * 4u);
       if (++fcc == cpt) {
         fcc = 0;
         ftap++;
@@ -626,8 +673,14 @@ void launch_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, 
   using E = Engine<BM, BN, WM, WN>;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   if (f32_single_buffer()) {
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), E::STAGE * sizeof(float), st,
-                       A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, tiles_m, tiles_n);
+    const bool full = M % BM == 0 && N % BN == 0 && K % BK == 0 && (size_t)M * lda * sizeof(float) < (1ull << 32) &&
+                      (size_t)N * ldb * sizeof(float) < (1ull << 32);
+    if (full)
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, true, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), E::STAGE * sizeof(float), st,
+                         A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), E::STAGE * sizeof(float), st,
+                         A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, tiles_m, tiles_n);
     return;
   }
   const size_t lds = 2 * E::STAGE * sizeof(float);
@@ -642,8 +695,13 @@ void launch_conv(const float *in, const float *w, const float *bias, float *out,
   const int M = F * H * W;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
   if (f32_single_buffer()) {
-    hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), E::STAGE * sizeof(float), st,
-                       in, w, bias, out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
+    const bool small = (size_t)M * Cin * sizeof(float) < (1ull << 31) && (size_t)Cout * 9 * Cin * sizeof(float) < (1ull << 31);
+    if (small)
+      hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WM, WN, true, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), E::STAGE * sizeof(float), st,
+                         in, w, bias, out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), E::STAGE * sizeof(float), st,
+                         in, w, bias, out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
     return;
   }
   const size_t lds = 2 * E::STAGE * sizeof(float);
@@ -776,11 +834,13 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
   const long t128 = (long)(((long)F * H * W + 127) / 128) * ((Cout + 127) / 128);
   const char *sm = nafae::experiment_env("NAFAE_F32_CONV_SMALL");
   const bool small_ok = sm ? sm[0] == '1' : F32_CONV_SMALL_DEFAULT;
+  // both tensors below 2 GiB: the kernels may use buffer-addressed loads (ldbuf4)
+  const bool small = (size_t)F * H * W * Cin * sizeof(float) < (1ull << 31) && (size_t)Cout * 9 * Cin * sizeof(float) < (1ull << 31);
   if (Cout <= 64) {
     // (256 x 64 tiles -- the 64 MFMAs per wave and k-tile of the 128 x 128 kernel -- need 176 registers, two workgroups per CU
     // instead of four: 64 -> 64 at 224^2 2.44 vs 2.25 ms, rejected)
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
-  } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) && (long)F * H * W * Cin < (1L << 32) &&   // (32-bit element offsets)
+  } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) && small &&   // (buffer-addressed loads)
              workspace_bytes >= (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float)) {
     // whole rounds (a multiple of #CUs tiles: every CU gets the same number) go through the tile kernel at its three workgroups
     // per CU; only the remainder -- the part that would leave most CUs idle -- runs on the stream-K schedule (two per CU)
@@ -792,7 +852,7 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
     const int rounds = (int)(t128 / sk_num_cus());
     const int full = rounds >= 4 ? rounds * sk_num_cus() : 0, rem = (int)t128 - full;
     if (full > 0) {
-      hipLaunchKernelGGL((conv3x3_kernel<128, 128, 2, 2, true>), dim3(full), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias,
+      hipLaunchKernelGGL((conv3x3_kernel<128, 128, 2, 2, true, true>), dim3(full), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias,
                          out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
       if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/r2m
 O=gpurun_out/r2m
-(timeout 300 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k conv > $O/t.log 2>&1; echo rc=$? >> $O/t.log); tail -3 $O/t.log
+(timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m gpu -x > $O/t.log 2>&1; echo rc=$? >> $O/t.log); tail -3 $O/t.log
 (timeout 300 python scripts/layer_times_f32.py > $O/layers_f32.log 2>&1; echo rc=$? >> $O/layers_f32.log); grep -v amdgpu.ids $O/layers_f32.log
 (timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-precisions > $O/bench_f32.json 2> $O/bench_f32.err; echo rc=$? >> $O/bench_f32.err)
 python3 -c "
