@@ -754,6 +754,19 @@ static int gemm_tn_dispatch(const float *A, int lda, const float *B, int ldb, fl
   return launch_gemm_tn<64, 64>(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, rows, count, false, st);
 }
 
+namespace {
+inline int sk_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+}  // namespace
+
 extern "C" {
 
 int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M,
@@ -761,7 +774,10 @@ int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, in
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((K & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
   if (lda < K || ldb < K || ldc < N) return NAFAE_EINVAL;
-  if (N <= 64)
+  // 128 x 64 tiles also when 128 x 128 would leave fewer than two workgroups per CU (VisEbd: 8192 x 512 = 256 tiles, one per CU,
+  // whose barrier / staging bubbles nobody fills)
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (N <= 64 || t128 < 2L * sk_num_cus())
     launch_gemm_nt<128, 64, 4, 1>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
   else
     launch_gemm_nt<128, 128, 2, 2>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
@@ -793,16 +809,6 @@ int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias
 }
 
 namespace {
-inline int sk_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
 // stream-K pays when the CUs that hold one more tile than the average idle the others for more than ~5 % of the launch
 inline bool f32_sk_pays(long tiles, int cus) {
   const long per = (tiles + cus - 1) / cus;

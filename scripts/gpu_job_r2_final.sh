@@ -1,6 +1,6 @@
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2f
+O=$R/gpurun_out/r2z
 mkdir -p $O
 cd $R
 (timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_all.log 2>&1; echo rc=$? >> $O/gpu_all.log)
@@ -20,4 +20,10 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   n=$(echo $pmc | cut -d" " -f1)
   timeout 200 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmck_$n -o t -- python3 $R/scripts/kernels_only.py 3 > $O/pmck_$n.log 2>&1
 done
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $pmc | cut -d" " -f1)
+  timeout 200 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmcb_$n -o t -- python3 $R/scripts/kernels_bf16_only.py > $O/pmcb_$n.log 2>&1 < /dev/null
+done
+cd $R
+(timeout 300 python scripts/layer_times_f32.py > $O/layers_f32.log 2>&1); (timeout 300 python scripts/layer_times.py > $O/layers_bf16x3.log 2>&1)
 ls $O | wc -l
