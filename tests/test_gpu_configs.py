@@ -60,9 +60,10 @@ def c2():
 # precision: (base_feat / fc7 / V tolerance relative to tensor scale, min identical-ROI fraction, loss tolerance,
 #             min D_ind agreement on comparable entries, gradient tolerance)
 C2_BARS = {
-    # measured (round 2): f32 8192/8192 identical rois with one conv tile per workgroup and 8190/8192 on the stream-K conv
-    # schedule that is the default (a cut tile sums its K range as two fp32 chains: two proposals at an NMS / top-N near-tie
-    # flip against the oracle's own summation order), bf16x3 8182/8192 (59 of 64 frames with all 128 identical)
+    # measured (round 2): f32 8192/8192 identical rois with one conv tile per workgroup; on the stream-K conv schedules that are
+    # the default a cut tile sums its K range as two fp32 chains, and proposals at an NMS / top-N near-tie can flip against the
+    # oracle's own summation order: 8190/8192 with stream-K over whole layers, 8192/8192 with the split schedule that shipped;
+    # bf16x3 8182/8192 (59 of 64 frames with all 128 identical)
     "f32": dict(feat=1e-4, rois=0.9995, loss=1e-4, dind=1.0, grad=5e-4, ground=0.999),
     "bf16x3": dict(feat=1e-4, rois=0.998, loss=1e-4, dind=1.0, grad=5e-4, ground=0.995),
     # BASELINE config C3: bf16 operands (8-bit mantissa), fp32 accumulation.  Stated tolerance: 3e-2 of the tensor scale on
