@@ -120,6 +120,24 @@ def test_conv3x3_stream_k(ops, Fr, H, W, Cin, Cout):
     assert relerr(s1.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("Fr,H,Cin,Cout", [(170, 224, 64, 64), (350, 112, 128, 128)])
+def test_conv3x3_inputs_beyond_2gib(ops, Fr, H, Cin, Cout):
+    """fp32 conv with an input above 2 GiB: the kernels fall back from buffer-addressed loads (hardware zero fill, tensors below
+    2 GiB) to pointer loads and from the stream-K schedule to one tile per workgroup (gemm.hip, nafae_conv3x3_relu_ws); the last
+    frames of the big batch must equal the same frames convolved on their own, bit for bit."""
+    if torch.cuda.mem_get_info()[0] < 30 * 2 ** 30:
+        pytest.skip("needs 30 GB of free HBM")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.relu(torch.randn(Fr, H, H, Cin, device="cuda", generator=g))
+    assert x.numel() * 4 > 2 ** 31
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * 0.05
+    b = torch.randn(Cout, device="cuda", generator=g)
+    big = ops.conv3x3_relu(x, w, b, relu=True)[Fr - 2:].clone()
+    small = ops.conv3x3_relu(x[Fr - 2:].contiguous(), w, b, relu=True, use_workspace=False)
+    assert float(small.abs().max()) > 0
+    assert torch.equal(big, small)
+
+
 def test_conv1(ops):
     x = torch.randint(0, 255, (3, 3, 20, 18), generator=torch.Generator().manual_seed(9)).float() - 127.5
     w = rnd(10, 64, 3, 3, 3, std=0.01)
