@@ -843,8 +843,8 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
   // both tensors below 2 GiB: the kernels may use buffer-addressed loads (ldbuf4)
   const bool small = (size_t)F * H * W * Cin * sizeof(float) < (1ull << 31) && (size_t)Cout * 9 * Cin * sizeof(float) < (1ull << 31);
   if (Cout <= 64) {
-    // (256 x 64 tiles -- the 64 MFMAs per wave and k-tile of the 128 x 128 kernel -- need 176 registers, two workgroups per CU
-    // instead of four: 64 -> 64 at 224^2 2.44 vs 2.25 ms, rejected)
+    // (256 x 64 tiles -- the 64 MFMAs per wave and k-tile of the 128 x 128 kernel -- measured twice and rejected: 176 registers / two
+    // workgroups per CU 2.44 vs 2.25 ms; after the buffer-load rewrite 152 registers / three per CU 2.21 vs 2.12 ms)
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) && small &&   // (buffer-addressed loads)
              workspace_bytes >= (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float)) {
