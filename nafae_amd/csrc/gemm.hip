@@ -131,7 +131,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv, pad 1, stride 1, NHWC, as implicit GEMM.  k-tile kt <-> (tap = kt / (Cin/32), 32 channels).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool SB = false, bool BUF = false>
+// POOL: the layer is followed by the 2x2/2 max-pool and only the pooled map is written.  The rows of the implicit GEMM may be any
+// enumeration of the pixels, so here row g stands for pixel (f, y = 2*sr + (g & 1), x) with g >> 1 = (f*H/2 + sr)*W + x: four
+// consecutive aligned rows are one pooling window, and in the 32x32 MFMA accumulator layout (register r of a lane = row
+// (r & 3) + 8*(r >> 2) + 4*(lane >> 5)) those are four consecutive REGISTERS of one lane -- the pool is three v_max per
+// output, no shuffles, and g / 4 is the raster index of the pooled pixel.  max commutes with + bias and ReLU (monotone), so
+// the result equals conv -> ReLU -> pool bit for bit; the full-resolution map (822 MB after conv1_2) is never written.
+template <int BM, int BN, int WM, int WN, bool SB = false, bool BUF = false, bool POOL = false>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restrict__ in,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ bias,
@@ -159,8 +165,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restri
 #pragma unroll
   for (int i = 0; i < E::NA; i++) {
     const int m = m0 + e.srow + 32 * i;
-    const int mm = m < M ? m : 0;
-    const int x = mm % W, y = (mm / W) % H;
+    int mm = m < M ? m : 0, x, y;
+    if (POOL) {   // row -> pixel in pooling-window order
+      const int t = mm >> 1, s = t / W;
+      x = t - s * W;
+      y = 2 * (s % (H >> 1)) + (mm & 1);
+      mm = ((s / (H >> 1)) * H + y) * W + x;
+    } else {
+      x = mm % W;
+      y = (mm / W) % H;
+    }
     unsigned mk = 0;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
@@ -223,6 +237,25 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restri
     __syncthreads();
   }
 
+  if (POOL) {
+#pragma unroll
+    for (int j = 0; j < E::TN; j++) {
+      const int n = n0 + e.acc_col(j);
+      if (n >= Cout) continue;
+      const float bv = bias[n];
+#pragma unroll
+      for (int i = 0; i < E::TM; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int g = m0 + e.acc_row(i, 4 * k);   // first row of the window held in registers 4k .. 4k+3
+          if (g < M) {
+            float v = fmaxf(fmaxf(e.acc[i][j][4 * k], e.acc[i][j][4 * k + 1]), fmaxf(e.acc[i][j][4 * k + 2], e.acc[i][j][4 * k + 3])) + bv;
+            out[(size_t)(g >> 2) * Cout + n] = ((relu & 1) && v < 0.f) ? 0.f : v;
+          }
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < E::TN; j++) {
     const int n = n0 + e.acc_col(j);
@@ -235,7 +268,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restri
         const int m = m0 + e.acc_row(i, r);
         if (m < M) {
           float v = e.acc[i][j][r] + bv;
-          out[(size_t)m * Cout + n] = (relu && v < 0.f) ? 0.f : v;
+          out[(size_t)m * Cout + n] = ((relu & 1) && v < 0.f) ? 0.f : v;
         }
       }
   }
@@ -272,7 +305,7 @@ __device__ __forceinline__ void conv_epilogue(const E &e, int m0, int n0, int M,
         const int m = m0 + e.acc_row(i, r);
         if (m < M) {
           float v = e.acc[i][j][r] + bv;
-          out[(size_t)m * Cout + n] = (relu && v < 0.f) ? 0.f : v;
+          out[(size_t)m * Cout + n] = ((relu & 1) && v < 0.f) ? 0.f : v;
         }
       }
   }
@@ -688,12 +721,17 @@ void launch_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, 
                      ldb, C, ldc, bias, M, N, K, alpha, act, tiles_m, tiles_n);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool POOL = false>
 void launch_conv(const float *in, const float *w, const float *bias, float *out, int F, int H, int W, int Cin,
                  int Cout, int relu, hipStream_t st) {
   using E = Engine<BM, BN, WM, WN>;
   const int M = F * H * W;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (Cout + BN - 1) / BN;
+  if (POOL) {   // (single-buffer, buffer-load build only: the caller has checked `small`)
+    hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WM, WN, true, true, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), E::STAGE * sizeof(float), st,
+                       in, w, bias, out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
+    return;
+  }
   if (f32_single_buffer()) {
     const bool small = (size_t)M * Cin * sizeof(float) < (1ull << 31) && (size_t)Cout * 9 * Cin * sizeof(float) < (1ull << 31);
     if (small)
@@ -842,6 +880,18 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
   const bool small_ok = sm ? sm[0] == '1' : F32_CONV_SMALL_DEFAULT;
   // both tensors below 2 GiB: the kernels may use buffer-addressed loads (ldbuf4)
   const bool small = (size_t)F * H * W * Cin * sizeof(float) < (1ull << 31) && (size_t)Cout * 9 * Cin * sizeof(float) < (1ull << 31);
+  if (relu & ~0x11) return NAFAE_EINVAL;
+  if (relu & 16) {
+    // fused 2x2/2 max-pool (bit 4, as in nafae_conv3x3_bf16): out is [F, H/2, W/2, Cout].  Offered by the tile kernel for the
+    // layers it serves best -- NAFAE_ELIMIT tells the caller to pool separately (odd sizes, tensors above 2 GiB, layers that go
+    // to the stream-K schedule, whose gain is larger than the pool's)
+    if ((H & 1) || (W & 1) || !small || !f32_single_buffer() || (workspace && Cout > 64 && f32_sk_pays(t128, sk_num_cus()))) return NAFAE_ELIMIT;
+    if (Cout <= 64)
+      launch_conv<128, 64, 4, 1, true>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
+    else
+      launch_conv<128, 128, 2, 2, true>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
+    return launched();
+  }
   if (Cout <= 64) {
     // (256 x 64 tiles -- the 64 MFMAs per wave and k-tile of the 128 x 128 kernel -- measured twice and rejected: 176 registers / two
     // workgroups per CU 2.44 vs 2.25 ms; after the buffer-load rewrite 152 registers / three per CU 2.21 vs 2.12 ms)

@@ -174,13 +174,18 @@ class _fasterRCNN(nn.Module):
             return x
         x = ops.conv1_3x3_relu(im_data.contiguous(), P['conv1_w'], P['conv1_b'])
         li = 0
-        for v in VGG_CFG_D[1:]:
-            if v == 'M':
+        seq = VGG_CFG_D[1:]
+        k = 0
+        while k < len(seq):
+            if seq[k] == 'M':
                 x = ops.maxpool2x2(x)
-            else:
-                w, b = P['convs'][li]
-                x = ops.conv3x3_relu(x, w, b, relu=True, use_workspace=self.conv_stream_k)
-                li += 1
+                k += 1
+                continue
+            w, b = P['convs'][li]
+            li += 1
+            fused = k + 1 < len(seq) and seq[k + 1] == 'M'          # conv + ReLU + max-pool: fused where the library can
+            x = ops.conv3x3_relu(x, w, b, relu=True, use_workspace=self.conv_stream_k, pool=fused)
+            k += 2 if fused else 1
         return x
 
     def base_features(self, im_data):

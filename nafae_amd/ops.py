@@ -141,17 +141,29 @@ def conv1_3x3_relu(x_nchw, w27, bias):
     return out
 
 
-def conv3x3_relu(x_nhwc, w_ohwi, bias, relu=True, use_workspace=True):
+def conv3x3_relu(x_nhwc, w_ohwi, bias, relu=True, use_workspace=True, pool=False):
     """x [F,H,W,Cin], w [Cout,3,3,Cin] -> [F,H,W,Cout].
-    use_workspace=False forces the one-tile-per-workgroup schedule (results independent of F in the last bit; tests / A-B)."""
+    use_workspace=False forces the one-tile-per-workgroup schedule (results independent of F in the last bit; tests / A-B).
+    pool=True: conv + ReLU + the 2x2/2 max-pool that follows -> [F,H/2,W/2,Cout]; fused into the conv's epilogue where the library
+    offers it (bit-identical to the two launches it falls back to otherwise)."""
     _chk(x_nhwc); _chk(w_ohwi); _chk(bias)
     F, H, W, Cin = x_nhwc.shape
     Cout = w_ohwi.shape[0]
     if w_ohwi.numel() != Cout * 9 * Cin:
         raise NafaeOpError("conv3x3: weight shape mismatch")
-    out = torch.empty(F, H, W, Cout, device=x_nhwc.device, dtype=torch.float32)
     nws = int(_lib.lib().nafae_conv3x3_workspace_bytes(F, H, W, Cin, Cout)) if use_workspace else 0
     ws = _conv_workspace(nws, x_nhwc.device) if nws > 0 else None
+    if pool:
+        if H % 2 == 0 and W % 2 == 0:
+            out = torch.empty(F, H // 2, W // 2, Cout, device=x_nhwc.device, dtype=torch.float32)
+            rc = _lib.lib().nafae_conv3x3_relu_ws(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)) | 16,
+                                                  _p(ws), max(nws, 0), _stream())
+            if rc == 0:
+                return out
+            if rc != _lib.NAFAE_ELIMIT:
+                _rc(rc, "nafae_conv3x3_relu_ws")
+        return maxpool2x2(conv3x3_relu(x_nhwc, w_ohwi, bias, relu=relu, use_workspace=use_workspace))
+    out = torch.empty(F, H, W, Cout, device=x_nhwc.device, dtype=torch.float32)
     _rc(_lib.lib().nafae_conv3x3_relu_ws(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)),
                                          _p(ws), max(nws, 0), _stream()), "nafae_conv3x3_relu_ws")
     return out

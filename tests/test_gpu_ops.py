@@ -120,6 +120,31 @@ def test_conv3x3_stream_k(ops, Fr, H, W, Cin, Cout):
     assert relerr(s1.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout,relu", [(3, 16, 24, 64, 64, True), (2, 10, 6, 32, 132, False), (5, 28, 28, 64, 128, True),
+                                                  (1, 2, 2, 32, 64, True), (7, 14, 18, 96, 200, True)])
+def test_conv3x3_fused_pool(ops, Fr, H, W, Cin, Cout, relu):
+    """conv (+ ReLU) + 2x2/2 max-pool fused into the conv epilogue (pooling-window row order, gemm.hip) equals the two launches
+    bit for bit, and fp64 within tolerance."""
+    import nafae_amd._lib as L
+    x = rnd(31, Fr, H, W, Cin)
+    w = rnd(32, Cout, 3, 3, Cin, std=0.05)
+    b = rnd(33, Cout, std=0.1)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    out = torch.empty(Fr, H // 2, W // 2, Cout, device="cuda")
+    import ctypes
+    rc = L.lib().nafae_conv3x3_relu_ws(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), Fr, H, W, Cin, Cout, int(relu) | 16,
+                                       None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, "the fused path must be taken for these shapes"
+    two = ops.maxpool2x2(ops.conv3x3_relu(xd, wd, bd, relu=relu, use_workspace=False))
+    assert torch.equal(out, two)
+    assert torch.equal(ops.conv3x3_relu(xd, wd, bd, relu=relu, pool=True, use_workspace=False), two)
+    # default call: layers that go to the stream-K schedule pool in a second launch (last-bit differences of that schedule)
+    assert relerr(ops.conv3x3_relu(xd, wd, bd, relu=relu, pool=True).cpu(), two.cpu()) < 4e-6
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1)
+    ref = F.max_pool2d(torch.relu(ref) if relu else ref, 2).permute(0, 2, 3, 1)
+    assert relerr(out.cpu(), ref) < TOL
+
+
 @pytest.mark.parametrize("Fr,H,Cin,Cout", [(170, 224, 64, 64), (350, 112, 128, 128)])
 def test_conv3x3_inputs_beyond_2gib(ops, Fr, H, Cin, Cout):
     """fp32 conv with an input above 2 GiB: the kernels fall back from buffer-addressed loads (hardware zero fill, tensors below
