@@ -35,7 +35,7 @@ __device__ __forceinline__ bool plane_il(const void *hi, const void *lo) {
 template <class E, bool SPLIT>
 __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, float alpha, const float *__restrict__ bias,
                                          int act, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
-                                         __bf16 *__restrict__ Clo, int ldc) {
+                                         __bf16 *__restrict__ Clo, int ldc, int jlo = 0, int jhi = E::NJ) {   // [jlo, jhi): pixel tiles to write
   const bool oil = SPLIT && plane_il(Chi, Clo);
   // Common case of the conv / fc layers -- interleaved planes only, bias present, tile entirely inside the matrix: one straight
   // block without the per-piece bounds / output-kind branches of the general path below (which costs ~3300 instructions per
@@ -50,6 +50,7 @@ __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, flo
         const size_t co = ((size_t)(n >> 5) << 6) + (n & 31);
 #pragma unroll
         for (int j = 0; j < E::NJ; j++) {
+          if (j < jlo || j >= jhi) continue;
           bf16x4 hi, lo;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
@@ -70,7 +71,7 @@ __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, flo
 #pragma unroll
   for (int j = 0; j < E::NJ; j++) {
     const int m = m0 + e.pm(j);
-    if (m >= M) continue;
+    if (m >= M || j < jlo || j >= jhi) continue;
 #pragma unroll
     for (int i = 0; i < E::NI; i++)
 #pragma unroll
@@ -772,7 +773,9 @@ __global__ __launch_bounds__(NT16) void conv_sk_fixup_kernel(const float *__rest
                                                              __bf16 *__restrict__ Clo, int M, int Cout, int relu, int tiles_m,
                                                              int tiles_n, int ngrp, int G) {
   using E = EngineH<BX, BW, WX, WW, SPLIT, IL, false>;
-  const int w = blockIdx.x + 1;
+  // NJ workgroups per boundary, one per 32-pixel accumulator tile column j: the kernel is all memory traffic (2-3 partials of
+  // 256 KB in, one tile out through 8-byte pieces), and one 8-wave workgroup per cut tile does not keep enough of it in flight
+  const int w = blockIdx.x / E::NJ + 1, jsel = blockIdx.x - (w - 1) * E::NJ;
   const long U = (long)tiles_m * tiles_n * ngrp;
   const long b = U * w / G;
   const int t = (int)(b / ngrp);
@@ -789,16 +792,19 @@ __global__ __launch_bounds__(NT16) void conv_sk_fixup_kernel(const float *__rest
 #pragma unroll
     for (int i = 0; i < E::NI; i++)
 #pragma unroll
-      for (int j = 0; j < E::NJ; j++)
+      for (int j = 0; j < E::NJ; j++) {
+        if (j != jsel) continue;
 #pragma unroll
         for (int g = 0; g < E::NG; g++) {
           const f32x4 v = src[(size_t)((i * E::NJ + j) * E::NG + g) * NT16];
 #pragma unroll
           for (int q = 0; q < 4; q++) e.acc[i][j][4 * g + q] += v[q];
         }
+      }
   }
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
-  epilogue<E, SPLIT>(e, tm * BX, tn * BW, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+  epilogue<E, SPLIT>(e, tm * BX, tn * BW, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout, jsel,
+                     jsel + 1);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv, 3 taps / barrier
@@ -1459,7 +1465,8 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
                      (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch);
   if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
   // (PAIR: plain output -- the fix-up only needs the accumulator geometry, so the plain-epilogue instantiation serves)
-  hipLaunchKernelGGL((conv_sk_fixup_kernel<BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, BX>), dim3(G - 1), dim3(NT16), 0, st, scratch, bias, Cf,
+  using EF = EngineH<BX, BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, false>;
+  hipLaunchKernelGGL((conv_sk_fixup_kernel<BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, BX>), dim3((G - 1) * EF::NJ), dim3(NT16), 0, st, scratch, bias, Cf,
                      (__bf16 *)Chi, (__bf16 *)Clo, M, Cout, relu, tiles_m, tiles_n, 3 * (Cin / BKH), G);
   return launched();
 }
