@@ -123,7 +123,11 @@ int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float
  * 14^2 VGG layers idle 12-23 % of the CUs with one tile per workgroup): pass a workspace of nafae_conv3x3_workspace_bytes()
  * bytes (0 = the layer does not need one; the plain kernel then runs, as it does for workspace == NULL).  Deterministic; a tile
  * cut by the schedule sums its K range as two or three fp32 chains instead of one, so results can differ from
- * nafae_conv3x3_relu in the last bit, and WHICH tiles are cut depends on F.  */
+ * nafae_conv3x3_relu in the last bit, and WHICH tiles are cut depends on F.
+ * relu: bit 0 = ReLU; bit 4 = also apply the 2x2/2 max-pool that follows the layer (vgg16_rpn.py:38: conv1_2, conv2_2, conv3_3,
+ * conv4_3) inside the conv's epilogue -- `out` is then [F, H/2, W/2, Cout] and equals nafae_maxpool2x2(conv) bit for bit.
+ * NAFAE_ELIMIT = the fused form is not offered for this call (odd H or W, tensors above 2 GiB, or a layer that goes to the
+ * stream-K schedule): run the conv without bit 4 and pool separately.  Other bits: NAFAE_EINVAL.  */
 int64_t nafae_conv3x3_workspace_bytes(int F, int H, int W, int Cin, int Cout);
 int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, float *out, int F, int H, int W,
                           int Cin, int Cout, int relu, void *workspace, int64_t workspace_bytes, void *stream);
