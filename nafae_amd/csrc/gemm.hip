@@ -13,6 +13,15 @@
 
 using namespace nafae;
 
+// Occupancy the fp32 tile kernels are compiled for (waves per SIMD = workgroups per CU).  Unset: what the register allocation gives
+// (3 for the 128 x 128 tiles: 140-152 registers).  NAFAE_F32_TILE_WPE=4 caps them at 128 registers (A/B builds; measured after the
+// buffer-load rewrite: 10 registers spilled outside the MFMA block, conv stack 15.81 -> 16.35 ms, fc6 12.19 -> 13.44 ms -- rejected).
+#ifdef NAFAE_F32_TILE_WPE
+#define F32_TILE_OCC __attribute__((amdgpu_waves_per_eu(NAFAE_F32_TILE_WPE, NAFAE_F32_TILE_WPE)))
+#else
+#define F32_TILE_OCC
+#endif
+
 namespace {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -45,7 +54,7 @@ __device__ __forceinline__ f32x4 ldbuf4(__amdgpu_buffer_rsrc_t r, unsigned voff,
 // workgroup holds 32 KB instead of 64 KB of LDS and three of them (12 waves, 3 per SIMD = the register limit) share a CU
 // instead of two: while one workgroup sits in its barrier / staging bubble, two others can feed the matrix pipe.
 template <int BM, int BN, int WM, int WN, bool SB = false, bool FULL = false>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const float *__restrict__ A, int lda,
+__global__ __launch_bounds__(NTHREADS) F32_TILE_OCC void gemm_nt_kernel(const float *__restrict__ A, int lda,
                                                            const float *__restrict__ B, int ldb,
                                                            float *__restrict__ C, int ldc,
                                                            const float *__restrict__ bias, int M, int N, int K,
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const float *__restri
 // output, no shuffles, and g / 4 is the raster index of the pooled pixel.  max commutes with + bias and ReLU (monotone), so
 // the result equals conv -> ReLU -> pool bit for bit; the full-resolution map (822 MB after conv1_2) is never written.
 template <int BM, int BN, int WM, int WN, bool SB = false, bool BUF = false, bool POOL = false>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(NTHREADS) F32_TILE_OCC void conv3x3_kernel(const float *__restrict__ in,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, int F, int H, int W, int Cin,
