@@ -375,7 +375,11 @@ def run_rank(a):
                                "algorithmic_flops": fl, "algorithmic_bytes": opb * (R * 25088 + 4096 * 25088 + R * 4096),
                                "traffic": traffic,
                                "traffic_source": ("static: %s (separate --pmc passes on scripts/kernels*_only.py at this shape, "
-                                                  "FETCH_SIZE x2; not read in this run)" % src) if traffic else None}
+                                                  "FETCH_SIZE x2; not read in this run)" % src) if traffic else None,
+                               "traffic_note": ("L2-miss bytes (Infinity-Cache hits included), not HBM bytes: each 128x128 tile streams "
+                                                "its two K panels and the workgroups that share a panel drift apart along K, so "
+                                                "L2 re-serves little (36 % hits).  The kernel is MFMA-bound (PMC MFMA-busy 0.87 of "
+                                                "active cycles), so the re-reads cost power, not time: DESIGN.md section 8") if (traffic and prec == "f32") else None}
         res["stage_ms"] = {k: round(v["avg_ms"], 4) for k, v in sorted(prof.items())}
         det_ms = sum(v["avg_ms"] for k, v in prof.items() if k in ("base", "rpn", "roi_align", "fc6", "fc7"))
         if det_ms > 0:
