@@ -579,10 +579,11 @@ struct ConvRun {
         if (DO_X && x < NXC) issue_x(x, grp + 1);
       }
     };
-    if (NOPS > NGRP) {
+    // more staging instructions than hook slots (64-channel tiles: 6 against 4): the FIRST ones go out here, so that the issue
+    // order -- weight tile before run, which the vmcnt arithmetic above counts on -- is kept
+    constexpr int PRE = NOPS > NGRP ? NOPS - NGRP : 0;
 #pragma unroll
-      for (int k = NGRP; k < NOPS; k++) op(k);
-    }
+    for (int k = 0; k < PRE; k++) op(k);
     const __bf16 *sX = xbuf + (size_t)(grp & 1) * XRUN;
     const __bf16 *sW = wbuf + (size_t)(st % NSTW) * WST;
     const int fr = e.frow();
@@ -655,7 +656,7 @@ struct ConvRun {
           e.acc[i][j] = mfma_bf16(wa[s & 1][i][pw], x[px], e.acc[i][j]);
           if (t == NT - 1) {
             const int g = u * NI + i;   // NU * NI = NGRP staging slots per step
-            if (g < NGRP && g < NOPS) op(g);
+            if (g < NGRP && g + PRE < NOPS) op(g + PRE);
           }
         }
       }

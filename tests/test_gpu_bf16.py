@@ -217,6 +217,26 @@ def test_conv_inputs_beyond_4gib(F, H, Cin, Cout, pool):
         del got, want
 
 
+@pytest.mark.parametrize("F,H,W,Cin,Cout", [(33, 64, 28, 512, 64), (3, 20, 36, 128, 64), (9, 14, 14, 64, 48)])
+def test_conv_plain_bf16_64_channel_tiles(F, H, W, Cin, Cout):
+    """Plain bf16 with at most 64 output channels runs the raster-run kernel on 256 x 64 tiles, the one configuration with more
+    staging instructions per step (6) than hook slots between its MFMA groups (4).  The surplus must go out in issue order --
+    weight tile first -- or the counted vmcnt wait lets a step start on a weight tile that has not landed (found by
+    scripts/stress_conv.py: relative error 0.22 at the first shape)."""
+    from nafae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(F, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    xp, wp = ops.split_bf16(x, False, False), ops.split_bf16(w, False, False)
+    xr, wr = ops.merge_bf16(xp), ops.merge_bf16(wp)
+    ref = torch.relu(torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1)
+    for _ in range(3):      # (the failure was a race: repeat)
+        _, p = ops.conv3x3_bf16(xp, wp, b, relu=True)
+        out = ops.merge_bf16(p)
+        assert float((out - ref).abs().max()) <= 8e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("F,H,Cin,Cout", [(64, 56, 64, 256), (64, 28, 256, 512), (24, 56, 64, 128), (5, 56, 32, 256), (33, 28, 64, 512)])
 def test_conv_stream_k_schedule(F, H, Cin, Cout):
     """Stream-K schedule of the run-reuse conv (tile counts that leave the last round mostly empty: 784 / 392 / 294 / 62 / 204
