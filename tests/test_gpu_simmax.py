@@ -70,6 +70,46 @@ def test_sim_max_v2_matches_fp64(case, with_hint):
     assert float((S1.cpu().double() - S).abs().max()) < 2e-5 * scale
 
 
+def _random_cases(n, seed):
+    import random
+    rs = random.Random(seed)
+    out = []
+    for _ in range(n):
+        Na, Ns = rs.randint(1, 8), rs.randint(1, 8)
+        Nb = rs.choice([1, 5, 31, 32, 33, 64, 100, 128, 129, 256, 300, 320])
+        Ne = rs.choice([1, 3, 8, 16, 20, 32, 64])
+        D = rs.choice([32, 64, 96, 128, 256, 512, 1024])
+        kind = rs.random()
+        if kind < 0.25:
+            lens = [Ne] * Na                                     # every slot live (the dense path when Na * Ne > 64)
+        elif kind < 0.35:
+            lens = [0] * Na
+        else:
+            lens = [rs.randint(0, Ne) for _ in range(Na)]
+        if Na * Ns * Nb * D > 6e6:
+            Ns = max(1, int(6e6 / (Na * Nb * D)))
+        out.append((Na, Ns, Nb, Ne, D, lens))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(48, 2024), ids=lambda c: "Na%d_Ns%d_Nb%d_Ne%d_D%d_L%d" % (c[:5] + (sum(c[5]),)))
+def test_sim_max_v2_random_shapes(case):
+    """Seeded random sweep over the shape / length space (both the live-column kernel and the dense tile path, ragged row
+    blocks, empty and full segments): same checks as above."""
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, D, lens = case
+    V = torch.tanh(syn.randn(33, "Vr%d_%d" % (D, Nb), (Na * Ns * Nb, D)))
+    W = torch.tanh(syn.randn(33, "Wr%d_%d" % (D, Ne), (Na * Ne, D)))
+    m, i, gap, masked = _ref(V, W, lens, Na, Nb, Ne)
+    for hint in (lens, None):
+        S, Di = _run(V, W, lens, Na, Ns, Nb, Ne, lens=hint)
+        S, Di = S.cpu().double(), Di.cpu()
+        scale = max(float(m.abs().max()), 1e-6)
+        assert (S[masked] == 0).all() and (Di[masked] == 0).all()
+        assert float((S - m).abs().max()) < 2e-6 * scale
+        assert not ((Di != i) & ~masked & (gap > 1e-5 * scale)).any()
+
+
 def test_sim_max_v2_ties_pick_first_index():
     """Duplicate proposals (zero-padded rois give identical rows) -> the FIRST maximal index, like torch.max(dim)."""
     from nafae_amd import synthetic as syn
