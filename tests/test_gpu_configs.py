@@ -224,3 +224,65 @@ def test_sim_loss_full_size_vs_oracle(name, lens_kind, capsys):
     assert e_L < 1e-4 and e_vis < 1e-4, (e_L, e_vis)
     if not mism.any():
         assert e_dV < 5e-4 and e_dW < 5e-4, (e_dV, e_dW)
+
+
+def _random_simloss_cases(n, seed):
+    import random
+    rs = random.Random(seed)
+    out = []
+    for _ in range(n):
+        Na, Ns = rs.randint(1, 6), rs.randint(1, 6)
+        Nb = rs.choice([1, 7, 20, 32, 33, 64, 100, 128])
+        Ne = rs.choice([1, 4, 8, 13, 16, 32])
+        kind = rs.random()
+        lens = [Ne] * Na if kind < 0.25 else ([rs.randint(0, Ne) for _ in range(Na)])
+        if sum(lens) == 0:
+            lens[0] = max(1, Ne // 2)          # (the reference skips batches without any entity, model.py:685-686)
+        out.append((Na, Ns, Nb, Ne, lens, rs.choice([64, 128, 512])))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _random_simloss_cases(36, 77), ids=lambda c: "Na%d_Ns%d_Nb%d_Ne%d_D%d_L%d" % (c[:4] + (c[5], sum(c[4]))))
+def test_sim_loss_random_shapes_vs_oracle(case):
+    """Seeded random sweep of the whole similarity + ranking / clustering loss + backward chain (simmax.hip, simloss.hip:
+    live-column and dense paths, LDS and global-memory loss tails, ragged segment lengths) against oracle.dvsa."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from nafae_amd import ops
+    from nafae_amd import synthetic as syn
+    from oracle import dvsa as O
+    Na, Ns, Nb, Ne, lens, D = case
+    F, Q, R = Na * Ns, Na * Ne, Na * Ns * Nb
+    V, W = syn.embeddings(R, Q, D, seed=5 + Nb)
+    Vo, Wo = V.clone().requires_grad_(), W.clone().requires_grad_()
+    Di_o, Ds_o, L_o, parts = O.dvsa_forward(Vo, Wo, lens, Na, Nb, Ne, 10.0, 4.13, 'train', return_parts=True)
+    L_o.backward()
+    with torch.no_grad():
+        S = (V @ W.t()).view(F, Nb, Q)
+        gap = (S.topk(2, dim=1)[0][:, 0] - S.topk(2, dim=1)[0][:, 1]).numpy() if Nb > 1 else np.full((F, Q), np.inf)
+    Vg, Wg = V.cuda(), W.cuda()
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    S_max, D_ind = ops.sim_max_fwd(Vg, Wg, lt, Na, Ns, Nb, Ne)
+    loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, Vg, lt, Na, Ns, Nb, Ne, 10.0, 4.13, True)
+    dV, dW = ops.sim_bwd(dS, D_ind, Vg, Wg, lt, Na, Ns, Nb, Ne, True, ws)
+    live = np.zeros((Na, Ne), dtype=bool)
+    for a_, l in enumerate(lens):
+        live[a_, :l] = True
+    live = np.broadcast_to(live.reshape(1, Q), (F, Q))
+    scale = max(float(Ds_o.detach().abs().max()), 1e-6)
+    decided = gap >= 1e-4 * scale
+    Dg, Do = D_ind.cpu().numpy(), Di_o.numpy()
+    mism = (Dg != Do) & live
+    assert (Dg[~live] == 0).all() and (S_max.cpu().numpy()[~live] == 0).all()
+    assert float((S_max.cpu() - Ds_o.detach()).abs().max() / scale) < 1e-4
+    if (mism & decided).any():
+        pytest.fail("D_ind differs from the oracle at decided entries")
+    if np.isnan(float(L_o.detach())):   # degenerate batches (one frame per segment: the reference's own clustering term is 0/0): NaN both
+        assert np.isnan(float(loss_out[0]))
+        return
+    if not mism.any():          # (an undecided arg-max feeds another row into the clustering term: compare the losses only when equal)
+        assert abs(float(loss_out[0]) - float(L_o.detach())) < 1e-4 * max(abs(float(L_o.detach())), 1e-3)
+        assert int(loss_out[3]) == parts['dem']
+        assert relerr(dV.cpu(), Vo.grad) < 5e-4 and relerr(dW.cpu(), Wo.grad) < 5e-4
+
