@@ -254,6 +254,7 @@ def test_sim_loss_random_shapes_vs_oracle(case):
     from oracle import dvsa as O
     Na, Ns, Nb, Ne, lens, D = case
     F, Q, R = Na * Ns, Na * Ne, Na * Ns * Nb
+    torch.set_num_threads(8)      # (the full-size tests above raise it to every host thread, which slows these small shapes ~20x)
     V, W = syn.embeddings(R, Q, D, seed=5 + Nb)
     Vo, Wo = V.clone().requires_grad_(), W.clone().requires_grad_()
     Di_o, Ds_o, L_o, parts = O.dvsa_forward(Vo, Wo, lens, Na, Nb, Ne, 10.0, 4.13, 'train', return_parts=True)
