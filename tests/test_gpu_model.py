@@ -142,6 +142,28 @@ def test_detector_config_c1_against_oracle(gpu, precision):
     assert (fr.n_keep.cpu() <= 32).all()
 
 
+@pytest.mark.parametrize("F,H,W", [(1, 64, 96), (3, 96, 80), (2, 112, 160), (5, 144, 48), (2, 48, 208), (7, 80, 80)])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_detector_other_frame_sizes_against_oracle(gpu, precision, F, H, W):
+    """The whole detector at frame sizes other than 224 x 224 (feature maps that are not multiples of the conv kernels' tile
+    shapes, frame counts that leave ragged tiles, layers that change schedule: patch / raster-run / stream-K, fused or separate
+    pool) against the CPU oracle."""
+    from nafae_amd import synthetic as syn
+    from oracle import detector as OD
+    torch.set_num_threads(16)
+    gpu.TEST.RPN_POST_NMS_TOP_N = 16
+    fr = _detector(77, precision)
+    im, im_info = syn.frames(F, H, W, seed=100 + H + W)
+    rois, roi_scores, pooled, fc7 = fr(im.cuda(), im_info.cuda(), None, None)
+    sd = syn.detector_state(seed=77, heads=False)
+    ocfg = dict(FEAT_STRIDE=16, ANCHOR_SCALES=[4, 8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_PRE_NMS_TOP_N=6000,
+                RPN_POST_NMS_TOP_N=16, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
+    r_o, s_o, pooled_o, fc7_o = OD.detector_forward(im, im_info, sd, ocfg)
+    same = ((rois.cpu() - r_o).abs() < 0.02).all(-1).view(-1).numpy()
+    assert same.mean() >= 0.9, same.mean()
+    assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < TOL
+
+
 def test_full_train_step_and_eval_step(gpu):
     """One iteration of the reference's train loop body (model.py:706-774) and of validate (model.py:875-947)."""
     from nafae_amd.model import default_args, postprocess, stepRCNN
