@@ -164,6 +164,21 @@ def test_detector_other_frame_sizes_against_oracle(gpu, precision, F, H, W):
     assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < TOL
 
 
+@pytest.mark.parametrize("F,H,W", [(1, 64, 96), (3, 96, 80), (2, 112, 160), (9, 224, 224)])
+def test_conv_stack_plain_bf16_other_sizes(gpu, F, H, W):
+    """BASELINE C3's arithmetic (plain bf16 operands, fp32 accumulation) through the conv stack at small frame counts and sizes:
+    few tiles send the 64-channel layers to the raster-run kernel's 256 x 64 tiles instead of the patch kernel (the configuration
+    that had the staging-order bug).  Against the oracle's fp32 conv stack, at the bf16 tolerance."""
+    from nafae_amd import synthetic as syn
+    from oracle import detector as OD
+    torch.set_num_threads(16)
+    fr = _detector(78, "bf16")
+    im, _ = syn.frames(F, H, W, seed=300 + H + W)
+    got = _base_nhwc_f32(fr, im.cuda()).cpu().permute(0, 3, 1, 2)
+    want = OD.vgg16_features(im, syn.detector_state(seed=78, heads=False))
+    assert relerr(got, want) < 3e-2
+
+
 def test_full_train_step_and_eval_step(gpu):
     """One iteration of the reference's train loop body (model.py:706-774) and of validate (model.py:875-947)."""
     from nafae_amd.model import default_args, postprocess, stepRCNN
