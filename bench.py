@@ -256,15 +256,34 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            # rank 0 is done: the others finish within seconds -- or, if rank 0 died, hang in a collective: stop exactly them
-            rcs.append(p.wait(timeout=120 if rcs[0] == 0 else 10))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(p.wait())
+    # Poll EVERY child: if any rank dies (out of memory, bad LOCAL_RANK, a failed collective) the others would block inside an
+    # RCCL collective for as long as the watchdog lets them, so the first non-zero exit stops exactly the processes started
+    # here and the launcher fails fast.  Rank 0's stdout is drained by a reader thread so that a long JSON line cannot fill
+    # the pipe while the parent polls.  A wall-clock limit (BENCH_LAUNCH_TIMEOUT_S, default 3600 s) bounds a hang.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "3600"))
+    rcs = [None] * n
+    failed = False
+    while any(c is None for c in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(c not in (None, 0) for c in rcs) or time.time() > deadline:
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                p.kill()
+                rcs[r] = p.wait()
+        if time.time() > deadline:
+            sys.stderr.write("bench.py: ranks still running after the launch timeout; stopped them\n")
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else b""
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]

@@ -48,7 +48,7 @@ def build(force=False, verbose=False, experiments=False):
     tuning environment variables that scripts/ use (select it with NAFAE_LIB=<path>); the default build has neither."""
     deps_common = [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
     objs = []
-    rebuilt = False
+    jobs = []
     lib = LIB.replace(".so", "_exp.so") if experiments else LIB
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
@@ -56,12 +56,19 @@ def build(force=False, verbose=False, experiments=False):
         if experiments:
             extra = extra + ["-DNAFAE_EXPERIMENTS"]
         if force or _stale(o, [s] + deps_common):
-            cmd = [_hipcc()] + COMMON + extra + ["-c", s, "-o", o]
+            jobs.append([_hipcc()] + COMMON + extra + ["-c", s, "-o", o])
+        objs.append(o)
+    rebuilt = bool(jobs)
+    if jobs:            # translation units are independent: compile them side by side (the bf16 engine alone takes minutes)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            rebuilt = True
-        objs.append(o)
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, jobs))
     if force or rebuilt or _stale(lib, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
         if verbose:

@@ -262,11 +262,36 @@ class FusedClipAdam:
     def zero_grad(self):
         self.reducer.zero_grad()
 
+    def set_reference_layout(self, model):
+        """Record where each flat-buffer parameter sits in the REFERENCE's optimiser (model.py:1077-1082: Adam over three
+        param groups in the order DVSA, word_ebd, vis_ebd), so that state_dict() / load_state_dict() speak the index space of
+        the 'optimizer' entry of a reference vis_ground_*.pth.  (This class keeps vis_ebd before word_ebd in its flat buffer;
+        without the mapping a reference state would put moments on the wrong parameters -- silently for the equal-shaped
+        bias / BatchNorm vectors.)"""
+        groups = [list(model.DVSA.parameters()), list(model.word_ebd.parameters()), list(model.vis_ebd.parameters())]
+        index, self._ref_groups, k = {}, [], 0
+        for g in groups:
+            self._ref_groups.append(list(range(k, k + len(g))))
+            for p in g:
+                index[id(p)] = k
+                k += 1
+        self._ref_index = [index[id(p)] for p in self.reducer.params]
+
+    def _layout(self):
+        idx = getattr(self, "_ref_index", None)
+        if idx is None:
+            n = len(self.reducer.params)
+            return list(range(n)), [list(range(n))]
+        return idx, self._ref_groups
+
     def state_dict(self):
-        """torch.optim.Adam-shaped state ('state' keyed by parameter index over the reducer's parameter list, 'param_groups'),
-        so that the 'optimizer' entry of a vis_ground_*.pth checkpoint (model.py:1118-1124) round-trips."""
+        """torch.optim.Adam-shaped state: 'state' keyed by the parameter's index in the reference's optimiser (after
+        set_reference_layout; DVSA's parameters never receive a gradient and have no entry, exactly as in torch) and the
+        reference's three 'param_groups', so that the 'optimizer' entry of a vis_ground_*.pth checkpoint (model.py:1118-1124)
+        round-trips in both directions."""
+        idx, groups = self._layout()
         state, o = {}, 0
-        for i, p in enumerate(self.reducer.params):
+        for i, p in zip(idx, self.reducer.params):
             k = p.numel()
             state[i] = {"step": torch.tensor(float(self.step_count)),
                         "exp_avg": self.exp_avg[o:o + k].view_as(p).clone(),
@@ -274,22 +299,37 @@ class FusedClipAdam:
             o += k
         return {"state": state,
                 "param_groups": [{"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps,
-                                  "weight_decay": self.weight_decay, "max_norm": self.max_norm,
-                                  "params": list(range(len(self.reducer.params)))}]}
+                                  "weight_decay": self.weight_decay, "max_norm": self.max_norm, "amsgrad": False,
+                                  "params": list(g)} for g in groups]}
 
     def load_state_dict(self, sd):
+        """Accepts the reference's optimiser state (three groups, indices over DVSA + word_ebd + vis_ebd) and this class's own.
+        Every moment tensor is checked against the shape of the parameter it lands on; a mismatch raises instead of loading
+        moments onto the wrong parameter."""
         state = sd.get("state", {})
+        groups = sd.get("param_groups") or []
+        idx, my_groups = self._layout()
+        n_saved = sum(len(g.get("params", [])) for g in groups)
+        if groups and n_saved != sum(len(g) for g in my_groups):
+            if n_saved == len(self.reducer.params) and len(groups) == 1:
+                idx = list(range(n_saved))        # a state saved by this class before the reference layout was recorded
+            else:
+                raise ValueError("optimizer state covers %d parameters in %d group(s); expected %d (reference layout) or %d"
+                                 % (n_saved, len(groups), sum(len(g) for g in my_groups), len(self.reducer.params)))
         o = 0
         with torch.no_grad():
-            for i, p in enumerate(self.reducer.params):
+            for i, p in zip(idx, self.reducer.params):
                 k = p.numel()
                 st = state.get(i, state.get(str(i)))
                 if st is not None:
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        if tuple(st[key].shape) != tuple(p.shape):
+                            raise ValueError("optimizer state %d: %s has shape %s, the parameter %s"
+                                             % (i, key, tuple(st[key].shape), tuple(p.shape)))
                     self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
                     self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
                     self.step_count = int(float(st["step"]))
                 o += k
-        groups = sd.get("param_groups") or []
         if groups:
             g = groups[0]
             self.param_groups[0]["lr"] = g.get("lr", self.param_groups[0]["lr"])

@@ -308,6 +308,7 @@ def setup_training(args, device='cuda', seed=1234, distributed=False, grad_excha
     # gradients always live in one flat buffer (all-reduced when world > 1); the optimiser step is the fused HIP one
     reducer = GradAllReducer(trainable_parameters(model), mode=grad_exchange)
     optimizer = FusedClipAdam(reducer, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip)
+    optimizer.set_reference_layout(model)        # checkpoints carry the reference's optimiser index space
     criterion = torch.nn.L1Loss()
     return model, optimizer, criterion, reducer
 

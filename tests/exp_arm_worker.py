@@ -1,0 +1,53 @@
+"""Child process of tests/test_gpu_bf16.py's A/B tests: runs the listed conv cases against the EXPERIMENTS build of the library
+(NAFAE_LIB=.../libnafae_hip_exp.so, the only build that honours the NAFAE_* dispatch switches) with whatever switches the
+parent put into the environment, and saves the merged fp32 outputs.  One process per arm: the library caches some switches
+in function-local statics, so an arm cannot be changed inside a process.
+
+    python tests/exp_arm_worker.py <kind: patch|pair> <out.pt>
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PATCH_CASES = [(8, 64, 128, 64, 64), (3, 112, 112, 64, 64), (5, 48, 160, 64, 64), (4, 64, 64, 128, 128), (2, 112, 112, 64, 128),
+               (9, 32, 32, 256, 64)]
+PAIR_CASES = [(8, 64, 128, 64, 64), (3, 112, 112, 64, 128), (4, 64, 64, 128, 128), (40, 56, 56, 128, 256), (64, 28, 28, 256, 512),
+              (6, 14, 14, 512, 512), (2, 20, 36, 64, 64)]
+
+
+def inputs(case, seed_of):
+    F, H, W, Cin, Cout = case
+    g = torch.Generator(device="cuda").manual_seed(seed_of(case))
+    x = torch.randn(F, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    return x, w, b
+
+
+def main():
+    kind, out_path = sys.argv[1], sys.argv[2]
+    from nafae_amd import _lib, ops
+    assert _lib.LIB_PATH.endswith("_exp.so"), _lib.LIB_PATH
+    out = {}
+    if kind == "patch":
+        for c in PATCH_CASES:
+            x, w, b = inputs(c, lambda c: c[0] * c[1] + c[2])
+            xp, wp = ops.split_bf16(x, True, True), ops.split_bf16(w, True, True)
+            _, p = ops.conv3x3_bf16(xp, wp, b, relu=True)
+            out[c] = ops.merge_bf16(p).cpu()
+    else:
+        for c in PAIR_CASES:
+            x, w, b = inputs(c, lambda c: c[0] + c[1] + c[3])
+            xp, wp = ops.split_bf16(x, False), ops.split_bf16(w, False)
+            f, p1 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)
+            _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True)
+            out[c] = (f.cpu(), ops.merge_bf16(p1).cpu(), ops.merge_bf16(p2).cpu())
+    torch.save(out, out_path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,8 +1,9 @@
-"""Generates tests/golden/config_c2.npz: the CPU ORACLE (oracle/, itself pinned to the imported reference by the
-fixtures of make_golden.py) run once, in the build container, on BASELINE config C2 AT SIZE -- 64 frames 224x224
-(Na=8, Ns=8), 128 proposals/frame, 16 query slots -- because ~3 s/frame of CPU time is too slow to repeat inside a test.
+"""Generates tests/golden/config_{c2,c4,c5}.npz: the CPU ORACLE (oracle/, itself pinned to the imported reference by the
+fixtures of make_golden.py) run once, in the build container, on a BASELINE config AT SIZE -- 64 frames 224x224
+(Na=8, Ns=8) with 128 proposals/frame x 16 query slots (C2 / C3), 256 x 32 (C4, the per-GPU share) or 300 x 64 (C5) --
+because minutes of CPU time per batch are too slow to repeat inside a test.
 
-    python tests/golden/make_config_golden.py            (about 5 minutes on 8 cores)
+    python tests/golden/make_config_golden.py [c2|c4|c5]        (1-5 minutes on 8 cores)
 
 Weights and inputs are the seeded synthetic ones of nafae_amd.synthetic / nafae_amd.train.build_model (seed 1234), which a
 test regenerates bit-identically on any machine running the same torch build; only output arrays are stored:
@@ -48,7 +49,7 @@ def embedding_params(seed=SEED, vis_fc_dim=4096, glove_dim=200, D=512):
     return p
 
 
-def main():
+def main(name="c2"):
     torch.set_num_threads(os.cpu_count() or 1)
     F = Na * Ns
     sd = syn.detector_state(seed=SEED, heads=False)
@@ -96,11 +97,21 @@ def main():
         g_ve_b=leaves["vis_ebd.fc1.bias"].grad.numpy(), g_we_w=leaves["word_ebd.fc1.weight"].grad.numpy(),
         g_we_b=leaves["word_ebd.fc1.bias"].grad.numpy(), g_bn_w=leaves["word_ebd.bn.weight"].grad.numpy(),
         g_bn_b=leaves["word_ebd.bn.bias"].grad.numpy())
-    path = os.path.join(HERE, "config_c2.npz")
+    path = os.path.join(HERE, "config_%s.npz" % name)
     np.savez_compressed(path, **out)
     print("wrote %s %.1f KB  (loss %.6f, kept %s..%s proposals/frame, total %.1f s)"
           % (path, os.path.getsize(path) / 1024, loss.item(), min(n_keep), max(n_keep), time.time() - t0))
 
 
+CONFIGS = {
+    # BASELINE configs at the size one GPU runs them: (Na, Ns, Nb, Ne).  C4 = the per-GPU share of the 8-GPU configuration.
+    "c2": (8, 8, 128, 16),
+    "c4": (8, 8, 256, 32),
+    "c5": (8, 8, 300, 64),
+}
+
+
 if __name__ == "__main__":
-    main()
+    name = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    Na, Ns, Nb, Ne = CONFIGS[name]
+    main(name)

@@ -57,8 +57,10 @@ def test_self_launched_two_ranks_run_the_dp_step_end_to_end():
     import torch
     if torch.cuda.device_count() < 1:
         pytest.skip("needs a GPU")
-    r = _run(["--gpus", "2", "--test-shared-gpu", "--steps", "2", "--warmup", "1", "--no-other-precisions", "--precision", "bf16x3",
-              "--workload", "c2"], timeout=600)
+    # no --workload: the default of an N > 1 run -- BASELINE config C4's per-GPU share (64 frames, 256 proposals, 32 query
+    # slots) -- is exactly what the driver's `bench.py --gpus 8` executes on every rank
+    r = _run(["--gpus", "2", "--test-shared-gpu", "--steps", "2", "--warmup", "1", "--no-other-precisions", "--precision", "bf16x3"],
+             timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]     # (gloo announces itself on stdout)
     assert len(lines) == 1
@@ -66,3 +68,5 @@ def test_self_launched_two_ranks_run_the_dp_step_end_to_end():
     assert d["n_gpus"] == 2 and d["config"]["rccl_world_size"] == 2 and d["config"]["parallelism"] == "dp2"
     assert d["config"]["grad_allreduce_bytes"] == 2201600 * 4 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["steps"] == 2
+    assert d["config"]["workload"].startswith("C4:") and d["config"]["proposals_per_frame"] == 256
+    assert d["config"]["queries_per_segment"] == 32 and d["config"]["frames_per_gpu"] == 64

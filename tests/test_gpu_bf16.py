@@ -177,7 +177,7 @@ def test_detector_c1_in_bf16_modes(ops, precision, tol):
     r_o, s_o, pooled_o, fc7_o = OD.detector_forward(im, im_info, sd, ocfg)
     if precision == "bf16x3":
         same = ((rois.cpu() - r_o).abs() < 0.05).all(-1).view(-1).numpy()
-        assert same.mean() >= 0.9, same.mean()
+        assert same.sum() >= same.size - 1, same.mean()        # measured: all identical; one near-tie flip tolerated
         assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < tol
         assert relerr(pooled.cpu().numpy()[same], pooled_o.numpy()[same]) < tol
     else:
@@ -267,59 +267,87 @@ def test_conv_stream_k_schedule(F, H, Cin, Cout):
         assert nws > 0                                                             # 784 tiles on 256 CUs: selected
 
 
-@pytest.mark.parametrize("F,H,W,Cin,Cout,widen", [(8, 64, 128, 64, 64, False), (3, 112, 112, 64, 64, False), (5, 48, 160, 64, 64, False),
-                                                  (4, 64, 64, 128, 128, True), (2, 112, 112, 64, 128, True), (9, 32, 32, 256, 64, True)])
-def test_conv_patch_kernel(F, H, W, Cin, Cout, widen, monkeypatch):
-    """(The NAFAE_* switches below are honoured by the EXPERIMENTS build only -- NAFAE_LIB=.../libnafae_hip_exp.so; with the
-    production library both arms run the production dispatch and the test reduces to kernel-vs-fp32-conv.)
-    2-D patch conv (conv3x3_patch_kernel; layers up to 128 channels by default, any eligible layer with NAFAE_CONV_PATCH=all)
-    against the raster-run kernels (same products, different summation order over the taps -> fp32 noise) and the fp32
-    conv; borders, image seams between frames, several tiles per workgroup, more workgroups than tiles."""
+def _exp_arm(kind, env, tmp_path, tag):
+    """One arm of a kernel A/B comparison: tests/exp_arm_worker.py in a child process against the EXPERIMENTS build of the
+    library (the production build ignores every NAFAE_* switch by design), with `env` selecting the dispatch."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "nafae_amd", "csrc", "libnafae_hip_exp.so")
+    if not os.path.exists(lib):
+        pytest.skip("experiments build missing: python -m nafae_amd.build --experiments")
+    out = str(tmp_path / ("%s_%s.pt" % (kind, tag)))
+    e = dict(os.environ, NAFAE_LIB=lib)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "exp_arm_worker.py"), kind, out], env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return torch.load(out)
+
+
+def test_conv_patch_kernel_vs_run_kernels(tmp_path):
+    """2-D patch conv (conv3x3_patch_kernel; layers up to 128 channels by default, any eligible layer with
+    NAFAE_CONV_PATCH=all) against the raster-run kernels (NAFAE_CONV_PATCH=0: same products, different summation order over
+    the taps -> fp32 noise) and the fp32 conv; borders, image seams between frames, several tiles per workgroup, more
+    workgroups than tiles.  The arms are separate processes on libnafae_hip_exp.so (tests/exp_arm_worker.py)."""
+    from tests.exp_arm_worker import PATCH_CASES, inputs
+    off = _exp_arm("patch", {"NAFAE_CONV_PATCH": "0"}, tmp_path, "off")
+    on = _exp_arm("patch", {"NAFAE_CONV_PATCH": "1"}, tmp_path, "on")
+    wide = _exp_arm("patch", {"NAFAE_CONV_PATCH": "all"}, tmp_path, "all")
+    differs = 0
+    for c in PATCH_CASES:
+        x, w, b = inputs(c, lambda c: c[0] * c[1] + c[2])
+        ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1).cpu()
+        scale = float(ref.abs().max())
+        for arm in (off, on, wide):
+            assert float((arm[c] - ref).abs().max()) <= 5e-5 * scale, c
+        assert float((wide[c] - off[c]).abs().max()) <= 2e-5 * scale, c
+        differs += int(not torch.equal(wide[c], off[c]))
+    assert differs >= 4          # the arms really ran different kernels (another summation order shows in the last bits)
+
+
+def test_conv_plain_bf16_pair_vs_plain_kernels(tmp_path):
+    """Plain bf16 (BASELINE config C3) through the 64-channel k-tile ("PAIR") form of the split kernels -- patch kernel,
+    run-reuse kernels and their stream-K schedule -- against the 32-channel plain kernels (NAFAE_BF16_PAIR=0: same bf16
+    products, other summation order) and the fp32 conv at bf16 tolerance.  Separate processes on libnafae_hip_exp.so."""
+    from tests.exp_arm_worker import PAIR_CASES, inputs
     from nafae_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(F * H + W)
-    x = torch.randn(F, H, W, Cin, device="cuda", generator=g)
-    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
-    b = torch.randn(Cout, device="cuda", generator=g)
-    xp, wp = ops.split_bf16(x, True, True), ops.split_bf16(w, True, True)
-    monkeypatch.setenv("NAFAE_CONV_PATCH", "0")
-    _, p0 = ops.conv3x3_bf16(xp, wp, b, relu=True)
-    monkeypatch.setenv("NAFAE_CONV_PATCH", "all" if widen else "1")
-    _, p1 = ops.conv3x3_bf16(xp, wp, b, relu=True)
-    _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True)
-    assert torch.equal(p1.hi, p2.hi)                                               # deterministic (hi | lo interleaved)
-    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1)
-    scale = float(ref.abs().max())
-    o0, o1 = ops.merge_bf16(p0), ops.merge_bf16(p1)
-    assert float((o1 - ref).abs().max()) <= 5e-5 * scale
-    assert float((o1 - o0).abs().max()) <= 2e-5 * scale
-    assert not torch.equal(o1, torch.zeros_like(o1))
+    a0 = _exp_arm("pair", {"NAFAE_BF16_PAIR": "0"}, tmp_path, "off")
+    a1 = _exp_arm("pair", {"NAFAE_BF16_PAIR": "1"}, tmp_path, "on")
+    differs = 0
+    for c in PAIR_CASES:
+        x, w, b = inputs(c, lambda c: c[0] + c[1] + c[3])
+        xr, wr = ops.merge_bf16(ops.split_bf16(x, False)), ops.merge_bf16(ops.split_bf16(w, False))   # the bf16-rounded operands
+        ref = torch.relu(torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1).cpu()
+        scale = float(ref.abs().max())
+        for arm in (a0, a1):
+            f, m1, m2 = arm[c]
+            assert float((f - ref).abs().max()) <= 2e-5 * scale, c          # fp32 accumulation of exact bf16 products
+            assert float((m1 - ref).abs().max()) <= 5e-3 * scale and float((m2 - ref).abs().max()) <= 5e-3 * scale, c
+        assert float((a1[c][0] - a0[c][0]).abs().max()) <= 2e-5 * scale, c
+        differs += int(not torch.equal(a1[c][0], a0[c][0]))
+    assert differs >= 4
 
 
 @pytest.mark.parametrize("F,H,W,Cin,Cout", [(8, 64, 128, 64, 64), (3, 112, 112, 64, 128), (4, 64, 64, 128, 128), (40, 56, 56, 128, 256),
-                                            (64, 28, 28, 256, 512), (6, 14, 14, 512, 512), (2, 20, 36, 64, 64)])
-def test_conv_plain_bf16_pair_mode(F, H, W, Cin, Cout, monkeypatch):
-    """(NAFAE_BF16_PAIR is honoured by the EXPERIMENTS build only; see test_conv_patch_kernel.)
-    Plain bf16 (BASELINE config C3) through the 64-channel k-tile ("PAIR") form of the split kernels -- patch kernel,
-    run-reuse kernels and their stream-K schedule -- against the 32-channel plain kernels (same bf16 products, other
-    summation order) and the fp32 conv at bf16 tolerance."""
+                                            (64, 28, 28, 256, 512), (6, 14, 14, 512, 512), (2, 20, 36, 64, 64), (4, 64, 64, 128, 32)])
+@pytest.mark.parametrize("split", [True, False])
+def test_conv_production_dispatch_vs_fp32_conv(F, H, W, Cin, Cout, split):
+    """The production library's own dispatch (patch / run-reuse / stream-K kernels as it picks them) for the VGG layer shapes
+    of the A/B tests above, against the fp32 conv on the rounded operands."""
     from nafae_amd import ops
     g = torch.Generator(device="cuda").manual_seed(F + H + Cin)
     x = torch.randn(F, H, W, Cin, device="cuda", generator=g)
     w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (1.0 / (9 * Cin)) ** 0.5
     b = torch.randn(Cout, device="cuda", generator=g)
-    xp, wp = ops.split_bf16(x, False), ops.split_bf16(w, False)
-    monkeypatch.setenv("NAFAE_BF16_PAIR", "0")
-    f0, p0 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)
-    monkeypatch.setenv("NAFAE_BF16_PAIR", "1")
-    f1, p1 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)      # fp32 + plane output: run kernels
-    _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True)                      # planes only: the patch kernel where eligible
-    xr, wr = ops.merge_bf16(xp), ops.merge_bf16(wp)                     # the bf16-rounded operands, exactly
+    xp, wp = ops.split_bf16(x, split, split), ops.split_bf16(w, split, split)
+    f1, p1 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)
+    _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True)
+    xr, wr = ops.merge_bf16(xp), ops.merge_bf16(wp)
     ref = torch.relu(torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1)
     scale = float(ref.abs().max())
-    assert float((f1 - ref).abs().max()) <= 2e-5 * scale               # fp32 accumulation of exact bf16 products
-    assert float((f1 - f0).abs().max()) <= 2e-5 * scale
+    assert float((f1 - ref).abs().max()) <= (5e-5 if split else 2e-5) * scale
     for p in (p1, p2):
-        assert p.lo is None and float((ops.merge_bf16(p) - ref).abs().max()) <= 5e-3 * scale   # one bf16 rounding of the output
+        assert float((ops.merge_bf16(p) - ref).abs().max()) <= (5e-5 if split else 5e-3) * scale
 
 
 @pytest.mark.parametrize("F,H,W,Cin,Cout,split", [(8, 64, 128, 64, 64, True), (3, 112, 112, 64, 128, True), (4, 64, 64, 128, 128, True),

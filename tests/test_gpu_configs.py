@@ -37,14 +37,22 @@ def relerr(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
 
 
-@pytest.fixture(scope="module")
-def c2():
+_CONFIG_CACHE = {}
+
+
+def load_config(name):
+    """Model + seeded batch + oracle fixture of one BASELINE config at size (cached: the 4096 x 25088 fc6 weight alone takes
+    seconds to draw).  Only one config's model is kept alive."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if name in _CONFIG_CACHE:
+        return _CONFIG_CACHE[name]
+    _CONFIG_CACHE.clear()
+    torch.cuda.empty_cache()
     from nafae_amd.config import cfg, cfg_from_file, reset_cfg
     from nafae_amd.model import default_args
     from nafae_amd.train import make_batch, setup_training
-    g = np.load(os.path.join(G, "config_c2.npz"))
+    g = np.load(os.path.join(G, "config_%s.npz" % name))
     Na, Ns, Nb, Ne = [int(x) for x in g["shape"]]
     reset_cfg()
     cfg_from_file(os.path.join(ROOT, "cfgs", "vgg16.yml"))
@@ -54,7 +62,9 @@ def c2():
     model, opt, crit, reducer = setup_training(args, device="cuda", seed=int(g["seed"]))
     batch = make_batch(Na, Ns, Ne, seed=int(g["seed"]), device="cuda")
     assert batch.entities_length == g["lens"].tolist()
-    return dict(g=g, cfg=cfg, args=args, model=model, opt=opt, crit=crit, reducer=reducer, batch=batch, dims=(Na, Ns, Nb, Ne))
+    _CONFIG_CACHE[name] = dict(g=g, cfg=cfg, args=args, model=model, opt=opt, crit=crit, reducer=reducer, batch=batch,
+                               dims=(Na, Ns, Nb, Ne))
+    return _CONFIG_CACHE[name]
 
 
 # precision: (base_feat / fc7 / V tolerance relative to tensor scale, min identical-ROI fraction, loss tolerance,
@@ -71,14 +81,24 @@ C2_BARS = {
     # coordinates by more than 0.02 px and flips NMS decisions, so index-wise comparison is meaningless): the share of oracle
     # proposals that have a HIP proposal with IoU >= 0.9 in the same frame, and the share of live (frame, query) pairs whose
     # grounded box overlaps the oracle's grounded box with IoU >= 0.5.
-    "bf16": dict(feat=3e-2, rois=None, loss=2e-2, dind=None, grad=None, ground=None, roi_iou=0.5, ground_iou=0.3),
+    # Measured (rounds 2 and 3): 0.9825 of the oracle's proposals matched, 0.9507 of the grounded boxes at IoU >= 0.5; the bars
+    # sit a few points below that, so a regression that halves the agreement fails.
+    "bf16": dict(feat=3e-2, rois=None, loss=2e-2, dind=None, grad=None, ground=None, roi_iou=0.95, ground_iou=0.90),
 }
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
-def test_c2_full_size_detector_and_grounding(c2, precision, capsys):
-    """C2 (f32, bf16x3) / C3 (bf16) at 64 frames x 128 proposals x 16 query slots, end to end, vs the oracle fixture."""
+FULL_CASES = [("c2", "f32"), ("c2", "bf16x3"), ("c2", "bf16"),       # C2 and (bf16) C3: 128 proposals, 16 query slots
+              ("c4", "f32"), ("c4", "bf16x3"),                       # C4 per-GPU share: 256 proposals, 32 query slots
+              ("c5", "f32"), ("c5", "bf16x3")]                       # C5: 300 proposals, 64 query slots
+
+
+@pytest.mark.parametrize("name,precision", FULL_CASES, ids=["%s-%s" % c for c in FULL_CASES])
+def test_full_size_detector_and_grounding(name, precision, capsys):
+    """Every BASELINE config at 64 frames -- C2 (f32, bf16x3) / C3 (bf16) with 128 proposals x 16 query slots, C4's per-GPU
+    share (256 x 32: ROI-Align of 16 384 ROIs, fc6 at M = 16 384, top-N 256 after NMS) and C5 (300 x 64: 19 200 ROIs) -- end
+    to end (detector, embeddings, DVSA, backward) against the oracle fixture of that config."""
     from nafae_amd import ops
+    c2 = load_config(name)
     g, model, batch = c2["g"], c2["model"], c2["batch"]
     Na, Ns, Nb, Ne = c2["dims"]
     bars = C2_BARS[precision]
@@ -135,7 +155,7 @@ def test_c2_full_size_detector_and_grounding(c2, precision, capsys):
     giou = np.array([box_iou(gb_hip[k:k + 1], gb_ora[k:k + 1])[0, 0] for k in range(len(fi))])
     ground_same, ground_half = float((giou >= 0.999).mean()), float((giou >= 0.5).mean())
     with capsys.disabled():
-        print("\n[C2 %-6s] base_feat %.2e | identical rois %.4f (%d/%d), frames with all %d rois identical %d/%d | fc7 %.2e | V %.2e W %.2e"
+        print("\n[" + name.upper() + " %-6s] base_feat %.2e | identical rois %.4f (%d/%d), frames with all %d rois identical %d/%d | fc7 %.2e | V %.2e W %.2e"
               " | D_ind agree %.5f on %d decided entries (%d near-ties excluded) | D_sim %.2e | loss %.6f vs %.6f (rel %.1e)"
               " | oracle rois matched at IoU>=0.9: %.4f | grounded box identical %.4f, IoU>=0.5 %.4f (%d live pairs)"
               % (precision, e_base, same.mean(), same.sum(), same.size, Nb, frame_ok.sum(), F, e_fc7, e_V, e_W, dind_rate, n_cmp,
@@ -164,6 +184,68 @@ def test_c2_full_size_detector_and_grounding(c2, precision, capsys):
         gw = ve.fc1.weight.grad
         assert relerr(gw[:8].cpu(), g["g_ve_w_rows"]) < bars["grad"] * max(1.0, np.abs(gw.cpu().numpy()).max() / max(np.abs(g["g_ve_w_rows"]).max(), 1e-30))
         assert abs(float(gw.double().norm()) - float(g["g_ve_w_norm"])) < bars["grad"] * float(g["g_ve_w_norm"])
+
+
+@pytest.mark.parametrize("name", ["c4", "c5"])
+def test_full_step_at_size_properties(name, capsys):
+    """C4's per-GPU share and C5 as FULL TRAINING STEPS on one GPU (what `bench.py --gpus 8` runs per rank): two pipelined
+    steps (detector of step k+1 overlapping the tail of step k), then the size-independent properties: every frame keeps
+    exactly top-N proposals whose rows are inside the frame and sorted by score, padding rows are zero, the loss is finite
+    and positive, the step is bit-reproducible (same inputs, same state -> identical rois / fc7 / D_ind / loss / gradients),
+    and the optimiser moved exactly the parameters that own gradients."""
+    from nafae_amd.train import PipelinedTrainer, detector_forward
+    c = load_config(name)
+    model, batch, reducer, opt, crit, args = c["model"], c["batch"], c["reducer"], c["opt"], c["crit"], c["args"]
+    Na, Ns, Nb, Ne = c["dims"]
+    F, Q = Na * Ns, Na * Ne
+    c["cfg"].TEST.RPN_POST_NMS_TOP_N = Nb
+    fr = model.fasterRCNN
+    fr.precision = "f32"
+    model.train(); model.DVSA.init_train(); fr.eval()
+
+    def fwd_bwd():
+        rois, roi_scores, _, fc7 = detector_forward(model, batch)
+        reducer.zero_grad()
+        V = model.vis_ebd(fc7)
+        W = model.word_ebd(batch.glove_feats)
+        D_ind, D_sim, L = model.DVSA(V, W, batch.entities_length)
+        L.backward()
+        return rois, roi_scores, fc7, D_ind, D_sim, L.detach().clone(), reducer.flat.clone(), fr.n_keep.clone()
+
+    a = fwd_bwd()
+    b = fwd_bwd()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    rois, roi_scores, fc7, D_ind, D_sim, L, grad, n_keep = a
+    assert tuple(rois.shape) == (F, Nb, 5) and tuple(fc7.shape) == (F * Nb, 4096) and tuple(D_ind.shape) == (F, Q)
+    nk = n_keep.cpu().numpy()
+    assert ((nk >= 1) & (nk <= Nb)).all()
+    r = rois.cpu().numpy(); sc = roi_scores.cpu().numpy()
+    for f in range(F):
+        k = nk[f]
+        assert (r[f, :, 0] == f).all()                                  # column 0 = frame index on every row (proposal_layer.py:153-163)
+        assert (r[f, :k, 1] >= 0).all() and (r[f, :k, 3] <= 223).all() and (r[f, :k, 2] >= 0).all() and (r[f, :k, 4] <= 223).all()
+        assert (np.diff(sc[f, :k]) <= 0).all()                          # kept in descending score order
+        assert (r[f, k:, 1:] == 0).all() and (sc[f, k:] == 0).all()     # rows beyond n_keep stay zero
+    assert torch.isfinite(fc7).all() and torch.isfinite(D_sim).all() and torch.isfinite(grad).all()
+    assert float(L) > 0 and np.isfinite(float(L))
+    Di = D_ind.cpu().numpy()
+    assert (Di >= 0).all() and (Di < Nb).all()
+    # two real optimiser steps through the pipelined trainer
+    p0 = torch.cat([p.detach().reshape(-1) for p in reducer.params])
+    pipe = PipelinedTrainer(model, opt, crit, args, reducer)
+    pipe.submit(batch)
+    l1 = pipe.step(batch)[0]
+    l2 = pipe.step(None)[0]
+    torch.cuda.synchronize()
+    p1 = torch.cat([p.detach().reshape(-1) for p in reducer.params])
+    assert np.isfinite(float(l1)) and np.isfinite(float(l2))
+    assert abs(float(l1) - float(L)) <= 1e-6 * abs(float(L))           # first pipelined step = the forward above
+    assert not torch.equal(p0.reshape(-1), p1)
+    with capsys.disabled():
+        print("\n[%s full step] kept %d..%d of %d proposals/frame | loss %.6f -> %.6f after one Adam step | |grad| %.4e"
+              % (name.upper(), nk.min(), nk.max(), Nb, float(l1), float(l2), float(grad.norm())))
+    _CONFIG_CACHE.clear()        # the optimiser moved the parameters: the cached model no longer matches the fixture
 
 
 SIM_CONFIGS = {

@@ -104,7 +104,7 @@ def test_detector_matches_reference_golden(gpu, precision):
     assert tuple(pooled.shape) == (16, 512, 7, 7) and tuple(fc7.shape) == (16, 4096)
     # box coordinates are fp32 values downstream of 14 conv layers: "same proposal" = within 0.02 px (1e-4 of 224)
     same = (np.abs(rois.cpu().numpy() - g["rois"]) < 0.02).all(-1).reshape(-1)
-    assert same.mean() >= 0.9, "rois differ from the reference: %s" % same
+    assert same.sum() >= same.size - 1, "rois differ from the reference: %s" % same     # measured: all identical; one near-tie flip tolerated
     assert np.allclose(roi_scores.cpu().numpy().reshape(-1)[same], g["roi_scores"].reshape(-1)[same], rtol=1e-5)
     assert relerr(pooled.cpu().numpy()[same][:, ::37], g["pooled_sub"][same]) < TOL
     assert relerr(fc7.cpu().numpy()[same], g["fc7"][same]) < TOL
@@ -114,7 +114,7 @@ def test_detector_matches_reference_golden(gpu, precision):
     prob, deltas = OD.rpn_head(base.permute(0, 3, 1, 2).cpu().contiguous(), rp)
     s, props = OD.decode_proposals(prob, deltas, im_info, 16, [4, 8, 16, 32], [0.5, 1, 2])
     r_o, rs_o, _ = OD.select_proposals(s, props, OD.sort_desc(s), 6000, int(g["post_nms_topN"]), 0.7)
-    assert ((rois.cpu() - r_o).abs().max(-1)[0] < 1e-3).float().mean() >= 0.9
+    assert ((rois.cpu() - r_o).abs().max(-1)[0] < 1e-3).all()      # identical base_feat in, identical proposals out
     # ROI-Align + head fed with the HIP rois
     pooled_o = OD.roi_align_avg(base.permute(0, 3, 1, 2).cpu().contiguous(), rois.cpu().view(-1, 5))
     assert relerr(pooled.cpu(), pooled_o) < 2e-5
@@ -137,7 +137,7 @@ def test_detector_config_c1_against_oracle(gpu, precision):
                 RPN_POST_NMS_TOP_N=32, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
     r_o, s_o, pooled_o, fc7_o = OD.detector_forward(im, im_info, sd, ocfg)
     same = ((rois.cpu() - r_o).abs() < 0.02).all(-1).view(-1).numpy()
-    assert same.mean() >= 0.9, same.mean()
+    assert same.sum() >= same.size - 1, same.mean()        # measured: all identical; one near-tie flip tolerated
     assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < TOL
     assert (fr.n_keep.cpu() <= 32).all()
 
@@ -160,7 +160,7 @@ def test_detector_other_frame_sizes_against_oracle(gpu, precision, F, H, W):
                 RPN_POST_NMS_TOP_N=16, RPN_NMS_THRESH=0.7, POOLING_SIZE=7)
     r_o, s_o, pooled_o, fc7_o = OD.detector_forward(im, im_info, sd, ocfg)
     same = ((rois.cpu() - r_o).abs() < 0.02).all(-1).view(-1).numpy()
-    assert same.mean() >= 0.9, same.mean()
+    assert same.sum() >= same.size - 1, same.mean()        # measured: all identical; one near-tie flip tolerated
     assert relerr(fc7.cpu().numpy()[same], fc7_o.numpy()[same]) < TOL
 
 

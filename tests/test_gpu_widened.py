@@ -73,7 +73,10 @@ def test_ground_checkpoint_roundtrip_with_optimizer_state(gpu, tmp_path):
     ck = torch.load(path, map_location='cpu')
     assert set(ck.keys()) == {'session', 'epoch', 'model', 'optimizer', 'pooling_mode'}
     assert len(ck['optimizer']['state']) == len(red.params) and ck['optimizer']['param_groups'][0]['lr'] == args.lr
-    assert float(ck['optimizer']['state'][0]['exp_avg'].abs().max()) > 0
+    # the reference's index space (model.py:1077-1082): three groups DVSA (10 parameters, never stepped: no state), word_ebd, vis_ebd
+    assert [len(g['params']) for g in ck['optimizer']['param_groups']] == [10, 4, 2]
+    assert sorted(ck['optimizer']['state'].keys()) == [10, 11, 12, 13, 14, 15]
+    assert float(ck['optimizer']['state'][10]['exp_avg'].abs().max()) > 0
     train_step(model, opt, crit, b2, args, red)
     want = {k: v.clone() for k, v in model.state_dict().items()}
     # "new process": different seed, then load
@@ -90,6 +93,45 @@ def test_ground_checkpoint_roundtrip_with_optimizer_state(gpu, tmp_path):
     load_ground_checkpoint(model3, path, resume=True)
     train_step(model3, opt3, crit3, b2, args, red3)
     assert not torch.equal(model3.state_dict()['vis_ebd.fc1.weight'], want['vis_ebd.fc1.weight'])
+
+
+def test_reference_optimizer_state_lands_on_the_right_parameters(gpu):
+    """The 'optimizer' entry of a REFERENCE checkpoint is the state_dict of torch.optim.Adam over the three param groups
+    DVSA, word_ebd, vis_ebd (model.py:1077-1082, :1118-1124).  Loading it must put every moment tensor on the parameter it
+    belongs to although FusedClipAdam's flat buffer keeps vis_ebd first -- four of the six trainable tensors are [512]
+    vectors, so a swap would not even raise -- and a state of the wrong shape must raise."""
+    import copy
+    from nafae_amd.model import default_args
+    from nafae_amd.train import setup_training
+    args = default_args(batch_size=2, sample_num=3, max_ent_len=4, dropout_rate=0.0)
+    model, opt, crit, red = setup_training(args, seed=5)
+    ref = copy.deepcopy(model)
+    ropt = torch.optim.Adam([{'params': ref.DVSA.parameters()}, {'params': ref.word_ebd.parameters()},
+                             {'params': ref.vis_ebd.parameters()}], lr=args.lr, weight_decay=args.weight_decay)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for m in (ref.word_ebd, ref.vis_ebd):
+        for p in m.parameters():
+            p.grad = torch.randn(p.shape, device="cuda", generator=g)
+    ropt.step()
+    sd = ropt.state_dict()
+    assert sorted(sd['state'].keys()) == [10, 11, 12, 13, 14, 15]
+    opt.load_state_dict(sd)
+    assert opt.step_count == 1
+    names = {id(p): n for n, p in model.named_parameters()}
+    ref_state = {n: ropt.state[p] for n, p in ref.named_parameters() if p in ropt.state}
+    o = 0
+    for p in red.params:
+        k, n = p.numel(), names[id(p)]
+        assert torch.equal(opt.exp_avg[o:o + k].view_as(p), ref_state[n]['exp_avg']), n
+        assert torch.equal(opt.exp_avg_sq[o:o + k].view_as(p), ref_state[n]['exp_avg_sq']), n
+        o += k
+    back = opt.state_dict()
+    for i in sd['state']:
+        assert torch.equal(back['state'][i]['exp_avg'], sd['state'][i]['exp_avg'])
+    bad = copy.deepcopy(sd)
+    bad['state'][14], bad['state'][10] = bad['state'][10], bad['state'][14]        # vis_ebd.fc1.weight <-> word_ebd.fc1.weight
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
 
 
 def test_stepRCNN_stream_vs_oracle_and_unbounded_chunk(gpu):
