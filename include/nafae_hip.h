@@ -102,6 +102,10 @@ int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, in
  * Used with nafae_nonzero_rows: the gradient wrt the visual embedding is exactly zero on >= 85 % of its rows.  */
 int nafae_gemm_tn_rows(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N,
                        const int32_t *rows, const int32_t *count, int max_rows, float alpha, void *stream);
+/* The same with C += ... when accumulate != 0 (a parameter's .grad buffer: autograd's separate accumulation launch goes away).  */
+int nafae_gemm_tn_rows_acc(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N,
+                           const int32_t *rows, const int32_t *count, int max_rows, float alpha, int accumulate,
+                           void *stream);
 /* idx_out[0 .. *count_out) = ascending indices of the rows of x [rows, cols] that hold a non-zero; flag_ws: int32[rows].  */
 int nafae_nonzero_rows(const float *x, int rows, int cols, int32_t *flag_ws, int32_t *idx_out, int32_t *count_out,
                        void *stream);
@@ -318,8 +322,18 @@ int nafae_batchnorm_fwd(const float *x, const float *weight, const float *bias, 
 int nafae_batchnorm_bwd(const float *g_y, const float *x, const float *weight, const float *save_mean,
                         const float *save_invstd, float *g_x, float *g_weight, float *g_bias, int Q, int D,
                         void *stream);
+/* The same with g_weight / g_bias accumulated into (+=) when accumulate != 0.  */
+int nafae_batchnorm_bwd_acc(const float *g_y, const float *x, const float *weight, const float *save_mean,
+                            const float *save_invstd, float *g_x, float *g_weight, float *g_bias, int Q, int D,
+                            int accumulate, void *stream);
 /* out[j] = sum_i x[i, j]  (bias gradients).  */
 int nafae_colsum(const float *x, float *out, int rows, int cols, void *stream);
+/* out[j] (+)= sum_i x[i, j] (accumulate != 0: +=).  */
+int nafae_colsum_acc(const float *x, float *out, int rows, int cols, int accumulate, void *stream);
+/* out[j] (+)= sum over the listed rows idx[0 .. *count) of x[idx[r], j]; idx int32 [max_rows] and count int32 [1] live on the device
+ * (nafae_nonzero_rows' outputs): the bias gradient of VisEbd.fc1 over the rows that carry any gradient.  */
+int nafae_colsum_rows(const float *x, const int32_t *idx, const int32_t *count, int max_rows, int cols, float *out,
+                      int accumulate, void *stream);
 
 /* One optimiser step over a flat fp32 buffer = torch.nn.utils.clip_grad_norm_(params, max_norm) followed by
  * torch.optim.Adam(lr, betas, eps, weight_decay).step()  (model.py:773-774, :1077-1082), `step` = 1, 2, ...

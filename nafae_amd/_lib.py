@@ -26,6 +26,7 @@ SIGNATURES = {
     "nafae_gemm_nt": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_float, c_int, P]),
     "nafae_gemm_tn": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "nafae_gemm_tn_rows": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_float, P]),
+    "nafae_gemm_tn_rows_acc": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_float, c_int, P]),
     "nafae_nonzero_rows": (c_int, [P, c_int, c_int, P, P, P, P]),
     "nafae_conv1_3x3_relu": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "nafae_conv3x3_relu": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -64,7 +65,10 @@ SIGNATURES = {
     "nafae_dropout_tanh_bwd_seeded": (c_int, [P, P, ctypes.c_uint64, c_float, P, c_int64, P]),
     "nafae_batchnorm_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "nafae_batchnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "nafae_batchnorm_bwd_acc": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "nafae_colsum": (c_int, [P, P, c_int, c_int, P]),
+    "nafae_colsum_acc": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "nafae_colsum_rows": (c_int, [P, P, P, c_int, c_int, P, c_int, P]),
     "nafae_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int, P, P, P]),
 }
 

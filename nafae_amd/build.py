@@ -23,10 +23,11 @@ SOURCES = [
     ("proposal.hip", ["-ffp-contract=off"]),
     ("simloss.hip", []),
     ("simmax.hip", []),
+    ("simfused.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "--offload-arch=" + ARCH, "-fhip-fp32-correctly-rounded-divide-sqrt", "-std=c++17",
           "-Wall", "-Wno-unused-function"]
-DEPS = ["mfma_tile.h", "bf16_tile.h", "hip_util.h", os.path.join(ROOT, "include", "nafae_hip.h")]
+DEPS = ["mfma_tile.h", "bf16_tile.h", "hip_util.h", "sim_common.h", os.path.join(ROOT, "include", "nafae_hip.h")]
 
 
 def _hipcc():

@@ -838,11 +838,16 @@ int nafae_gemm_tn(const float *A, int lda, const float *B, int ldb, float *C, in
   return gemm_tn_dispatch(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, nullptr, nullptr, S(stream));
 }
 
-int nafae_gemm_tn_rows(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, const int32_t *rows,
-                       const int32_t *count, int max_rows, float alpha, void *stream) {
+int nafae_gemm_tn_rows_acc(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, const int32_t *rows,
+                           const int32_t *count, int max_rows, float alpha, int accumulate, void *stream) {
   if (!A || !B || !C || !rows || !count || M <= 0 || N <= 0 || max_rows <= 0) return NAFAE_EINVAL;
   if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
-  return gemm_tn_dispatch(A, lda, B, ldb, C, ldc, M, N, max_rows, alpha, 0, rows, count, S(stream));
+  return gemm_tn_dispatch(A, lda, B, ldb, C, ldc, M, N, max_rows, alpha, accumulate, rows, count, S(stream));
+}
+
+int nafae_gemm_tn_rows(const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, const int32_t *rows,
+                       const int32_t *count, int max_rows, float alpha, void *stream) {
+  return nafae_gemm_tn_rows_acc(A, lda, B, ldb, C, ldc, M, N, rows, count, max_rows, alpha, 0, stream);
 }
 
 int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias, float *out_nhwc, int F, int H,

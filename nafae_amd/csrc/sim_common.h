@@ -1,0 +1,102 @@
+// sim_common.h -- pieces shared by the similarity kernels (simmax.hip, simfused.hip): live-column bookkeeping, the
+// arg-max ordering, the fp32 -> bf16 hi/lo split.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace nafae_sim {
+
+constexpr int NA_MAX = 2048;   // segments per batch the live-column prefix table holds (LDS)
+
+// (value desc, index asc): the order torch.max(dim) resolves ties in (first maximal index)
+__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+// The same with torch.max's NaN rule: a NaN is the maximum (the first one wins).  For the exact-fp32 decisions.
+__device__ __forceinline__ bool better_nan(float va, int ia, float vb, int ib) {
+  const bool na = va != va, nb = vb != vb;
+  if (na || nb) return na && (!nb || ia < ib);
+  return va > vb || (va == vb && ia < ib);
+}
+
+// exclusive prefix of the clamped entity counts into LDS (prefix[Na] = number of live columns); wave 0 works, caller syncs
+__device__ __forceinline__ void build_prefix(const int32_t *__restrict__ ent_len, int Na, int Ne, int *prefix) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < Na; base += 64) {
+      const int a = base + lane;
+      int x = 0;
+      if (a < Na) {
+        const int l = ent_len[a];
+        x = l < 0 ? 0 : (l > Ne ? Ne : l);
+      }
+      int incl = x;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (a < Na) prefix[a] = carry + incl - x;
+      carry += __shfl(incl, 63);
+    }
+    if (lane == 0) prefix[Na] = carry;
+  }
+}
+
+// segment a with prefix[a] <= c < prefix[a+1]  (c < prefix[Na])
+__device__ __forceinline__ int find_seg(const int *prefix, int Na, int c) {
+  int lo = 0, hi = Na;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= c) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+    hi[e] = h0;
+    hi[4 + e] = h1;
+    lo[e] = (__bf16)(x0[e] - (float)h0);
+    lo[4 + e] = (__bf16)(x1[e] - (float)h1);
+  }
+}
+
+__device__ __forceinline__ void split4(const f32x4 x, bf16x4 &hi, bf16x4 &lo) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const __bf16 h = (__bf16)x[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(x[e] - (float)h);
+  }
+}
+
+// exact fp32 dot product of two D-float rows by one wave (D % 4 == 0, D <= 1024): lane l takes the float4s at l*4 + 256*t, a
+// 4-FMA chain per piece, then a fixed xor tree.  `wf` = this lane's pieces of the query row (loaded once per column).
+template <int MAXT>
+__device__ __forceinline__ float wave_dot(const float *__restrict__ vrow, const f32x4 (&wf)[MAXT], int D, int lane) {
+  float acc = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) {
+    const int d = lane * 4 + 256 * t;
+    if (d < D) {
+      const f32x4 x = *reinterpret_cast<const f32x4 *>(vrow + d);
+      acc = fmaf(x[0], wf[t][0], acc);
+      acc = fmaf(x[1], wf[t][1], acc);
+      acc = fmaf(x[2], wf[t][2], acc);
+      acc = fmaf(x[3], wf[t][3], acc);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  return acc;
+}
+
+}  // namespace nafae_sim

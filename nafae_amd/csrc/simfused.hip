@@ -1,0 +1,832 @@
+// simfused.hip -- region x query similarity reduced to per-frame max / arg-max (DVSA.forward, reference model.py:548-551,
+// 580-583, 610-612), third generation, gfx950.  Two kernels that replace simmax.hip's part / tile + finish pairs where they apply
+// (simmax.hip's make_plan routes; its kernels stay as the fallback for the shapes these do not take):
+//
+//   sim_few_kernel (+ sim_few_merge_kernel)   L <= 32 live query slots -- every BASELINE configuration with entity lengths from the
+//       data set's histogram (C2: 19 of 128 slots live, C5: 17 of 512).  The problem is then a pure stream of V (C5: 39 MB
+//       against 0.7 GFLOP), so the kernel has no filter and no second pass over V at all: every (proposal, live query) score is
+//       an EXACT fp32 FMA dot product on the vector ALU while the rows stream through registers -- each wave owns 16 rows (two
+//       octets; a load instruction covers 8 rows x one full 128-B line), W (live rows only) sits in LDS as fp32 in a
+//       conflict-free [chunk][slot][column] image, one ds_read_b128 of W feeds 8 FMAs.  A workgroup owns 64 consecutive rows of
+//       ONE frame and leaves its per-column (max, arg-max) in the workspace; the merge kernel takes the best of a frame's
+//       workgroups (ties -> smaller index, NaN -> first NaN: torch.max's rules) and zero-fills the masked slots.
+//       All of V is requested within the first microsecond (320 workgroups x 4 waves x 32 KB in flight at C5).
+//
+//   sim_frame_kernel<RW, CW>   L > 32 (C5 with every slot live: 512 columns).  One workgroup = (frame, group of 64*CW live
+//       columns): it streams ALL rows of its frame, so the per-frame max, the exact-fp32 re-evaluation of the winner and the
+//       output happen inside the kernel -- no partials, no finish launch, no second pass over V from HBM (round 2: finish kernel
+//       21 us re-gathering 2 x 35 MB).  Operands are staged global -> registers -> LDS: every thread converts the fp32 it
+//       loaded into bf16 hi/lo ONCE and writes the planes in MFMA-fragment order (XOR-swizzled 128-B rows, conflict-free
+//       ds_read_b128), so the k-loop has no LDS-DMA issue cost, no per-wave re-split of shared fragments and no W pre-pass
+//       (round 2: sim_wprep 5 us).  4 waves (one per SIMD) = 2 row halves x 2 column halves, a wave holds RW x CW 32x32
+//       accumulator tiles (RW = 5, CW = 2: 14 fragment reads per 30 MFMAs).  bf16x3 = hi*hi + hi*lo + lo*hi FILTERS: per column
+//       the kernel keeps the top-2 (value, row) and the third-best value of each contributor; the winner and every listed
+//       runner-up within `margin` of it are re-evaluated with exact fp32 dot products; if an unlisted row could lie within the
+//       margin (third-best value too close), or a NaN was seen, the column takes the slow path: exact fp32 over all rows.
+//       margin = 2^-14 * D * max|V_frame| * max|W_group| + 2^-11 * |score| -- the maxima are measured while staging, so the
+//       bound holds for ANY embeddings, not only tanh outputs (round 2 assumed |V|, |W| <= 1).
+//
+// Algorithmic bytes: 4*D*(R+Q) + 12*F*Q.  No atomics; every reduction runs in a fixed order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "hip_util.h"
+#include "sim_common.h"
+
+using namespace nafae;
+using namespace nafae_sim;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------- few live columns
+constexpr int FEW_MAXL = 32;    // live columns the kernel takes (accumulators: 2 rows x FEW_MAXL per lane)
+constexpr int FEW_ROWS = 64;    // rows per workgroup: 4 waves x 2 octets x 8 rows
+constexpr int FEW_NCH = 16;     // 32-k chunks (D <= 512)
+constexpr int FEW_WIN = 8;      // chunks per octet held in registers
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 8 lanes 8k .. 8k+7; every lane ends with the same bits (fixed tree; + is commutative)
+__device__ __forceinline__ float sum8(float x) {
+  x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141>(x);   // row_half_mirror: lane i <-> 7 - i of its 8
+  return x;
+}
+
+__device__ __forceinline__ float dot4(const f32x4 x, const f32x4 w, float acc) {
+  acc = fmaf(x[0], w[0], acc);
+  acc = fmaf(x[1], w[1], acc);
+  acc = fmaf(x[2], w[2], acc);
+  acc = fmaf(x[3], w[3], acc);
+  return acc;
+}
+
+struct FewLds {
+  int wimg, wbest, scr, qmap, prefix, total;
+};
+__host__ __device__ inline FewLds few_lds(int D, int L, int Na) {
+  FewLds o;
+  const int Lp = L | 1;
+  o.wimg = 0;
+  int p = D * Lp * 4 + Lp * 16 + 64;        // [D/32][8][Lp] float4, then Lp zero float4s (the W "row" of a chunk beyond D)
+  o.wbest = p;  p += 4 * FEW_MAXL * 8;      // [wave][column] (value, row)
+  o.scr = p;    p += 4 * 16 * FEW_MAXL * 4; // [wave][row of the wave][column] transposition scratch
+  o.qmap = p;   p += FEW_MAXL * 4;
+  o.prefix = p; p += ((Na + 1) * 4 + 15) & ~15;
+  o.total = p;
+  return o;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// grid F * S workgroups of 256 threads; workgroup (f, s) owns rows [s*64, s*64+64) of frame f.  parts[(f*S + s)*32 + j] =
+// (best value, row as int bits) of live column j over those rows.  LT = live columns rounded up to a multiple of 4 (compile
+// time: the accumulators are registers and the body has no branch; columns L .. LT-1 run on zero-filled W).
+template <int LT>
+__global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
+                                                         const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
+                                                         int D, int S, int Lh, float2 *__restrict__ parts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const FewLds lo = few_lds(D, LT, Na);
+  f32x4 *wimg = reinterpret_cast<f32x4 *>(smem + lo.wimg);
+  float2 *wbest = reinterpret_cast<float2 *>(smem + lo.wbest);
+  float *scr = reinterpret_cast<float *>(smem + lo.scr);
+  int *qmap = reinterpret_cast<int *>(smem + lo.qmap);
+  int *prefix = reinterpret_cast<int *>(smem + lo.prefix);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.x / S, s = blockIdx.x - f * S;
+  const int nch = D >> 5;
+  const int sl = lane & 7, rg = lane >> 3;     // 16-B slot of the 128-B line, row of the octet
+  constexpr int Lp = LT | 1;                   // odd column pitch: the 8 slots of a ds_read_b128 group fall on distinct banks
+
+  // ---- V: this wave's two octets.  A rolling window of FEW_WIN chunks per octet lives in registers (2 x 8 x 16 B per lane =
+  // 16 KB in flight per wave, 128 KB per CU); the loads of octet 0 go out before anything else.
+  const int row0 = s * FEW_ROWS + wave * 16 + rg, row1 = row0 + 8;
+  const bool oct0 = s * FEW_ROWS + wave * 16 < Nb, oct1 = s * FEW_ROWS + wave * 16 + 8 < Nb;   // wave-uniform
+  const float *v0 = V + ((size_t)f * Nb + (row0 < Nb ? row0 : Nb - 1)) * D + sl * 4;
+  const float *v1 = V + ((size_t)f * Nb + (row1 < Nb ? row1 : Nb - 1)) * D + sl * 4;
+  // The loop body has NO branch: an octet beyond the frame reads the frame's last row (its rows are dropped by the row < Nb
+  // test at the end), a chunk beyond D re-reads the last chunk and meets a zero W row.
+  (void)oct0; (void)oct1;
+  f32x4 x0[FEW_WIN], x1[FEW_WIN];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < FEW_WIN; c++) x0[c] = *reinterpret_cast<const f32x4 *>(v0 + (c < nch ? c : nch - 1) * 32);
+#pragma unroll
+  for (int c = 0; c < FEW_WIN; c++) x1[c] = *reinterpret_cast<const f32x4 *>(v1 + (c < nch ? c : nch - 1) * 32);
+  // (both windows are requested before anything else: the W staging below waits for its own loads with vmcnt, which retires
+  // in order -- with octet 1 requested behind it the kernel paid two HBM round trips back to back before the first FMA)
+
+  build_prefix(ent_len, Na, Ne, prefix);
+  __syncthreads();
+  const int Ql = prefix[Na];
+  int L = Ql < Lh ? Ql : Lh;                   // (columns beyond the caller's bound are reported as NaN by the merge kernel)
+  L = L < LT ? L : LT;
+  if (tid < FEW_MAXL) {
+    int q = -1;
+    if (tid < L) {
+      const int a = find_seg(prefix, Na, tid);
+      q = a * Ne + (tid - prefix[a]);
+    }
+    qmap[tid] = q;
+  }
+  __syncthreads();
+  // ---- W (live rows; zeros for the columns L .. LT-1) -> LDS as fp32, image [chunk][slot][column]
+  {
+    const int k4n = D >> 2;
+    const int total = LT * k4n;
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+      f32x4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = i0 + 256 * u;
+        const int j = idx / k4n, k4 = idx - j * k4n;
+        w[u] = (idx < total && j < L) ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)qmap[j] * D + k4 * 4) : z4;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = i0 + 256 * u;
+        const int j = idx / k4n, k4 = idx - j * k4n;
+        if (idx < total) wimg[(size_t)k4 * Lp + j] = w[u];      // k4 = chunk * 8 + slot
+      }
+    }
+    if (tid < Lp) wimg[(size_t)(D >> 2) * Lp + tid] = z4;       // the zero row
+  }
+  __syncthreads();
+
+  // ---- exact fp32 scores: a[o][j] = (even-k, odd-k) partial sums of this lane's k-slots of row o against live column j; two
+  // packed FMAs per (row, column, 16 B)
+  f32x2 a0[LT], a1[LT];
+#pragma unroll
+  for (int j = 0; j < LT; j++) {
+    a0[j] = f32x2{0.f, 0.f};
+    a1[j] = f32x2{0.f, 0.f};
+  }
+  // Steps of 4 columns; the W reads of step t + 1 are issued before the FMAs of step t and a scheduling fence closes every
+  // step (unfenced, hipcc hoisted the LDS reads of a whole 8-chunk window above the arithmetic and spilled them).
+  // The two windows are unrolled (as a loop, the refilled registers were copied into place at the back edge -- behind a
+  // vmcnt(0) that drained the loads the next window needs).
+  constexpr int NG = LT / 4;
+#pragma unroll
+  for (int c0 = 0; c0 < FEW_NCH; c0 += FEW_WIN) {
+    if (c0 >= nch) break;
+    auto wptr = [&](int u) {
+      const int c = c0 + u;
+      return wimg + (size_t)(c < nch ? c * 8 + sl : nch * 8) * Lp;   // (a chunk beyond D: the zero row)
+    };
+    f32x4 wc[4], wn[4];
+    {
+      const f32x4 *wp = wptr(0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) wc[k] = wp[k];
+    }
+#pragma unroll
+    for (int u = 0; u < FEW_WIN; u++) {
+      const f32x4 xa = x0[u], xb = x1[u];
+      int cn = c0 + u + FEW_WIN;               // refill the slot
+      cn = cn < nch ? cn : nch - 1;
+      x0[u] = *reinterpret_cast<const f32x4 *>(v0 + cn * 32);
+      x1[u] = *reinterpret_cast<const f32x4 *>(v1 + cn * 32);
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (g + 1 < NG || u + 1 < FEW_WIN) {
+          const f32x4 *wp = (g + 1 < NG) ? wptr(u) + 4 * (g + 1) : wptr(u + 1);
+#pragma unroll
+          for (int k = 0; k < 4; k++) wn[k] = wp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int j = g * 4 + k;
+          a0[j] = __builtin_elementwise_fma(xa.xy, wc[k].xy, a0[j]);
+          a0[j] = __builtin_elementwise_fma(xa.zw, wc[k].zw, a0[j]);
+          a1[j] = __builtin_elementwise_fma(xb.xy, wc[k].xy, a1[j]);
+          a1[j] = __builtin_elementwise_fma(xb.zw, wc[k].zw, a1[j]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) wc[k] = wn[k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // ---- rows x columns of this wave -> LDS (one lane per row writes), then column-wise: lane (j, half) scans 8 rows
+  float *ws = scr + wave * 16 * FEW_MAXL;
+#pragma unroll
+  for (int j = 0; j < LT; j++) {
+    const float s0 = sum8(a0[j].x + a0[j].y), s1 = sum8(a1[j].x + a1[j].y);
+    if (sl == 0) {
+      ws[rg * FEW_MAXL + j] = s0;
+      ws[(8 + rg) * FEW_MAXL + j] = s1;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own LDS writes have completed (same-wave hand-off)
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int j = lane & 31, half = lane >> 5;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (j < L) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int row = s * FEW_ROWS + wave * 16 + half * 8 + r;
+        const float v = ws[(half * 8 + r) * FEW_MAXL + j];
+        if (row < Nb && better_nan(v, row, bv, bi)) {
+          bv = v;
+          bi = row;
+        }
+      }
+    }
+    const float ov = __shfl_xor(bv, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (better_nan(ov, oi, bv, bi)) {
+      bv = ov;
+      bi = oi;
+    }
+    if (lane < 32) wbest[wave * FEW_MAXL + lane] = make_float2(bv, __int_as_float(bi));
+  }
+  __syncthreads();
+  if (tid < L) {
+    float2 b = wbest[tid];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      const float2 o = wbest[w * FEW_MAXL + tid];
+      if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
+    }
+    parts[((size_t)f * S + s) * FEW_MAXL + tid] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__restrict__ parts, const int32_t *__restrict__ ent_len,
+                                                            int F, int Nb, int Na, int Ne, int S, int Lh,
+                                                            float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
+  __shared__ int prefix[NA_MAX + 1];
+  build_prefix(ent_len, Na, Ne, prefix);
+  __syncthreads();
+  const int Q = Na * Ne;
+  const long total = (long)F * Q;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int f = (int)(idx / Q), q = (int)(idx - (long)f * Q);
+    const int a = q / Ne, e = q - a * Ne;
+    if (e >= prefix[a + 1] - prefix[a]) {      // masked slot: the whole S_ column is 0 (model.py:551) -> (0, 0)
+      S_max[idx] = 0.f;
+      D_ind[idx] = 0;
+      continue;
+    }
+    const int j = prefix[a] + e;
+    if (j >= Lh) {                              // the caller's bound on the live columns was too small: loud, not truncated
+      S_max[idx] = NAN;
+      D_ind[idx] = 0;
+      continue;
+    }
+    float2 b = parts[((size_t)f * S) * FEW_MAXL + j];
+    for (int s = 1; s < S; s++) {
+      const float2 o = parts[((size_t)f * S + s) * FEW_MAXL + j];
+      if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
+    }
+    int bi = __float_as_int(b.y);
+    bi = bi < 0 ? 0 : (bi >= Nb ? Nb - 1 : bi);
+    S_max[idx] = b.x;
+    D_ind[idx] = (int64_t)bi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- many live columns
+// per-column statistics of one contributor: best two (value, row) and the third-best value
+struct Top {
+  float m1, m2, m3;
+  int i1, i2;
+};
+__device__ __forceinline__ Top top_empty() { return Top{-INFINITY, -INFINITY, -INFINITY, 0x7fffffff, 0x7fffffff}; }   // (index: none)
+// One element into the running top-3.  Elements arrive in ascending row order, so strict `>` keeps the smaller row on ties.  The
+// payload is the element's compile-time id (ID - 16 is an inline constant for ID < 80), decoded into a row afterwards: eight
+// branch-free vector instructions.  (Written as ternaries hipcc turned the updates into exec-masked branches and hoisted all
+// 160 row-validity compares of the tile into spilled SGPR masks.)
+template <int ID>
+__device__ __forceinline__ void top_push(Top &t, float v) {
+  static_assert(ID >= 0 && ID < 80, "id must fit an inline constant");
+  asm volatile(
+      "v_med3_f32 %2, %1, %2, %5\n\t"
+      "v_cmp_gt_f32 vcc, %5, %1\n\t"
+      "v_cndmask_b32_e64 %4, %4, %6, vcc\n\t"
+      "v_med3_f32 %1, %0, %1, %5\n\t"
+      "v_cmp_gt_f32 vcc, %5, %0\n\t"
+      "v_cndmask_b32_e32 %4, %4, %3, vcc\n\t"
+      "v_cndmask_b32_e64 %3, %3, %6, vcc\n\t"
+      "v_max_f32 %0, %0, %5"
+      : "+v"(t.m1), "+v"(t.m2), "+v"(t.m3), "+v"(t.i1), "+v"(t.i2)
+      : "v"(v), "n"(ID - 16)
+      : "vcc");
+}
+__device__ __forceinline__ Top top_merge(Top a, Top b) {
+  if (better(b.m1, b.i1, a.m1, a.i1)) {
+    const Top t = a;
+    a = b;
+    b = t;
+  }
+  Top o;
+  o.m1 = a.m1;
+  o.i1 = a.i1;
+  if (better(a.m2, a.i2, b.m1, b.i1)) {
+    o.m2 = a.m2;
+    o.i2 = a.i2;
+    o.m3 = fmaxf(a.m3, b.m1);
+  } else {
+    o.m2 = b.m1;
+    o.i2 = b.i1;
+    o.m3 = fmaxf(a.m2, b.m2);
+  }
+  return o;
+}
+
+constexpr int FR_MAXT = 2;      // D <= 512: float4 pieces per lane of an exact dot product
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, typename Fn>
+__device__ __forceinline__ void unroll_blocks(Fn &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    unroll_blocks<N, I + 1>(f);
+  }
+}
+
+// workgroup barrier without the vmcnt(0) of __syncthreads(): the staging waves keep global loads in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// grid ceil(F/8)*8*G workgroups of 512 threads (one per CU: ~120 KB of LDS); workgroup = (frame f, column group g).
+// Waves 0-3 (one per SIMD) issue the MFMAs: wave = (row half rh, column half ch), RW x CW accumulator tiles.  Waves 4-7 (their
+// SIMD partners) STAGE: global_load_dwordx4 (8 lanes per 128-B line) -> split into bf16 hi / lo -> ds_write_b64 into the other
+// LDS stage, two chunks of loads in flight.  The hardware interleaves the partner's vector work with the MFMA wave's matrix
+// work; as one instruction stream hipcc ran the conversion, the MFMAs and the loads of a chunk one after the other.
+// LDS: [2 stages][(RT + GC) rows][128 B: hi p0..p3 | lo p0..p3, 16-B slots XOR-swizzled by (row >> 1) & 7][qmap GC][prefix]
+template <int RW, int CW>
+__global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
+                                                        const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
+                                                        int D, int G, float *__restrict__ S_max, int64_t *__restrict__ D_ind,
+                                                        int dbg) {
+  constexpr int RT = 2 * RW * 32;            // rows per super-tile (two row halves)
+  (void)dbg;                                 // timing experiments of the experiments build: 1 = stop before the exact phase
+  constexpr int GC = 64 * CW;                // live columns per workgroup (two column halves)
+  constexpr int NSV = RT / 32, NSW = GC / 32;
+  constexpr int STAGE = (RT + GC) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *stage0 = smem;
+  int *qmap = reinterpret_cast<int *>(smem + 2 * STAGE);
+  int *prefix = qmap + GC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b8 = blockIdx.x >> 3;
+  const int f = (b8 / G) * 8 + (blockIdx.x & 7), g = b8 % G;     // the G workgroups of a frame share an XCD (blockIdx % 8)
+  if (f >= F) return;
+  const int Q = Na * Ne;
+  const int nch = D >> 5;
+
+  build_prefix(ent_len, Na, Ne, prefix);
+  __syncthreads();
+  const int Ql = prefix[Na];
+  if (g == 0) {      // masked slots of this frame: (0, 0) (model.py:551); live slots beyond the launch (bound too small): NaN
+    for (int q = tid; q < Q; q += 512) {
+      const int a = q / Ne, e = q - a * Ne;
+      const int l = prefix[a + 1] - prefix[a];
+      if (e >= l) {
+        S_max[(size_t)f * Q + q] = 0.f;
+        D_ind[(size_t)f * Q + q] = 0;
+      } else if (prefix[a] + e >= G * GC) {
+        S_max[(size_t)f * Q + q] = NAN;
+        D_ind[(size_t)f * Q + q] = 0;
+      }
+    }
+  }
+  if (g * GC >= Ql) return;                  // over-provisioned column group
+  if (tid < GC) {
+    const int c = g * GC + tid;
+    int q = -1;
+    if (c < Ql) {
+      const int a = find_seg(prefix, Na, c);
+      q = a * Ne + (c - prefix[a]);
+    }
+    qmap[tid] = q;
+  }
+  __syncthreads();
+  const float *Vf = V + (size_t)f * Nb * D;
+  const int nsuper = (Nb + RT - 1) / RT;
+
+  Top top[CW];
+  bool nanf[CW];
+#pragma unroll
+  for (int cb = 0; cb < CW; cb++) {
+    top[cb] = top_empty();
+    nanf[cb] = false;
+  }
+  float mv = 0.f, mw = 0.f;                    // max |x| over the operand elements this thread staged
+  const int lr = lane & 31, h = lane >> 5;
+  const int rh = (wave >> 1) & 1, ch = wave & 1;
+
+  if (wave >= 4) {
+    // ================================================================ staging waves
+    const int ct = tid - 256;
+    const int tr = ct >> 3, ts = ct & 7;       // thread (tr, ts) moves 16 B (4 k) of tile row tr + 32 i per slot
+    const int swz = (tr >> 1) & 7;
+    const int wr_hi = tr * 128 + ((ts >> 1) ^ swz) * 16 + (ts & 1) * 8;
+    const int wr_lo = tr * 128 + ((4 + (ts >> 1)) ^ swz) * 16 + (ts & 1) * 8;
+    int woff[NSW];
+#pragma unroll
+    for (int j = 0; j < NSW; j++) {
+      const int q = qmap[tr + 32 * j];
+      woff[j] = (q >= 0 ? q : 0) * D + ts * 4;   // (a column beyond the live count reads query row 0; its results are never stored)
+    }
+    for (int rt = 0; rt < nsuper; rt++) {
+      int voff[NSV];
+#pragma unroll
+      for (int i = 0; i < NSV; i++) {
+        int row = rt * RT + tr + 32 * i;
+        row = row < Nb ? row : Nb - 1;
+        voff[i] = row * D + ts * 4;
+      }
+      f32x4 sv[2][NSV], sw[2][NSW];            // two register sets: chunk c travels in set c & 1
+      auto issue = [&](int ci, auto set_tag) {
+        constexpr int S_ = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < NSV; i++) sv[S_][i] = *reinterpret_cast<const f32x4 *>(Vf + voff[i] + ci * 32);
+#pragma unroll
+        for (int j = 0; j < NSW; j++) sw[S_][j] = *reinterpret_cast<const f32x4 *>(Wm + woff[j] + ci * 32);
+      };
+      auto convert = [&](unsigned char *st, auto set_tag) {
+        constexpr int S_ = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < NSV; i++) {
+          bf16x4 hi, lo;
+          const f32x4 x = sv[S_][i];
+          split4(x, hi, lo);
+          mv = fmaxf(mv, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+          *reinterpret_cast<bf16x4 *>(st + wr_hi + i * 4096) = hi;
+          *reinterpret_cast<bf16x4 *>(st + wr_lo + i * 4096) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < NSW; j++) {
+          bf16x4 hi, lo;
+          const f32x4 x = sw[S_][j];
+          split4(x, hi, lo);
+          mw = fmaxf(mw, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+          *reinterpret_cast<bf16x4 *>(st + RT * 128 + wr_hi + j * 4096) = hi;
+          *reinterpret_cast<bf16x4 *>(st + RT * 128 + wr_lo + j * 4096) = lo;
+        }
+      };
+      using S0 = std::integral_constant<int, 0>;
+      using S1 = std::integral_constant<int, 1>;
+      if (rt > 0) lds_barrier();               // (the MFMA waves are done reading the previous super-tile's last stage)
+      issue(0, S0{});
+      if (nch > 1) issue(1, S1{});
+      convert(stage0, S0{});
+      if (nch > 2) issue(2, S0{});
+      lds_barrier();
+      // trip ci (the MFMA waves compute chunk ci): convert chunk ci + 1 into the other stage, request chunk ci + 3
+      for (int ci = 0; ci < nch; ci += 2) {
+        if (ci + 1 < nch) convert(stage0 + STAGE, S1{});
+        if (ci + 3 < nch) issue(ci + 3, S1{});
+        lds_barrier();
+        if (ci + 1 < nch) {
+          if (ci + 2 < nch) convert(stage0, S0{});
+          if (ci + 4 < nch) issue(ci + 4, S0{});
+          lds_barrier();
+        }
+      }
+    }
+  } else {
+    // ================================================================ MFMA waves
+    const int aswz = (lr >> 1) & 7;
+    const int a_base = (rh * RW * 32 + lr) * 128;
+    const int b_base = (RT + ch * CW * 32 + lr) * 128;
+    int fo[2][2];                              // [plane][k-step]: byte offset of this lane's 16-B piece inside its row
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+      for (int t = 0; t < 2; t++) fo[pl][t] = ((pl * 4 + 2 * t + h) ^ aswz) << 4;
+    for (int rt = 0; rt < nsuper; rt++) {
+      f32x16 acc[RW][CW];
+#pragma unroll
+      for (int rb = 0; rb < RW; rb++)
+#pragma unroll
+        for (int cb = 0; cb < CW; cb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[rb][cb][r] = 0.f;
+      if (rt > 0) lds_barrier();
+      lds_barrier();                           // chunk 0 is in stage 0
+      for (int ci = 0; ci < nch; ci++) {
+        const unsigned char *st = stage0 + (ci & 1) * STAGE;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          bf16x8 bhi[CW], blo[CW];
+#pragma unroll
+          for (int cb = 0; cb < CW; cb++) {
+            bhi[cb] = *reinterpret_cast<const bf16x8 *>(st + b_base + cb * 4096 + fo[0][t]);
+            blo[cb] = *reinterpret_cast<const bf16x8 *>(st + b_base + cb * 4096 + fo[1][t]);
+          }
+#pragma unroll
+          for (int rb = 0; rb < RW; rb++) {
+            const bf16x8 ahi = *reinterpret_cast<const bf16x8 *>(st + a_base + rb * 4096 + fo[0][t]);
+            const bf16x8 alo = *reinterpret_cast<const bf16x8 *>(st + a_base + rb * 4096 + fo[1][t]);
+#pragma unroll
+            for (int cb = 0; cb < CW; cb++) {
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[cb], acc[rb][cb], 0, 0, 0);
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[cb], acc[rb][cb], 0, 0, 0);
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[cb], acc[rb][cb], 0, 0, 0);
+            }
+          }
+        }
+        lds_barrier();
+      }
+      // ---- this lane's column: 16 rows per 32-row block, ascending.  Element id = rb * 16 + r; NaN / Inf anywhere in the column
+      // makes nanacc NaN (x * 0), which sends the column to the exact slow path.
+#pragma unroll
+      for (int cb = 0; cb < CW; cb++) {
+        Top loc = top_empty();
+        float nanacc = 0.f;
+        const int wbase = rt * RT + rh * RW * 32;        // first row of this wave's blocks
+        unroll_blocks<RW>([&](auto rb_tag) {
+          constexpr int rb = decltype(rb_tag)::value;
+          const int lim = Nb - (wbase + rb * 32) - 4 * h;  // element r is a real row iff (r & 3) + 8 * (r >> 2) < lim
+          unroll_blocks<16>([&](auto r_tag) {
+            constexpr int r = decltype(r_tag)::value;
+            float v = acc[rb][cb][r];
+            nanacc = fmaf(v, 0.f, nanacc);
+            if (wbase + rb * 32 + 32 > Nb) v = ((r & 3) + 8 * (r >> 2) < lim) ? v : -INFINITY;   // (uniform: the frame's last block only)
+            top_push<rb * 16 + r>(loc, v);
+          });
+        });
+        // payload -> row, then into the running statistics (an earlier super-tile's rows are smaller: better() keeps the order)
+        auto row_of = [&](int id) {
+          if (id > 63) return 0x7fffffff;             // (none)
+          id += 16;
+          return wbase + (id >> 4) * 32 + (id & 3) + 8 * ((id & 15) >> 2) + 4 * h;
+        };
+        loc.i1 = row_of(loc.i1);
+        loc.i2 = row_of(loc.i2);
+        top[cb] = top_merge(top[cb], loc);
+        nanf[cb] = nanf[cb] || (nanacc != nanacc);
+      }
+    }
+  }
+
+  // ---- the four contributors of a column (row half x 16-row lane half) leave their statistics in LDS: 8 listed candidates
+  __syncthreads();                             // the stages are free: reuse them as scratch
+  Top *ctop = reinterpret_cast<Top *>(smem);                       // [4 contributors][GC]
+  int *cnan = reinterpret_cast<int *>(smem + 4 * GC * sizeof(Top));   // [4][GC]
+  float *red = reinterpret_cast<float *>(smem + 4 * GC * sizeof(Top) + 4 * GC * 4);   // [2][4 staging waves]
+  int *nslow = reinterpret_cast<int *>(red + 8);                   // [1] number of columns on the slow path
+  int *slowc = nslow + 1;                                           // [GC] their column indices
+  float2 *sbest = reinterpret_cast<float2 *>(slowc + GC);          // [8 waves] per-wave result of a slow column
+  if (tid == 0) nslow[0] = 0;
+  if (wave < 4) {
+#pragma unroll
+    for (int cb = 0; cb < CW; cb++) {
+      const int c = (ch * CW + cb) * 32 + lr;
+      ctop[(rh * 2 + h) * GC + c] = top[cb];
+      cnan[(rh * 2 + h) * GC + c] = (int)nanf[cb];
+    }
+  } else {
+    float a = mv, b = mw;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a = fmaxf(a, __shfl_xor(a, o));
+      b = fmaxf(b, __shfl_xor(b, o));
+    }
+    if (lane == 0) {
+      red[wave - 4] = a;
+      red[wave] = b;
+    }
+  }
+  __syncthreads();
+#ifdef NAFAE_EXPERIMENTS
+  if (dbg & 1) return;                         // timing experiment: k-loop + scan only
+#endif
+  const float mvw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  const float mabs = 6.103515625e-05f * (float)D * mvw;          // 2^-14 * D * max|V| * max|W|
+
+  // ---- exact fp32, phase A: wave w takes columns [w * GC/8, (w+1) * GC/8), BATCH at a time: the W row and the winner's V row
+  // are requested together; every listed candidate within the margin of the best filter value is evaluated.  Columns where
+  // an UNLISTED row could lie within the margin (a contributor's third-best value too close), or that saw a NaN, go on the
+  // slow list.
+  constexpr int CPW = GC / 8, BATCH = 8;
+  for (int c0 = wave * CPW; c0 < (wave + 1) * CPW; c0 += BATCH) {
+    f32x4 wf[BATCH][FR_MAXT], xf[BATCH][FR_MAXT];
+    int qq[BATCH], i1[BATCH];
+    float bm[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; u++) {
+      const int c = c0 + u;
+      qq[u] = qmap[c];
+      float m = -INFINITY;
+      int ix = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const Top t = ctop[k * GC + c];
+        if (better(t.m1, t.i1, m, ix)) {
+          m = t.m1;
+          ix = t.i1;
+        }
+      }
+      bm[u] = m;
+      i1[u] = (ix >= 0 && ix < Nb) ? ix : 0;
+      const int q = qq[u] >= 0 ? qq[u] : 0;
+#pragma unroll
+      for (int k = 0; k < FR_MAXT; k++) {
+        const int d = lane * 4 + 256 * k;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        wf[u][k] = d < D ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + d) : z;
+        xf[u][k] = d < D ? *reinterpret_cast<const f32x4 *>(Vf + (size_t)i1[u] * D + d) : z;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; u++) {
+      if (qq[u] < 0) continue;                 // (wave-uniform) column beyond the live count
+      const int c = c0 + u;
+      const float margin = mabs + 4.8828125e-04f * fabsf(bm[u]);
+      bool slow = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) slow = slow || cnan[k * GC + c] != 0 || !(bm[u] - ctop[k * GC + c].m3 >= margin);
+      if (slow) {
+        if (lane == 0) slowc[atomicAdd(nslow, 1)] = c;
+        continue;
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < FR_MAXT; k++) {
+        acc = fmaf(xf[u][k][0], wf[u][k][0], acc);
+        acc = fmaf(xf[u][k][1], wf[u][k][1], acc);
+        acc = fmaf(xf[u][k][2], wf[u][k][2], acc);
+        acc = fmaf(xf[u][k][3], wf[u][k][3], acc);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      float eb = acc;
+      int ei = i1[u];
+      for (int k = 0; k < 8; k++) {            // the other listed candidates: decided in fp32 where the filter cannot
+        const Top t = ctop[(k >> 1) * GC + c];
+        const float m = (k & 1) ? t.m2 : t.m1;
+        const int ix = (k & 1) ? t.i2 : t.i1;
+        if (ix == i1[u] || ix < 0 || ix >= Nb || !(bm[u] - m < margin)) continue;
+        const float e = wave_dot<FR_MAXT>(Vf + (size_t)ix * D, wf[u], D, lane);
+        if (better_nan(e, ix, eb, ei)) {
+          eb = e;
+          ei = ix;
+        }
+      }
+      if (lane == 0) {
+        S_max[(size_t)f * Q + qq[u]] = eb;
+        D_ind[(size_t)f * Q + qq[u]] = (int64_t)ei;
+      }
+    }
+  }
+  // ---- phase B: the slow list, one column at a time by the WHOLE workgroup: wave w evaluates the rows r = w (mod 8), four
+  // rows (eight 16-B loads per lane) in flight, exactly; torch.max's rules decide (NaN first, ties -> smaller index)
+  __syncthreads();
+  const int ns = nslow[0];
+  for (int si = 0; si < ns; si++) {
+    const int c = slowc[si];
+    const int q = qmap[c];
+    f32x4 wq[FR_MAXT];
+#pragma unroll
+    for (int k = 0; k < FR_MAXT; k++) {
+      const int d = lane * 4 + 256 * k;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      wq[k] = d < D ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + d) : z;
+    }
+    float eb = -INFINITY;
+    int ei = 0x7fffffff;
+    for (int r0 = wave; r0 < Nb; r0 += 32) {
+      f32x4 xr[4][FR_MAXT];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = r0 + 8 * j < Nb ? r0 + 8 * j : Nb - 1;
+#pragma unroll
+        for (int k = 0; k < FR_MAXT; k++) {
+          const int d = lane * 4 + 256 * k;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          xr[j][k] = d < D ? *reinterpret_cast<const f32x4 *>(Vf + (size_t)r * D + d) : z;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = r0 + 8 * j;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < FR_MAXT; k++) {
+          acc = fmaf(xr[j][k][0], wq[k][0], acc);
+          acc = fmaf(xr[j][k][1], wq[k][1], acc);
+          acc = fmaf(xr[j][k][2], wq[k][2], acc);
+          acc = fmaf(xr[j][k][3], wq[k][3], acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (r < Nb && better_nan(acc, r, eb, ei)) {
+          eb = acc;
+          ei = r;
+        }
+      }
+    }
+    if (lane == 0) sbest[wave] = make_float2(eb, __int_as_float(ei));
+    __syncthreads();
+    if (tid == 0) {
+      float2 b = sbest[0];
+      for (int w = 1; w < 8; w++) {
+        const float2 o = sbest[w];
+        if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
+      }
+      const int bi = __float_as_int(b.y);
+      S_max[(size_t)f * Q + q] = b.x;
+      D_ind[(size_t)f * Q + q] = (int64_t)((bi >= 0 && bi < Nb) ? bi : 0);
+    }
+    __syncthreads();
+  }
+}
+
+template <int RW, int CW>
+int launch_frame(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int G,
+                 float *S_max, int64_t *D_ind, hipStream_t st) {
+  constexpr int RT = 2 * RW * 32, GC = 64 * CW;
+  const size_t lds = 2 * (size_t)(RT + GC) * 128 + GC * 4 + (((size_t)(Na + 1) * 4 + 15) & ~(size_t)15);
+  const void *k = reinterpret_cast<const void *>(sim_frame_kernel<RW, CW>);
+  if (lds > 64 * 1024) {
+    const int rc = allow_dynamic_lds(k, 160 * 1024);
+    if (rc != NAFAE_OK) return rc;
+  }
+  const int grid = ((F + 7) / 8) * 8 * G;
+  int dbg = 0;
+  if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
+  hipLaunchKernelGGL((sim_frame_kernel<RW, CW>), dim3(grid), dim3(512), lds, st, V, W, ent_len, F, Nb, Na, Ne, D, G, S_max, D_ind,
+                     dbg);
+  return launch_status();
+}
+
+}  // namespace
+
+namespace nafae_sim {
+
+// L <= 32 live columns (the caller's bound), D % 32 == 0, D <= 512.  workspace: F * ceil(Nb / 64) * 32 * 8 bytes.
+int64_t few_workspace_bytes(int F, int Nb) { return (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * FEW_MAXL * 8; }
+
+template <int LT>
+int launch_few_lt(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float2 *parts,
+                  hipStream_t st) {
+  const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
+  const FewLds lo = few_lds(D, LT, Na);
+  const void *k = reinterpret_cast<const void *>(sim_few_kernel<LT>);
+  if (lo.total > 64 * 1024) {
+    const int rc = allow_dynamic_lds(k, 160 * 1024);
+    if (rc != NAFAE_OK) return rc;
+  }
+  hipLaunchKernelGGL(sim_few_kernel<LT>, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts);
+  return NAFAE_OK;
+}
+
+int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
+               int64_t *D_ind, void *workspace, hipStream_t st) {
+  const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
+  float2 *parts = reinterpret_cast<float2 *>(workspace);
+  int rc = NAFAE_ELIMIT;
+  switch ((Lh + 3) / 4) {
+    case 1: rc = launch_few_lt<4>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 2: rc = launch_few_lt<8>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 3: rc = launch_few_lt<12>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 4: rc = launch_few_lt<16>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 5: rc = launch_few_lt<20>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 6: rc = launch_few_lt<24>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 7: rc = launch_few_lt<28>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 8: rc = launch_few_lt<32>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    default: break;
+  }
+  if (rc != NAFAE_OK) return rc;
+  const long total = (long)F * Na * Ne;
+  long blocks = (total + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, parts, ent_len, F, Nb, Na, Ne, S, Lh, S_max,
+                     D_ind);
+  return launch_status();
+}
+
+// L > 32 live columns: Qh = the caller's bound.  D % 32 == 0, D <= 512, Nb > 64.
+int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
+                  float *S_max, int64_t *D_ind, hipStream_t st) {
+  const int nrb = (Nb + 31) / 32;
+  // 128-column groups when they still give every CU a workgroup, else 64-column groups
+  const int cw = ((long)F * ((Qh + 127) / 128) >= 200) ? 2 : 1;
+  const int gc = 64 * cw;
+  const int G = (Qh + gc - 1) / gc;
+  int rw = (nrb + 1) / 2;                     // row blocks per wave so that one super-tile covers the frame, at most 5
+  rw = rw > 5 ? 5 : (rw < 2 ? 2 : rw);
+#define NAFAE_FR(RW_, CW_) \
+  if (rw == RW_ && cw == CW_) return launch_frame<RW_, CW_>(V, W, ent_len, F, Nb, Na, Ne, D, G, S_max, D_ind, st);
+  NAFAE_FR(2, 1) NAFAE_FR(3, 1) NAFAE_FR(4, 1) NAFAE_FR(5, 1)
+  NAFAE_FR(2, 2) NAFAE_FR(3, 2) NAFAE_FR(4, 2) NAFAE_FR(5, 2)
+#undef NAFAE_FR
+  return NAFAE_ELIMIT;
+}
+
+}  // namespace nafae_sim

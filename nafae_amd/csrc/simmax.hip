@@ -33,12 +33,10 @@
 
 #include "hip_util.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#include "sim_common.h"
 
 using namespace nafae;
+using namespace nafae_sim;
 
 #ifdef NAFAE_EXPERIMENTS
 // phase stamps of sim_part_kernel (experiments build only; scripts/sim_stamps.py): wall_clock64() = 100 MHz
@@ -53,56 +51,6 @@ __device__ unsigned long long nafae_sim_stamps[8 * 4096];
 #endif
 
 namespace {
-
-constexpr int NA_MAX = 2048;   // segments per batch the live-column prefix table holds (LDS)
-
-__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
-
-// exclusive prefix of the clamped entity counts into LDS (prefix[Na] = number of live columns); wave 0 works, caller syncs
-__device__ __forceinline__ void build_prefix(const int32_t *__restrict__ ent_len, int Na, int Ne, int *prefix) {
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    int carry = 0;
-    for (int base = 0; base < Na; base += 64) {
-      const int a = base + lane;
-      int x = 0;
-      if (a < Na) {
-        const int l = ent_len[a];
-        x = l < 0 ? 0 : (l > Ne ? Ne : l);
-      }
-      int incl = x;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-      }
-      if (a < Na) prefix[a] = carry + incl - x;
-      carry += __shfl(incl, 63);
-    }
-    if (lane == 0) prefix[Na] = carry;
-  }
-}
-
-// segment a with prefix[a] <= c < prefix[a+1]  (c < prefix[Na])
-__device__ __forceinline__ int find_seg(const int *prefix, int Na, int c) {
-  int lo = 0, hi = Na;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (prefix[mid] <= c) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
-__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8 &hi, bf16x8 &lo) {
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
-    hi[e] = h0;
-    hi[4 + e] = h1;
-    lo[e] = (__bf16)(x0[e] - (float)h0);
-    lo[4 + e] = (__bf16)(x1[e] - (float)h1);
-  }
-}
 
 // partial result of one 32-row block for one live column: top-2 (value, proposal index), 16 bytes
 __device__ __forceinline__ f32x4 pack_part(float m1, int i1, float m2, int i2) {
@@ -668,6 +616,12 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict
     c2 &= c2 - 1;
     eval(__shfl(i2, src));
   }
+  if (ei == 0x7fffffff) {
+    // nothing was re-evaluated: the frame's scores are NaN or infinite (margin / bm - e compare false everywhere).  torch.max
+    // propagates the NaN with a valid index; an out-of-range D_ind would reach the box gathers of postprocess / record_det
+    eb = (bm == bm && fabsf(bm) != INFINITY) ? bm : NAN;
+    ei = (bidx >= 0 && bidx < Nb) ? bidx : 0;
+  }
   if (lane == 0) {
     S_max[(size_t)f * Q + q] = eb;
     D_ind[(size_t)f * Q + q] = (int64_t)ei;
@@ -741,6 +695,29 @@ inline Plan make_plan(int F, int Nb, int Na, int Ne, int D, int max_live) {
 
 }  // namespace
 
+namespace nafae_sim {          // simfused.hip
+int64_t few_workspace_bytes(int F, int Nb);
+int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
+               int64_t *D_ind, void *workspace, hipStream_t st);
+int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
+                  float *S_max, int64_t *D_ind, hipStream_t st);
+}  // namespace nafae_sim
+
+namespace {
+// Which generation takes a call.  3 (simfused.hip): D % 32 == 0, D <= 512 and either at most 32 live columns (exact-fp32 stream
+// kernel) or more than 32 with more than 64 proposals per frame (frame kernel).  NAFAE_SIM_GEN=2 (experiments build only) keeps
+// the second-generation kernels of this file for A/B timing.
+inline int fused_route(int F, int Nb, int Na, int Ne, int D, int Qh) {
+  const char *e = nafae::experiment_env("NAFAE_SIM_GEN");
+  if (e && e[0] == '2') return 0;
+  if (D % 32 != 0 || D > 512 || Na > NA_MAX || F < 1 || Nb < 1) return 0;
+  if ((long)Nb * D >= (1L << 30) || (long)Na * Ne * D >= (1L << 30)) return 0;      // 32-bit element offsets inside the kernels
+  if (Qh <= 32) return 1;
+  if (Nb > 64) return 2;
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 #ifdef NAFAE_EXPERIMENTS
@@ -756,10 +733,12 @@ int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_
 int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D) {
   if (F <= 0 || Nb <= 0 || Na <= 0 || Ne <= 0 || D <= 0) return NAFAE_EINVAL;
   const Plan p = make_plan(F, Nb, Na, Ne, D, -1);
-  if (!p.ok) return 0;                   // the fallback kernel needs none
+  const int64_t few = nafae_sim::few_workspace_bytes(F, Nb);
+  if (!p.ok) return few;                 // (the exact-fp32 fallback kernel needs none)
   // the all-live plan is the largest: partials for Q rounded up to a 128-column tile + the converted W + header
   const int64_t q128 = ((int64_t)Na * Ne + 127) / 128 * 128;
-  return (int64_t)p.TRB * q128 * 16 + 1024 + q128 * D * 4;
+  const int64_t gen2 = (int64_t)p.TRB * q128 * 16 + 1024 + q128 * D * 4;
+  return gen2 > few ? gen2 : few;
 }
 
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
@@ -767,6 +746,18 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
                          void *stream) {
   if (!V || !W || !ent_len || !S_max || !D_ind) return NAFAE_EINVAL;
   if (Na <= 0 || F <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  if ((long)F * Na * Ne > (1L << 31) - 256) return NAFAE_ELIMIT;
+  {
+    const int Q = Na * Ne;
+    int Qh = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
+    if (Qh < 1) Qh = 1;
+    const int route = fused_route(F, Nb, Na, Ne, D, Qh);
+    if (route == 1) {
+      if (!workspace || workspace_bytes < nafae_sim::few_workspace_bytes(F, Nb)) return NAFAE_EINVAL;
+      return nafae_sim::launch_few(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, workspace, as_stream(stream));
+    }
+    if (route == 2) return nafae_sim::launch_frames(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, as_stream(stream));
+  }
   const Plan p = make_plan(F, Nb, Na, Ne, D, max_live_cols);
   if (!p.ok) return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
   if (!workspace || workspace_bytes < p.ws_bytes) return NAFAE_EINVAL;

@@ -89,6 +89,17 @@ def default_args(**over):
 
 
 # ---------------------------------------------------------------------------------------------------- autograd glue
+def _grad_slot(p):
+    """The buffer a parameter's gradient can be ADDED into by the kernel that computes it: its existing .grad (a view of the
+    data-parallel flat gradient buffer, parallel.GradAllReducer) when that is a dense fp32 tensor.  The backward functions
+    below then return None for that parameter, so autograd's own accumulation (one torch `add` launch per parameter and step)
+    never runs; accumulate-into semantics are unchanged (zeroed buffer + one contribution, or several backward passes)."""
+    g = p.grad
+    if g is not None and g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == p.shape:
+        return g
+    return None
+
+
 def _drop_mask(shape, p, device, generator=None):
     """Explicit Bernoulli keep mask (uint8) for nn.Dropout(p): the legacy / test form of the dropout argument."""
     return (torch.rand(shape, device=device, generator=generator) >= p).to(torch.uint8)
@@ -129,6 +140,7 @@ class _VisEbdFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, weight, bias, drop, planes=None):
+        ctx.params = (weight, bias)
         with ops.timed("vis_ebd"):
             if planes is not None:
                 # fc7 arrived with its split-bf16 planes (detector in 'bf16x3' mode): the same 3-MFMA arithmetic as fc6 / fc7
@@ -149,9 +161,11 @@ class _VisEbdFn(torch.autograd.Function):
             gpre = _tanh_drop_bwd(gy.contiguous(), y, ctx.drop)
             # only the arg-max (and clustering) rows carry gradient: contract over those rows alone
             rows, count = ops.nonzero_rows(gpre)
-            gw = ops.gemm_tn_rows(gpre, feats, rows, count, alpha=0.01)   # [D, 4096]
-            gb = ops.colsum(gpre)
-        return None, gw, gb, None, None
+            weight, bias = ctx.params
+            sw, sb = _grad_slot(weight), _grad_slot(bias)
+            gw = ops.gemm_tn_rows(gpre, feats, rows, count, alpha=0.01, out=sw, accumulate=True)   # [D, 4096]
+            gb = ops.colsum(gpre, out=sb, accumulate=True, rows=rows, count=count)
+        return None, (None if sw is not None else gw), (None if sb is not None else gb), None, None
 
 
 class _WordEbdFn(torch.autograd.Function):
@@ -159,6 +173,7 @@ class _WordEbdFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, weight, bias, bn_w, bn_b, run_mean, run_var, training, momentum, eps, drop):
+        ctx.params = (weight, bias, bn_w, bn_b)
         with ops.timed("word_ebd"):
             lin = ops.gemm_nt(feats, weight, bias)
             bn, save_mean, save_invstd = ops.batchnorm_fwd(lin, bn_w, bn_b, run_mean, run_var, training, momentum, eps)
@@ -173,10 +188,15 @@ class _WordEbdFn(torch.autograd.Function):
         gbn = _tanh_drop_bwd(gy.contiguous(), y, ctx.drop)
         if not ctx.training:
             raise NotImplementedError("WordEbd backward in eval mode is never taken by the reference")
-        glin, g_bn_w, g_bn_b = ops.batchnorm_bwd(gbn, lin, bn_w, save_mean, save_invstd)
-        gw = ops.gemm_tn(glin, feats)                                # [D, glove_dim]
-        gb = ops.colsum(glin)
-        return None, gw, gb, g_bn_w, g_bn_b, None, None, None, None, None, None
+        weight, bias, p_bn_w, p_bn_b = ctx.params
+        sw, sb, sbw, sbb = _grad_slot(weight), _grad_slot(bias), _grad_slot(p_bn_w), _grad_slot(p_bn_b)
+        both = sbw is not None and sbb is not None
+        glin, g_bn_w, g_bn_b = ops.batchnorm_bwd(gbn, lin, bn_w, save_mean, save_invstd, g_w=sbw if both else None,
+                                                 g_b=sbb if both else None)
+        gw = ops.gemm_tn(glin, feats, out=sw, accumulate=sw is not None)                # [D, glove_dim]
+        gb = ops.colsum(glin, out=sb, accumulate=True)
+        return (None, None if sw is not None else gw, None if sb is not None else gb, None if both else g_bn_w,
+                None if both else g_bn_b, None, None, None, None, None, None)
 
 
 class _DVSAFn(torch.autograd.Function):

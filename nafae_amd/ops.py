@@ -120,14 +120,17 @@ def nonzero_rows(x):
     return idx, count
 
 
-def gemm_tn_rows(A, B, rows, count, alpha=1.0):
-    """alpha * sum over the listed rows r of A[r,:]^T B[r,:]; A [K,M], B [K,N]."""
+def gemm_tn_rows(A, B, rows, count, alpha=1.0, out=None, accumulate=False):
+    """alpha * sum over the listed rows r of A[r,:]^T B[r,:]; A [K,M], B [K,N].  `out` + accumulate: out += (a .grad buffer)."""
     _chk(A); _chk(B); _chk(rows, torch.int32); _chk(count, torch.int32)
     K, M = A.shape
     N = B.shape[1]
-    out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    _rc(_lib.lib().nafae_gemm_tn_rows(_p(A), M, _p(B), N, _p(out), N, M, N, _p(rows), _p(count), K, float(alpha), _stream()),
-        "nafae_gemm_tn_rows")
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        accumulate = False
+    _chk(out, name="out")
+    _rc(_lib.lib().nafae_gemm_tn_rows_acc(_p(A), M, _p(B), N, _p(out), N, M, N, _p(rows), _p(count), K, float(alpha),
+                                          int(bool(accumulate)), _stream()), "nafae_gemm_tn_rows_acc")
     return out
 
 
@@ -608,22 +611,35 @@ def batchnorm_fwd(x, weight, bias, running_mean, running_var, training, momentum
     return y, save_mean, save_invstd
 
 
-def batchnorm_bwd(g_y, x, weight, save_mean, save_invstd):
+def batchnorm_bwd(g_y, x, weight, save_mean, save_invstd, g_w=None, g_b=None):
+    """-> (g_x, g_w, g_b).  With g_w / g_b given (a parameter's .grad buffers) the kernel adds into them."""
     _chk(g_y); _chk(x); _chk(weight); _chk(save_mean); _chk(save_invstd)
     Q, D = x.shape
     g_x = torch.empty_like(x)
-    g_w = torch.empty(D, device=x.device, dtype=torch.float32)
-    g_b = torch.empty(D, device=x.device, dtype=torch.float32)
-    _rc(_lib.lib().nafae_batchnorm_bwd(_p(g_y), _p(x), _p(weight), _p(save_mean), _p(save_invstd), _p(g_x), _p(g_w), _p(g_b),
-                                       Q, D, _stream()), "nafae_batchnorm_bwd")
+    acc = g_w is not None and g_b is not None
+    if not acc:
+        g_w = torch.empty(D, device=x.device, dtype=torch.float32)
+        g_b = torch.empty(D, device=x.device, dtype=torch.float32)
+    _chk(g_w); _chk(g_b)
+    _rc(_lib.lib().nafae_batchnorm_bwd_acc(_p(g_y), _p(x), _p(weight), _p(save_mean), _p(save_invstd), _p(g_x), _p(g_w), _p(g_b),
+                                           Q, D, int(acc), _stream()), "nafae_batchnorm_bwd_acc")
     return g_x, g_w, g_b
 
 
-def colsum(x):
+def colsum(x, out=None, accumulate=False, rows=None, count=None):
+    """out[j] (+)= sum_i x[i, j]; with `rows` / `count` (device int32, nafae_nonzero_rows) over the listed rows only."""
     _chk(x)
-    rows, cols = x.shape
-    out = torch.empty(cols, device=x.device, dtype=torch.float32)
-    _rc(_lib.lib().nafae_colsum(_p(x), _p(out), rows, cols, _stream()), "nafae_colsum")
+    n, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, device=x.device, dtype=torch.float32)
+        accumulate = False
+    _chk(out, name="out")
+    if rows is not None:
+        _chk(rows, torch.int32); _chk(count, torch.int32)
+        _rc(_lib.lib().nafae_colsum_rows(_p(x), _p(rows), _p(count), n, cols, _p(out), int(bool(accumulate)), _stream()),
+            "nafae_colsum_rows")
+    else:
+        _rc(_lib.lib().nafae_colsum_acc(_p(x), _p(out), n, cols, int(bool(accumulate)), _stream()), "nafae_colsum_acc")
     return out
 
 

@@ -484,3 +484,57 @@ def test_embedding_tail_ops(ops):
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(Exception):
         ops.gemm_nt(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_tail_kernels_accumulate_and_row_lists(ops):
+    """Round 3: the tail kernels write parameter gradients straight into (+=) the flat gradient buffer, and VisEbd's bias gradient
+    sums only the rows that carry any gradient: colsum (dense / listed rows / accumulate), gemm_tn_rows with accumulate,
+    batchnorm backward with accumulate, nonzero_rows at a row count that is not a multiple of the block size -- against torch."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    R, D, K = 4999, 512, 200
+    x = torch.randn(R, D, device="cuda", generator=g)
+    x[torch.rand(R, device="cuda", generator=g) < 0.8] = 0          # ~80 % exactly-zero rows
+    idx, count = ops.nonzero_rows(x)
+    nz = torch.nonzero(x.abs().sum(1) > 0).view(-1)
+    assert int(count) == nz.numel() and torch.equal(idx[:int(count)].long(), nz)
+    ref = x.double().sum(0)
+    assert relerr(ops.colsum(x).cpu(), ref.cpu()) < 1e-5
+    assert relerr(ops.colsum(x, rows=idx, count=count).cpu(), ref.cpu()) < 1e-5
+    base = torch.randn(D, device="cuda", generator=g)
+    out = base.clone()
+    ops.colsum(x, out=out, accumulate=True, rows=idx, count=count)
+    assert relerr(out.cpu(), (ref + base.double()).cpu()) < 1e-5
+    out = base.clone()
+    ops.colsum(x, out=out, accumulate=True)
+    assert relerr(out.cpu(), (ref + base.double()).cpu()) < 1e-5
+    out = base.clone()
+    ops.colsum(x, out=out, accumulate=False)
+    assert relerr(out.cpu(), ref.cpu()) < 1e-5
+    # gemm_tn_rows: C (+)= alpha * sum_rows A[r]^T B[r]
+    B = torch.randn(R, K, device="cuda", generator=g)
+    refw = 0.01 * (x.double().t() @ B.double())
+    assert relerr(ops.gemm_tn_rows(x, B, idx, count, alpha=0.01).cpu(), refw.cpu()) < 1e-5
+    C0 = torch.randn(D, K, device="cuda", generator=g)
+    C = C0.clone()
+    ops.gemm_tn_rows(x, B, idx, count, alpha=0.01, out=C, accumulate=True)
+    assert relerr(C.cpu(), (refw + C0.double()).cpu()) < 1e-5
+    # batchnorm forward / backward (parallel over rows) incl. accumulate, ragged Q and D
+    for Q, Dd in ((13, 40), (128, 512), (512, 512), (200, 96)):
+        xx = torch.randn(Q, Dd, device="cuda", generator=g) * 2 + 1
+        w, b = torch.rand(Dd, device="cuda", generator=g) + 0.5, torch.randn(Dd, device="cuda", generator=g)
+        rm, rv = torch.zeros(Dd, device="cuda"), torch.ones(Dd, device="cuda")
+        y, sm, si = ops.batchnorm_fwd(xx, w, b, rm, rv, True)
+        xt = xx.clone().double().requires_grad_()
+        wt, bt = w.double().requires_grad_(), b.double().requires_grad_()
+        rm_t, rv_t = torch.zeros(Dd, device="cuda", dtype=torch.float64), torch.ones(Dd, device="cuda", dtype=torch.float64)
+        yt = torch.nn.functional.batch_norm(xt, rm_t, rv_t, wt, bt, True, 0.1, 1e-5)
+        assert relerr(y.cpu(), yt.detach().cpu()) < 1e-5 and relerr(rm.cpu(), rm_t.cpu()) < 1e-5 and relerr(rv.cpu(), rv_t.cpu()) < 1e-5
+        gy = torch.randn(Q, Dd, device="cuda", generator=g)
+        yt.backward(gy.double())
+        gx, gw, gb = ops.batchnorm_bwd(gy, xx, w, sm, si)
+        assert relerr(gx.cpu(), xt.grad.cpu()) < 2e-5 and relerr(gw.cpu(), wt.grad.cpu()) < 2e-5 and relerr(gb.cpu(), bt.grad.cpu()) < 2e-5
+        aw, ab = torch.ones(Dd, device="cuda"), torch.full((Dd,), 2.0, device="cuda")
+        gx2, _, _ = ops.batchnorm_bwd(gy, xx, w, sm, si, g_w=aw, g_b=ab)
+        assert torch.equal(gx2, gx) and relerr(aw.cpu(), (wt.grad + 1).cpu()) < 2e-5 and relerr(ab.cpu(), (bt.grad + 2).cpu()) < 2e-5
+    ye, _, _ = ops.batchnorm_fwd(xx, w, b, rm, rv, False)
+    assert relerr(ye.cpu(), torch.nn.functional.batch_norm(xx, rm, rv, w, b, False, 0.1, 1e-5).cpu()) < 1e-5

@@ -195,3 +195,104 @@ def test_sim_max_v2_is_deterministic_and_graph_capturable():
         g.replay()
         st.synchronize()
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
+@pytest.mark.parametrize("Ne,lens", [(8, [8, 5]), (40, [40, 33])], ids=["few", "dense"])
+def test_sim_max_unsquashed_embeddings_with_planted_near_ties(Ne, lens):
+    """The reference's DVSA.forward accepts ANY embeddings (model.py:548), not only tanh outputs: |v| up to 10 here.  The few-column
+    kernel is exact fp32 throughout; the frame kernel measures max|V|, max|W| while staging and widens its refinement margin
+    accordingly (round 2 assumed |V|, |W| <= 1).  Planted near-ties (exact gap ~1e-5 of the score scale) must come out like the
+    fp64 arg-max in both index orders."""
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, D = 2, 3, 96, 512
+    V = syn.randn(11, "Vu%d" % Ne, (Na * Ns * Nb, D)) * 3.3            # |v| up to ~10
+    W = syn.randn(11, "Wu%d" % Ne, (Na * Ne, D)) * 2.0
+    V3 = V.view(Na * Ns, Nb, D)
+    V3[:, 11] = W[0] * 0.8                                              # a clear winner for query 0 ...
+    for f in range(Na * Ns):
+        j, sign = [(70, +1.0), (3, +1.0), (70, -1.0), (3, -1.0), (40, +1.0), (12, -1.0)][f]
+        r = V3[f, 11].clone()
+        k = int(torch.argmax(W[0].abs()))
+        r[k] = r[k] + sign * 2.0 ** -9 * torch.sign(W[0, k])           # ... and a near-copy: the exact score moves by ~2^-9 * |w_k|
+        V3[f, j] = r
+    m, i, gap, masked = _ref(V, W, lens, Na, Nb, Ne)
+    scale = float(m.abs().max())
+    assert float(gap[:, 0].max()) < 1e-4 * scale and float(gap[:, 0].min()) > 2e-6 * scale
+    for hint in (lens, None):
+        S, Di = _run(V, W, lens, Na, Ns, Nb, Ne, lens=hint)
+        S, Di = S.cpu().double(), Di.cpu()
+        assert Di[:, 0].tolist() == i[:, 0].tolist() == [70, 3, 11, 11, 40, 11]
+        assert float((S - m).abs().max()) < 2e-6 * scale
+        assert not ((Di != i) & ~masked & (gap > 1e-5 * scale)).any()
+        assert (S[masked] == 0).all() and (Di[masked] == 0).all()
+
+
+@pytest.mark.parametrize("Ne,lens,hint", [(8, [8, 5], 9), (8, [8, 8], 4), (40, [40, 33], 40), (64, [64, 64], 64)],
+                         ids=["few9of13", "few4of16", "dense40of73", "dense64of128"])
+def test_sim_max_too_small_live_hint_is_loud(Ne, lens, hint):
+    """max_live_cols is an UPPER BOUND the host promises.  If it is too small the live columns beyond it cannot be computed:
+    they must come back as NaN (like the loss kernel's NaN for the same mistake), never as silently wrong numbers; the columns
+    inside the bound stay correct and the masked slots stay (0, 0)."""
+    from nafae_amd import _lib, ops
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, D = 2, 2, 96, 512
+    V = torch.tanh(syn.randn(13, "Vh", (Na * Ns * Nb, D))).cuda()
+    W = torch.tanh(syn.randn(13, "Wh%d" % Ne, (Na * Ne, D))).cuda()
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    F, Q = Na * Ns, Na * Ne
+    S = torch.empty(F, Q, device="cuda")
+    Di = torch.empty(F, Q, device="cuda", dtype=torch.int64)
+    L = _lib.lib()
+    nws = int(L.nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D))
+    ws = torch.empty(max(nws, 16), device="cuda", dtype=torch.uint8)
+    rc = L.nafae_sim_max_fwd_ws(ops._p(V), ops._p(W), ops._p(lt), F, Nb, Na, Ne, D, hint, ops._p(S), ops._p(Di), ops._p(ws), ws.numel(),
+                                ops._stream())
+    assert rc == 0
+    m, i, gap, masked = _ref(V.cpu(), W.cpu(), lens, Na, Nb, Ne)
+    S, Di = S.cpu().double(), Di.cpu()
+    live_index = torch.full((Q,), -1, dtype=torch.long)
+    n = 0
+    for a, l in enumerate(lens):
+        for e in range(l):
+            live_index[a * Ne + e] = n
+            n += 1
+    assert n > hint
+    computed = (live_index >= 0) & (live_index < (hint if hint <= 32 else ((hint + 63) // 64) * 64))
+    lost = (live_index >= 0) & ~computed
+    assert lost.any() and torch.isnan(S[:, lost]).all() and (Di[:, lost] == 0).all()
+    scale = float(m.abs().max())
+    assert float((S[:, computed] - m[:, computed]).abs().max()) < 2e-6 * scale
+    assert (S[masked] == 0).all() and (Di[masked] == 0).all()
+
+
+@pytest.mark.parametrize("Ne,lens", [(8, [8, 5]), (40, [40, 33])], ids=["few", "dense"])
+def test_sim_max_nan_and_inf_inputs_follow_torch_max(Ne, lens):
+    """Diverged training puts NaN / Inf into the embeddings.  torch.max propagates a NaN with the index of the first NaN row
+    (model.py:610-612 -> D_ind feeds the box gathers of postprocess / record_det): the kernels must never emit an out-of-range
+    index, and a single NaN row of V must reach S_max instead of being skipped."""
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, D = 2, 2, 96, 512
+    V = torch.tanh(syn.randn(17, "Vq", (Na * Ns * Nb, D)))
+    W = torch.tanh(syn.randn(17, "Wq%d" % Ne, (Na * Ne, D)))
+    V3 = V.view(Na * Ns, Nb, D)
+    V3[0, 50, 7] = float("nan")          # one NaN element in one proposal of frame 0
+    V3[1, 20, 3] = float("inf")          # an Inf: the score of that row is +-Inf (or NaN where 0 * Inf meets)
+    V3[1, 60, 3] = float("inf")
+    W[1, 100] = float("nan")             # a NaN query row: every frame's column 1 is NaN, first index 0
+    Q = Na * Ne
+    S_ = V @ W.t()
+    masked = (torch.arange(Ne)[None, :] >= torch.tensor(lens)[:, None]).view(1, Q)
+    S_ = S_.masked_fill(masked, 0).view(-1, Nb, Q)
+    m, i = S_.max(1)                     # torch's own semantics are the oracle here
+    S, Di = _run(V, W, lens, Na, Ns, Nb, Ne, lens=lens)
+    S, Di = S.cpu(), Di.cpu()
+    assert int(Di.min()) >= 0 and int(Di.max()) < Nb
+    live = ~masked.expand_as(m)
+    assert torch.equal(torch.isnan(S) & live, torch.isnan(m) & live)
+    nanpos = torch.isnan(m) & live
+    assert nanpos[0][live[0]].all() and nanpos[:, 1].all()          # frame 0 (NaN row) and column 1 (NaN query) entirely
+    assert torch.equal(Di[nanpos], i[nanpos])              # the index of the FIRST NaN row
+    fin = live & torch.isfinite(m)
+    assert torch.allclose(S[fin], m[fin], rtol=0, atol=3e-6 * float(m[fin].abs().max()))
+    inf = live & torch.isinf(m)
+    assert inf.any() and torch.equal(S[inf], m[inf]) and torch.equal(Di[inf], i[inf])
