@@ -344,12 +344,29 @@ def run_rank(a):
             dist.barrier()
         torch.cuda.synchronize()
 
+    feeder = None
+    if a.stream_input:
+        import numpy as _np
+        from nafae_amd.train import FrameStreamer
+        rs = _np.random.RandomState(99 + rank)
+        host = [torch.from_numpy(rs.randint(0, 255, (F, 224, 224, 3)).astype(_np.uint8)).pin_memory() for _ in range(4)]
+        feeder = FrameStreamer(host, batch, dev)
+
     def time_mode(prec, steps, warmup):
         """warmup untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks."""
         model.fasterRCNN.precision = prec
         pipe = None if (a.no_pipeline or exact) else PipelinedTrainer(model, opt, crit, args, reducer)
 
         def run_steps(n):
+            if feeder is not None:                 # --stream-input: a different pinned-host uint8 batch every step
+                if pipe is None:
+                    for _ in range(n):
+                        loss, _, _, _ = train_step(model, opt, crit, feeder.next(), args, reducer)
+                    return loss
+                pipe.submit(feeder.next())
+                for i in range(n):
+                    loss, _, _, _ = pipe.step(feeder.next() if i + 1 < n else None)
+                return loss
             if exact:
                 for _ in range(n):
                     loss, _, _, _ = train_step_exact(model, opt, crit, batch, args, reducer)
@@ -431,7 +448,10 @@ def run_rank(a):
                        "rccl_world_size": world if distributed else 1, "collective_backend": backend if distributed else None,
                        "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
                        "grad_exchange": a.grad_exchange if distributed else None,
-                       "step_pipeline": head["step_pipeline"]},
+                       "step_pipeline": head["step_pipeline"],
+                       "input": ("streamed: a different pinned-host uint8 HWC batch every step (4 in rotation), H2D on a copy stream "
+                                 "into two device buffers, first conv layer reads the bytes (-127.5 in-kernel)") if a.stream_input
+                                else "resident fp32 NCHW frames (the same batch every step)"},
             "loss": head["loss"],
         }
         for k in ("roofline", "stage_ms", "detector"):
@@ -490,6 +510,9 @@ def main():
                     help="TEST ONLY: let the N ranks share the visible GPU(s) (LOCAL_RANK modulo device count) with gloo collectives "
                          "staged through host memory, so that the launcher and the data-parallel step can be exercised end to "
                          "end on a one-GPU box; the numbers it prints are meaningless as throughput")
+    ap.add_argument("--stream-input", action="store_true",
+                    help="feed every step a different batch of raw uint8 frames from pinned host memory through a copy stream "
+                         "(PCIe-inclusive figure; the default keeps one fp32 batch resident in HBM, as the contract's `value` requires)")
     ap.add_argument("--precision", default=os.environ.get("NAFAE_PRECISION"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the HEADLINE run (default f32, what BASELINE config C2 names): exact fp32 MFMA | "
                          "split-bf16 (fp32-accurate to ~1e-5) | bf16.  The other modes are reported under `modes`.")

@@ -170,6 +170,21 @@ int nafae_roi_align_avg_nhwc(const float *feat, int F, int H, int W, int C, cons
  * Replaces `img.astype(np.float32) - 127.5` (lib/datasets/youcook2.py:212-214) + the permute of model.py:692-698.  */
 int nafae_frames_u8_to_nchw_f32(const uint8_t *frames_hwc, float *out_nchw, int F, int H, int W, void *stream);
 
+/* Frame ingest without an fp32 copy of the frames: the first VGG layer reads its 27 taps straight from
+ *   in_kind 0  fp32 NCHW [F,3,H,W]         what model.py:692-698 hands over (= nafae_conv1_3x3_relu),
+ *   in_kind 1  uint8 HWC [F,H,W,3] (BGR)   decoded frames; the -127.5 of youcook2.py:212-214 is applied to each tap,
+ *   in_kind 2  fp32 HWC [F,H,W,3]          already minus 127.5: the output of nafae_frames_resize_bilinear.
+ * JPEG entropy decoding stays on the host (no rocJPEG in this image).  */
+int nafae_conv1_3x3_relu_in(const void *in, int in_kind, const float *w, const float *bias, float *out_nhwc, int F, int H, int W,
+                            void *stream);
+int nafae_conv1_3x3_relu_bf16_in(const void *in, int in_kind, const float *w, const float *bias, void *out_hi, void *out_lo,
+                                 int F, int H, int W, void *stream);
+/* Bilinear resize of decoded uint8 HWC frames [F,Hs,Ws,3] to fp32 HWC [F,Hd,Wd,3] minus 127.5 (youcook2.py:212-217:
+ * `img -= 127.5; img = cv2.resize(img, (img_h, img_w))`), by cv2.resize's INTER_LINEAR rule for float images: source
+ * coordinate (d + 0.5) * (src / dst) - 0.5, out-of-range taps collapse onto the border pixel, horizontal pass first.
+ * cv2 is not available offline: restated from the documented rule, NOT pinned against cv2 outputs.  */
+int nafae_frames_resize_bilinear(const uint8_t *frames_hwc, float *out_hwc, int F, int Hs, int Ws, int Hd, int Wd, void *stream);
+
 /* Layout helpers (weight re-layout at load; API-parity views): [N,C,H,W] <-> [N,H,W,C].  */
 int nafae_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, void *stream);
 int nafae_nhwc_to_nchw(const float *in, float *out, int N, int C, int H, int W, void *stream);

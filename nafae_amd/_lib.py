@@ -38,6 +38,9 @@ SIGNATURES = {
     "nafae_proposals": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, P, P, P, P]),
     "nafae_roi_align_avg_nhwc": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, P, P]),
     "nafae_frames_u8_to_nchw_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "nafae_conv1_3x3_relu_in": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, P]),
+    "nafae_conv1_3x3_relu_bf16_in": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
+    "nafae_frames_resize_bilinear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "nafae_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_split_bf16": (c_int, [P, P, P, c_int64, P]),

@@ -585,7 +585,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const float *__restri
 // channels would be one line per lane).  Same FMA order as a plain loop over (ci, ky, kx) starting from the bias.
 // Round 2: 0.51 -> 0.3 ms at 64 x 224^2 (one thread = one pixel x 16 channels with LDS weights before).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ in, const float *__restrict__ w,
+// IN: 0 = fp32 NCHW frames (what the reference's train loop hands over, model.py:692-698); 1 = raw uint8 HWC (BGR as decoded:
+// the -127.5 of youcook2.py:212-214 is applied to the tap, no fp32 copy of the frames exists); 2 = fp32 HWC already minus 127.5
+// (the output of the bilinear resize below).
+template <int IN>
+__device__ __forceinline__ float conv1_tap(const void *__restrict__ in, long n, int ci, int yy, int xx, int H, int W) {
+  if (IN == 0) return reinterpret_cast<const float *>(in)[((n * 3 + ci) * H + yy) * W + xx];
+  if (IN == 1) return (float)reinterpret_cast<const uint8_t *>(in)[((n * H + yy) * W + xx) * 3 + ci] - 127.5f;
+  return reinterpret_cast<const float *>(in)[((n * H + yy) * W + xx) * 3 + ci];
+}
+
+template <int IN>
+__global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in, const float *__restrict__ w,
                                                     const float *__restrict__ bias, float *__restrict__ out,
                                                     int F, int H, int W) {
   constexpr int ROWF = 32 + 4;                        // LDS floats per pixel: 32 channels (+16 B pad against bank conflicts)
@@ -604,7 +615,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ in
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const int yy = y + ky - 1, xx = x + kx - 1;
-        v[ci * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((n * 3 + ci) * H + yy) * W + xx] : 0.f;
+        v[ci * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? conv1_tap<IN>(in, n, ci, yy, xx, H, W) : 0.f;
       }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long wave_p0 = (long)blockIdx.x * 256 + wave * 64;   // first pixel of this wave
@@ -691,6 +702,38 @@ __global__ __launch_bounds__(256) void frames_u8_kernel(const uint8_t *__restric
     o[0] = (float)px[0] - 127.5f;
     o[hw] = (float)px[1] - 127.5f;
     o[2 * hw] = (float)px[2] - 127.5f;
+  }
+}
+
+// Bilinear resize of decoded uint8 HWC frames to Hd x Wd, fp32 HWC out, minus 127.5: youcook2.py:212-217 (`img -= 127.5;
+// img = cv2.resize(img, (img_h, img_w))` on the float image; interpolation is linear, so subtracting after it is the same).
+// cv2.resize's INTER_LINEAR rule for float images: source coordinate (d + 0.5) * (src / dst) - 0.5, floor -> left tap, a
+// coordinate left of pixel 0 or at / beyond the last pixel collapses onto that pixel with weight 0 on the neighbour; rows are
+// interpolated horizontally first (s0 * (1 - fx) + s1 * fx), then vertically.  cv2 is not installed here: this restates the
+// documented rule, it is NOT pinned against cv2 outputs.
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int F, int Hs, int Ws,
+                                                        int Hd, int Wd) {
+  const long total = (long)F * Hd * Wd;
+  const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(p % Wd), y = (int)((p / Wd) % Hd);
+    const long n = p / ((long)Wd * Hd);
+    float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+    int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    fy -= (float)y0;
+    fx -= (float)x0;
+    if (y0 < 0) { y0 = 0; fy = 0.f; }
+    if (y0 >= Hs - 1) { y0 = Hs - 1; fy = 0.f; }
+    if (x0 < 0) { x0 = 0; fx = 0.f; }
+    if (x0 >= Ws - 1) { x0 = Ws - 1; fx = 0.f; }
+    const int y1 = y0 + 1 < Hs ? y0 + 1 : Hs - 1, x1 = x0 + 1 < Ws ? x0 + 1 : Ws - 1;
+    const uint8_t *r0 = in + ((n * Hs + y0) * Ws) * 3, *r1 = in + ((n * Hs + y1) * Ws) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float h0 = (float)r0[x0 * 3 + c] * (1.f - fx) + (float)r0[x1 * 3 + c] * fx;
+      const float h1 = (float)r1[x0 * 3 + c] * (1.f - fx) + (float)r1[x1 * 3 + c] * fx;
+      out[p * 3 + c] = h0 * (1.f - fy) + h1 * fy - 127.5f;
+    }
   }
 }
 
@@ -850,13 +893,28 @@ int nafae_gemm_tn_rows(const float *A, int lda, const float *B, int ldb, float *
   return nafae_gemm_tn_rows_acc(A, lda, B, ldb, C, ldc, M, N, rows, count, max_rows, alpha, 0, stream);
 }
 
-int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias, float *out_nhwc, int F, int H,
-                         int W, void *stream) {
-  if (!in_nchw || !w || !bias || !out_nhwc || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
+int nafae_conv1_3x3_relu_in(const void *in, int in_kind, const float *w, const float *bias, float *out_nhwc, int F, int H, int W,
+                            void *stream) {
+  if (!in || !w || !bias || !out_nhwc || F <= 0 || H <= 0 || W <= 0 || in_kind < 0 || in_kind > 2) return NAFAE_EINVAL;
   long total = (long)F * H * W;
   if ((total + 255) / 256 > 0x7fffffffL) return NAFAE_ELIMIT;
   int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(conv1_kernel, dim3(blocks), dim3(256), 0, S(stream), in_nchw, w, bias, out_nhwc, F, H, W);
+  if (in_kind == 0) hipLaunchKernelGGL(conv1_kernel<0>, dim3(blocks), dim3(256), 0, S(stream), in, w, bias, out_nhwc, F, H, W);
+  else if (in_kind == 1) hipLaunchKernelGGL(conv1_kernel<1>, dim3(blocks), dim3(256), 0, S(stream), in, w, bias, out_nhwc, F, H, W);
+  else hipLaunchKernelGGL(conv1_kernel<2>, dim3(blocks), dim3(256), 0, S(stream), in, w, bias, out_nhwc, F, H, W);
+  return launched();
+}
+
+int nafae_conv1_3x3_relu(const float *in_nchw, const float *w, const float *bias, float *out_nhwc, int F, int H,
+                         int W, void *stream) {
+  return nafae_conv1_3x3_relu_in(in_nchw, 0, w, bias, out_nhwc, F, H, W, stream);
+}
+
+int nafae_frames_resize_bilinear(const uint8_t *frames_hwc, float *out_hwc, int F, int Hs, int Ws, int Hd, int Wd, void *stream) {
+  if (!frames_hwc || !out_hwc || F <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return NAFAE_EINVAL;
+  const long total = (long)F * Hd * Wd;
+  int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(resize_u8_kernel, dim3(blocks), dim3(256), 0, S(stream), frames_hwc, out_hwc, F, Hs, Ws, Hd, Wd);
   return launched();
 }
 

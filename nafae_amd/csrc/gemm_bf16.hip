@@ -1245,7 +1245,16 @@ __global__ __launch_bounds__(256) void merge_kernel(const __bf16 *hi, const __bf
 // LDS, 4 ds_read_b128 per 16 FMAs, and ran at a third of the FMA rate).  Channels are produced in two halves of 32 (one
 // interleaved plane piece = hi 32 | lo 32 = one 128-B line per pixel), transposed through LDS so that every store
 // instruction writes 8 full lines.  Summation order per output: bias, then (ci, ky, kx) ascending, fused multiply-adds.
-__global__ __launch_bounds__(256) void conv1_bf16_kernel(const float *__restrict__ in, const float *__restrict__ w,
+// IN as in gemm.hip's conv1_kernel: 0 = fp32 NCHW, 1 = raw uint8 HWC (minus 127.5 applied to the tap), 2 = fp32 HWC.
+template <int IN>
+__device__ __forceinline__ float conv1_tap(const void *__restrict__ in, long n, int ci, int yy, int xx, int H, int W) {
+  if (IN == 0) return reinterpret_cast<const float *>(in)[((n * 3 + ci) * H + yy) * W + xx];
+  if (IN == 1) return (float)reinterpret_cast<const uint8_t *>(in)[((n * H + yy) * W + xx) * 3 + ci] - 127.5f;
+  return reinterpret_cast<const float *>(in)[((n * H + yy) * W + xx) * 3 + ci];
+}
+
+template <int IN>
+__global__ __launch_bounds__(256) void conv1_bf16_kernel(const void *__restrict__ in, const float *__restrict__ w,
                                                          const float *__restrict__ bias, __bf16 *ohi, __bf16 *olo, int F,
                                                          int H, int W) {
   constexpr int ROWB = 128 + 16;                      // LDS bytes per pixel: hi 32 | lo 32 (+16 B pad against bank conflicts)
@@ -1265,7 +1274,7 @@ __global__ __launch_bounds__(256) void conv1_bf16_kernel(const float *__restrict
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const int yy = y + ky - 1, xx = x + kx - 1;
-        v[ci * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((n * 3 + ci) * H + yy) * W + xx] : 0.f;
+        v[ci * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? conv1_tap<IN>(in, n, ci, yy, xx, H, W) : 0.f;
       }
   const bool il = plane_il(ohi, olo);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1789,14 +1798,24 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
                                             relu, S(stream));
 }
 
-int nafae_conv1_3x3_relu_bf16(const float *in_nchw, const float *w, const float *bias, void *out_hi, void *out_lo, int F,
-                              int H, int W, void *stream) {
-  if (!in_nchw || !w || !bias || !out_hi || F <= 0 || H <= 0 || W <= 0) return NAFAE_EINVAL;
+int nafae_conv1_3x3_relu_bf16_in(const void *in, int in_kind, const float *w, const float *bias, void *out_hi, void *out_lo, int F,
+                                 int H, int W, void *stream) {
+  if (!in || !w || !bias || !out_hi || F <= 0 || H <= 0 || W <= 0 || in_kind < 0 || in_kind > 2) return NAFAE_EINVAL;
   long total = (long)F * H * W;
   if ((total + 255) / 256 > 0x7fffffffL) return NAFAE_ELIMIT;
-  hipLaunchKernelGGL(conv1_bf16_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, S(stream), in_nchw, w, bias,
-                     (__bf16 *)out_hi, (__bf16 *)out_lo, F, H, W);
+  const dim3 grid((int)((total + 255) / 256));
+  if (in_kind == 0)
+    hipLaunchKernelGGL(conv1_bf16_kernel<0>, grid, dim3(256), 0, S(stream), in, w, bias, (__bf16 *)out_hi, (__bf16 *)out_lo, F, H, W);
+  else if (in_kind == 1)
+    hipLaunchKernelGGL(conv1_bf16_kernel<1>, grid, dim3(256), 0, S(stream), in, w, bias, (__bf16 *)out_hi, (__bf16 *)out_lo, F, H, W);
+  else
+    hipLaunchKernelGGL(conv1_bf16_kernel<2>, grid, dim3(256), 0, S(stream), in, w, bias, (__bf16 *)out_hi, (__bf16 *)out_lo, F, H, W);
   return launched();
+}
+
+int nafae_conv1_3x3_relu_bf16(const float *in_nchw, const float *w, const float *bias, void *out_hi, void *out_lo, int F,
+                              int H, int W, void *stream) {
+  return nafae_conv1_3x3_relu_bf16_in(in_nchw, 0, w, bias, out_hi, out_lo, F, H, W, stream);
 }
 
 int nafae_maxpool2x2_bf16(const void *in_hi, const void *in_lo, void *out_hi, void *out_lo, int F, int H, int W, int C,

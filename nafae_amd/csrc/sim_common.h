@@ -78,8 +78,27 @@ __device__ __forceinline__ void split4(const f32x4 x, bf16x4 &hi, bf16x4 &lo) {
   }
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 64 lanes of a wave (all lanes active), the same bits in every lane: four DPP steps inside each row of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row sums through v_readlane, added as
+// (r0 + r1) + (r2 + r3).  (__shfl_xor lowers to ds_bpermute: six dependent LDS round trips per sum.)
+__device__ __forceinline__ float wave_sum(float x) {
+  x += dpp_mov<0xB1>(x);
+  x += dpp_mov<0x4E>(x);
+  x += dpp_mov<0x141>(x);
+  x += dpp_mov<0x140>(x);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 // exact fp32 dot product of two D-float rows by one wave (D % 4 == 0, D <= 1024): lane l takes the float4s at l*4 + 256*t, a
-// 4-FMA chain per piece, then a fixed xor tree.  `wf` = this lane's pieces of the query row (loaded once per column).
+// 4-FMA chain per piece, then wave_sum.  `wf` = this lane's pieces of the query row (loaded once per column).
 template <int MAXT>
 __device__ __forceinline__ float wave_dot(const float *__restrict__ vrow, const f32x4 (&wf)[MAXT], int D, int lane) {
   float acc = 0.f;
@@ -94,9 +113,7 @@ __device__ __forceinline__ float wave_dot(const float *__restrict__ vrow, const 
       acc = fmaf(x[3], wf[t][3], acc);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  return acc;
+  return wave_sum(acc);
 }
 
 }  // namespace nafae_sim

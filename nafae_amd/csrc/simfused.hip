@@ -46,10 +46,6 @@ constexpr int FEW_ROWS = 64;    // rows per workgroup: 4 waves x 2 octets x 8 ro
 constexpr int FEW_NCH = 16;     // 32-k chunks (D <= 512)
 constexpr int FEW_WIN = 8;      // chunks per octet held in registers
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
-}
 // sum over the 8 lanes 8k .. 8k+7; every lane ends with the same bits (fixed tree; + is commutative)
 __device__ __forceinline__ float sum8(float x) {
   x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
@@ -90,7 +86,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int LT>
 __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
                                                          const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
-                                                         int D, int S, int Lh, float2 *__restrict__ parts) {
+                                                         int D, int S, int Lh, float2 *__restrict__ parts, int dbg) {
+  (void)dbg;   // timing experiments (experiments build): 1 = no arithmetic (loads, staging and the epilogue only)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FewLds lo = few_lds(D, LT, Na);
   f32x4 *wimg = reinterpret_cast<f32x4 *>(smem + lo.wimg);
@@ -175,6 +172,20 @@ __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict
 #pragma unroll
   for (int c0 = 0; c0 < FEW_NCH; c0 += FEW_WIN) {
     if (c0 >= nch) break;
+#ifdef NAFAE_EXPERIMENTS
+    if (dbg & 1) {                             // timing experiment: consume the loads, skip the arithmetic
+#pragma unroll
+      for (int u = 0; u < FEW_WIN; u++) {
+        a0[0] += x0[u].xy;
+        a1[0] += x1[u].xy;
+        int cn = c0 + u + FEW_WIN;
+        cn = cn < nch ? cn : nch - 1;
+        x0[u] = *reinterpret_cast<const f32x4 *>(v0 + cn * 32);
+        x1[u] = *reinterpret_cast<const f32x4 *>(v1 + cn * 32);
+      }
+      continue;
+    }
+#endif
     auto wptr = [&](int u) {
       const int c = c0 + u;
       return wimg + (size_t)(c < nch ? c * 8 + sl : nch * 8) * Lp;   // (a chunk beyond D: the zero row)
@@ -353,6 +364,12 @@ __device__ __forceinline__ void unroll_blocks(Fn &&f) {
   }
 }
 
+// max(m, |x0|, |x1|, |x2|, |x3|) in two v_max3_f32 (the |.| are source modifiers)
+__device__ __forceinline__ float absmax4(float m, const f32x4 x) {
+  asm("v_max3_f32 %0, |%1|, |%2|, %0\n\tv_max3_f32 %0, |%3|, |%4|, %0" : "+v"(m) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+  return m;
+}
+
 // workgroup barrier without the vmcnt(0) of __syncthreads(): the staging waves keep global loads in flight across it
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
                                                         int D, int G, float *__restrict__ S_max, int64_t *__restrict__ D_ind,
                                                         int dbg) {
   constexpr int RT = 2 * RW * 32;            // rows per super-tile (two row halves)
-  (void)dbg;                                 // timing experiments of the experiments build: 1 = stop before the exact phase
+  (void)dbg;   // timing experiments (experiments build): 1 stop before the exact phase, 2 no MFMAs, 4 no global loads, 8 no conversion
   constexpr int GC = 64 * CW;                // live columns per workgroup (two column halves)
   constexpr int NSV = RT / 32, NSW = GC / 32;
   constexpr int STAGE = (RT + GC) * 128;
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
     // ================================================================ staging waves
     const int ct = tid - 256;
     const int tr = ct >> 3, ts = ct & 7;       // thread (tr, ts) moves 16 B (4 k) of tile row tr + 32 i per slot
-    const int swz = (tr >> 1) & 7;
+    const int swz = ((tr >> 1) & 7) ^ ((tr & 1) << 2);   // (+ the row's parity on bit 2: rows 2m, 2m+1 write different 64-B halves)
     const int wr_hi = tr * 128 + ((ts >> 1) ^ swz) * 16 + (ts & 1) * 8;
     const int wr_lo = tr * 128 + ((4 + (ts >> 1)) ^ swz) * 16 + (ts & 1) * 8;
     int woff[NSW];
@@ -452,6 +469,15 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       f32x4 sv[2][NSV], sw[2][NSW];            // two register sets: chunk c travels in set c & 1
       auto issue = [&](int ci, auto set_tag) {
         constexpr int S_ = decltype(set_tag)::value;
+#ifdef NAFAE_EXPERIMENTS
+        if (dbg & 4) {                         // timing experiment: no global loads
+#pragma unroll
+          for (int i = 0; i < NSV; i++) sv[S_][i] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+          for (int j = 0; j < NSW; j++) sw[S_][j] = f32x4{1.f, 2.f, 3.f, 4.f};
+          return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NSV; i++) sv[S_][i] = *reinterpret_cast<const f32x4 *>(Vf + voff[i] + ci * 32);
 #pragma unroll
@@ -459,12 +485,23 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       };
       auto convert = [&](unsigned char *st, auto set_tag) {
         constexpr int S_ = decltype(set_tag)::value;
+#ifdef NAFAE_EXPERIMENTS
+        if (dbg & 8) {                         // timing experiment: loads only (their values still have to arrive)
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < NSV; i++) t += sv[S_][i][0];
+#pragma unroll
+          for (int j = 0; j < NSW; j++) t += sw[S_][j][0];
+          mv = fmaxf(mv, t);
+          return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NSV; i++) {
           bf16x4 hi, lo;
           const f32x4 x = sv[S_][i];
           split4(x, hi, lo);
-          mv = fmaxf(mv, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+          mv = absmax4(mv, x);
           *reinterpret_cast<bf16x4 *>(st + wr_hi + i * 4096) = hi;
           *reinterpret_cast<bf16x4 *>(st + wr_lo + i * 4096) = lo;
         }
@@ -473,7 +510,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
           bf16x4 hi, lo;
           const f32x4 x = sw[S_][j];
           split4(x, hi, lo);
-          mw = fmaxf(mw, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+          mw = absmax4(mw, x);
           *reinterpret_cast<bf16x4 *>(st + RT * 128 + wr_hi + j * 4096) = hi;
           *reinterpret_cast<bf16x4 *>(st + RT * 128 + wr_lo + j * 4096) = lo;
         }
@@ -481,26 +518,29 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       using S0 = std::integral_constant<int, 0>;
       using S1 = std::integral_constant<int, 1>;
       if (rt > 0) lds_barrier();               // (the MFMA waves are done reading the previous super-tile's last stage)
+      // nch is even (the launcher checks D % 64 == 0).  Every convert / issue below is UNCONDITIONAL -- past the end a valid
+      // chunk is re-read and converted into a stage nobody reads any more: with `if (ci + 3 < nch) issue(...)` hipcc's
+      // wait-count pass had to assume the younger set of loads might not exist and waited vmcnt(13..0) in every convert,
+      // i.e. for BOTH sets, which halves the prefetch distance.
+      auto clampc = [&](int c) { return c < nch ? c : nch - 1; };
       issue(0, S0{});
-      if (nch > 1) issue(1, S1{});
+      issue(1, S1{});
       convert(stage0, S0{});
-      if (nch > 2) issue(2, S0{});
+      issue(clampc(2), S0{});
       lds_barrier();
       // trip ci (the MFMA waves compute chunk ci): convert chunk ci + 1 into the other stage, request chunk ci + 3
       for (int ci = 0; ci < nch; ci += 2) {
-        if (ci + 1 < nch) convert(stage0 + STAGE, S1{});
-        if (ci + 3 < nch) issue(ci + 3, S1{});
+        convert(stage0 + STAGE, S1{});
+        issue(clampc(ci + 3), S1{});
         lds_barrier();
-        if (ci + 1 < nch) {
-          if (ci + 2 < nch) convert(stage0, S0{});
-          if (ci + 4 < nch) issue(ci + 4, S0{});
-          lds_barrier();
-        }
+        convert(stage0, S0{});
+        issue(clampc(ci + 4), S0{});
+        lds_barrier();
       }
     }
   } else {
     // ================================================================ MFMA waves
-    const int aswz = (lr >> 1) & 7;
+    const int aswz = ((lr >> 1) & 7) ^ ((lr & 1) << 2);
     const int a_base = (rh * RW * 32 + lr) * 128;
     const int b_base = (RT + ch * CW * 32 + lr) * 128;
     int fo[2][2];                              // [plane][k-step]: byte offset of this lane's 16-B piece inside its row
@@ -520,6 +560,12 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       lds_barrier();                           // chunk 0 is in stage 0
       for (int ci = 0; ci < nch; ci++) {
         const unsigned char *st = stage0 + (ci & 1) * STAGE;
+#ifdef NAFAE_EXPERIMENTS
+        if (dbg & 2) {                         // timing experiment: no fragment reads, no MFMAs
+          lds_barrier();
+          continue;
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < 2; t++) {
           bf16x8 bhi[CW], blo[CW];
@@ -609,31 +655,54 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
   const float mvw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
   const float mabs = 6.103515625e-05f * (float)D * mvw;          // 2^-14 * D * max|V| * max|W|
 
-  // ---- exact fp32, phase A: wave w takes columns [w * GC/8, (w+1) * GC/8), BATCH at a time: the W row and the winner's V row
-  // are requested together; every listed candidate within the margin of the best filter value is evaluated.  Columns where
-  // an UNLISTED row could lie within the margin (a contributor's third-best value too close), or that saw a NaN, go on the
-  // slow list.
+  // ---- one thread per column: winner, the other LISTED candidates within the margin of the best filter value, and whether an
+  // UNLISTED row could lie within it (a contributor's third-best value too close) or a NaN was seen (-> slow list)
+  int *rec = reinterpret_cast<int *>(sbest + 8);                   // [GC][10]: i1, ncand, cand[0..7]
+  if (tid < GC) {
+    const int c = tid;
+    Top t[4];
+    int nan = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      t[k] = ctop[k * GC + c];
+      nan |= cnan[k * GC + c];
+    }
+    float bm = -INFINITY;
+    int i1 = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (better(t[k].m1, t[k].i1, bm, i1)) {
+        bm = t[k].m1;
+        i1 = t[k].i1;
+      }
+    const float margin = mabs + 4.8828125e-04f * fabsf(bm);
+    bool slow = nan != 0;
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      slow = slow || !(bm - t[k].m3 >= margin);
+      if (t[k].i1 != i1 && t[k].i1 >= 0 && t[k].i1 < Nb && bm - t[k].m1 < margin) rec[c * 10 + 2 + n++] = t[k].i1;
+      if (t[k].i2 != i1 && t[k].i2 >= 0 && t[k].i2 < Nb && bm - t[k].m2 < margin) rec[c * 10 + 2 + n++] = t[k].i2;
+    }
+    rec[c * 10] = (i1 >= 0 && i1 < Nb) ? i1 : 0;
+    rec[c * 10 + 1] = n;
+    if (slow && qmap[c] >= 0) slowc[atomicAdd(nslow, 1)] = c;
+    if (slow) rec[c * 10 + 1] = -1;
+  }
+  __syncthreads();
+
+  // ---- exact fp32, phase A: wave w takes columns [w * GC/8, (w+1) * GC/8), BATCH at a time: the W row and the winner's V row of
+  // the whole batch are requested together
   constexpr int CPW = GC / 8, BATCH = 8;
   for (int c0 = wave * CPW; c0 < (wave + 1) * CPW; c0 += BATCH) {
     f32x4 wf[BATCH][FR_MAXT], xf[BATCH][FR_MAXT];
-    int qq[BATCH], i1[BATCH];
-    float bm[BATCH];
+    int qq[BATCH], i1[BATCH], nc[BATCH];
 #pragma unroll
     for (int u = 0; u < BATCH; u++) {
       const int c = c0 + u;
       qq[u] = qmap[c];
-      float m = -INFINITY;
-      int ix = 0x7fffffff;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const Top t = ctop[k * GC + c];
-        if (better(t.m1, t.i1, m, ix)) {
-          m = t.m1;
-          ix = t.i1;
-        }
-      }
-      bm[u] = m;
-      i1[u] = (ix >= 0 && ix < Nb) ? ix : 0;
+      i1[u] = rec[c * 10];
+      nc[u] = rec[c * 10 + 1];
       const int q = qq[u] >= 0 ? qq[u] : 0;
 #pragma unroll
       for (int k = 0; k < FR_MAXT; k++) {
@@ -643,18 +712,9 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
         xf[u][k] = d < D ? *reinterpret_cast<const f32x4 *>(Vf + (size_t)i1[u] * D + d) : z;
       }
     }
+    float eb[BATCH];
 #pragma unroll
     for (int u = 0; u < BATCH; u++) {
-      if (qq[u] < 0) continue;                 // (wave-uniform) column beyond the live count
-      const int c = c0 + u;
-      const float margin = mabs + 4.8828125e-04f * fabsf(bm[u]);
-      bool slow = false;
-#pragma unroll
-      for (int k = 0; k < 4; k++) slow = slow || cnan[k * GC + c] != 0 || !(bm[u] - ctop[k * GC + c].m3 >= margin);
-      if (slow) {
-        if (lane == 0) slowc[atomicAdd(nslow, 1)] = c;
-        continue;
-      }
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < FR_MAXT; k++) {
@@ -663,23 +723,24 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
         acc = fmaf(xf[u][k][2], wf[u][k][2], acc);
         acc = fmaf(xf[u][k][3], wf[u][k][3], acc);
       }
+      eb[u] = wave_sum(acc);
+    }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      float eb = acc;
+    for (int u = 0; u < BATCH; u++) {
+      if (qq[u] < 0 || nc[u] < 0) continue;    // (wave-uniform) column beyond the live count, or on the slow list
+      const int c = c0 + u;
+      float e1 = eb[u];
       int ei = i1[u];
-      for (int k = 0; k < 8; k++) {            // the other listed candidates: decided in fp32 where the filter cannot
-        const Top t = ctop[(k >> 1) * GC + c];
-        const float m = (k & 1) ? t.m2 : t.m1;
-        const int ix = (k & 1) ? t.i2 : t.i1;
-        if (ix == i1[u] || ix < 0 || ix >= Nb || !(bm[u] - m < margin)) continue;
+      for (int k = 0; k < nc[u]; k++) {        // (rare) the other listed candidates: decided in fp32 where the filter cannot
+        const int ix = rec[c * 10 + 2 + k];
         const float e = wave_dot<FR_MAXT>(Vf + (size_t)ix * D, wf[u], D, lane);
-        if (better_nan(e, ix, eb, ei)) {
-          eb = e;
+        if (better_nan(e, ix, e1, ei)) {
+          e1 = e;
           ei = ix;
         }
       }
       if (lane == 0) {
-        S_max[(size_t)f * Q + qq[u]] = eb;
+        S_max[(size_t)f * Q + qq[u]] = e1;
         D_ind[(size_t)f * Q + qq[u]] = (int64_t)ei;
       }
     }
@@ -687,6 +748,9 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
   // ---- phase B: the slow list, one column at a time by the WHOLE workgroup: wave w evaluates the rows r = w (mod 8), four
   // rows (eight 16-B loads per lane) in flight, exactly; torch.max's rules decide (NaN first, ties -> smaller index)
   __syncthreads();
+#ifdef NAFAE_EXPERIMENTS
+  if (dbg & 16) return;                        // timing experiment: no slow list
+#endif
   const int ns = nslow[0];
   for (int si = 0; si < ns; si++) {
     const int c = slowc[si];
@@ -723,8 +787,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
           acc = fmaf(xr[j][k][2], wq[k][2], acc);
           acc = fmaf(xr[j][k][3], wq[k][3], acc);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        acc = wave_sum(acc);
         if (r < Nb && better_nan(acc, r, eb, ei)) {
           eb = acc;
           ei = r;
@@ -782,7 +845,9 @@ int launch_few_lt(const float *V, const float *W, const int32_t *ent_len, int F,
     const int rc = allow_dynamic_lds(k, 160 * 1024);
     if (rc != NAFAE_OK) return rc;
   }
-  hipLaunchKernelGGL(sim_few_kernel<LT>, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts);
+  int dbg = 0;
+  if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
+  hipLaunchKernelGGL(sim_few_kernel<LT>, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, dbg);
   return NAFAE_OK;
 }
 
@@ -811,7 +876,7 @@ int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, in
   return launch_status();
 }
 
-// L > 32 live columns: Qh = the caller's bound.  D % 32 == 0, D <= 512, Nb > 64.
+// L > 32 live columns: Qh = the caller's bound.  D % 64 == 0, D <= 512, Nb > 64.
 int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
                   float *S_max, int64_t *D_ind, hipStream_t st) {
   const int nrb = (Nb + 31) / 32;

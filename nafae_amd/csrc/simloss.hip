@@ -478,6 +478,158 @@ __global__ __launch_bounds__(1024) void loss_tail_lds_kernel(const float *__rest
     if (colmap[i % Q] < 0) dS[i] = 0.f;
 }
 
+// The ranking term for ANY number of live slots (C5 with all 512 slots live: F*L floats do not fit one workgroup's LDS, and the
+// global-memory kernel above walks every phase through L2: 78 us).  The term couples the columns of S_max only through
+// Sf[a,s,j] = sum over the slots e of segment j, so it splits by segment: loss_seg_fwd_kernel, one workgroup per segment j,
+// brings S_max[:, slots of j] into LDS (F * len_j floats: 16 KB at most at C5), takes the min / max over the frames of every
+// segment a and writes Sf[:, :, j]; loss_seg_bwd_kernel, again one workgroup per segment j, recomputes the O(F * Na) hinge terms
+// from the complete Sf (every workgroup the same arithmetic in the same order), and turns them into dS for the slots of j.
+// Same arithmetic and summation order as loss_tail_lds_kernel; the kernel boundary is the only synchronisation.
+__device__ __forceinline__ int clamp_len(int l, int Ne) { return l < 0 ? 0 : (l > Ne ? Ne : l); }
+
+__global__ __launch_bounds__(256) void loss_seg_fwd_kernel(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len, int Na,
+                                                           int Ns, int Ne, float *__restrict__ ws, LossWs L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int j = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int Q = Na * Ne, F = Na * Ns;
+  const int lraw = ent_len[j];
+  const int l = clamp_len(lraw, Ne);
+  int off = 0;
+  for (int a = 0; a < j; a++) off += clamp_len(ent_len[a], Ne);
+  {  // this segment's part of the compact live-slot list (what sim_bwd_dv scans)
+    int *live = reinterpret_cast<int *>(ws + L.live);
+    for (int e = tid; e < l; e += nt) live[4 + off + e] = j * Ne + e;
+    if (j == Na - 1 && tid == 0) live[0] = off + l;
+  }
+  float *Sf = ws + L.Sf;
+  if (l == 0) {
+    for (int i = tid; i < F; i += nt) Sf[(size_t)i * Na + j] = 0.f;      // (0 / max(len, 1))
+    return;
+  }
+  float *Sl = sm, *mn = Sl + (size_t)F * l, *mx = mn + (size_t)Na * l;
+  for (int i = tid; i < F * l; i += nt) {
+    const int f = i / l, e = i - f * l;
+    Sl[i] = Sm[(size_t)f * Q + j * Ne + e];
+  }
+  __syncthreads();
+  int *amin = reinterpret_cast<int *>(ws + L.amin), *amax = reinterpret_cast<int *>(ws + L.amax);
+  for (int i = tid; i < Na * l; i += nt) {     // A: min / max over the Ns frames of segment a, first occurrences (model.py:587)
+    const int a = i / l, e = i - a * l;
+    float lo = INFINITY, hi = -INFINITY;
+    int ilo = 0, ihi = 0;
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sl[(a * Ns + s) * l + e];
+      if (v < lo) {
+        lo = v;
+        ilo = s;
+      }
+      if (v > hi) {
+        hi = v;
+        ihi = s;
+      }
+    }
+    mn[i] = lo;
+    mx[i] = hi;
+    const size_t g = (size_t)a * Q + j * Ne + e;
+    ws[L.mn + g] = lo;
+    ws[L.mx + g] = hi;
+    amin[g] = ilo;
+    amax[g] = ihi;
+  }
+  __syncthreads();
+  for (int i = tid; i < F; i += nt) {          // B: Sf[a,s,j] = sum_e S*att / max(len_j,1)   (model.py:588-592)
+    const int a = i / Ns;
+    float acc = 0.f;
+    for (int e = 0; e < l; e++) {
+      const float v = Sl[i * l + e];
+      const float lo = mn[a * l + e], hi = mx[a * l + e];
+      acc += v * ((v - lo) / (hi - lo + EPS));
+    }
+    Sf[(size_t)i * Na + j] = acc / (float)(lraw == 0 ? 1 : lraw);
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_seg_bwd_kernel(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len, int Na,
+                                                           int Ns, int Ne, float Delta, float *__restrict__ dS,
+                                                           float *__restrict__ ws, LossWs L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int j = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int Q = Na * Ne, F = Na * Ns;
+  float *Sf = sm, *fs = Sf + (size_t)F * Na, *cs1 = fs + F, *rs2 = cs1 + F, *dcol = rs2 + F;
+  for (int i = tid; i < F * Na; i += nt) Sf[i] = ws[L.Sf + i];
+  __syncthreads();
+  for (int i = tid; i < F; i += nt) {          // C: frame_score (model.py:603) and the hinge-active counts
+    const int a = i / Ns, s = i - a * Ns;
+    const float diag = Sf[(a * Ns + s) * Na + a];
+    float t1 = 0.f, t2 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k = 0; k < Na; k++) {
+      const float u1 = Sf[(k * Ns + s) * Na + a] - diag + Delta;
+      const float u2 = Sf[(a * Ns + s) * Na + k] - diag + Delta;
+      if (u1 > 0.f) {
+        t1 += u1;
+        c1 += 1.f;
+      }
+      if (u2 > 0.f) {
+        t2 += u2;
+        c2 += 1.f;
+      }
+    }
+    fs[i] = t1 / (float)Na + t2 / (float)Na;
+    cs1[i] = c1;
+    rs2[i] = c2;
+  }
+  __syncthreads();
+  if (j == 0 && tid == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < F; i++) acc += fs[i];
+    ws[L.scal] = acc / (float)F;
+  }
+  if (dS == nullptr) return;
+  const float cN = 10.0f / (float)F / (float)Na;
+  for (int i = tid; i < F; i += nt) {          // E: d(10 * mean fs) / dSf[:, :, j]
+    const int a = i / Ns, s = i - a * Ns;
+    const float v = Sf[i * Na + j];
+    const float g1 = (v - Sf[(j * Ns + s) * Na + j] + Delta > 0.f) ? 1.f : 0.f;
+    const float g2 = (v - Sf[(a * Ns + s) * Na + a] + Delta > 0.f) ? 1.f : 0.f;
+    float g = cN * (g1 + g2);
+    if (a == j) g -= cN * (cs1[i] + rs2[i]);
+    dcol[i] = g;
+  }
+  __syncthreads();
+  const int lraw = ent_len[j];
+  const int l = clamp_len(lraw, Ne);
+  const float inv_div = 1.0f / (float)(lraw == 0 ? 1 : lraw);
+  const int *amin = reinterpret_cast<const int *>(ws + L.amin), *amax = reinterpret_cast<const int *>(ws + L.amax);
+  for (int i = tid; i < Na * l; i += nt) {     // F: back through S*att with the min / max paths (model.py:587-588)
+    const int a = i / l, e = i - a * l;
+    const int q = j * Ne + e;
+    const size_t g = (size_t)a * Q + q;
+    const float lo = ws[L.mn + g], hi = ws[L.mx + g];
+    const float den = hi - lo + EPS;
+    float gmn = 0.f, gmx = 0.f;
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sm[((size_t)a * Ns + s) * Q + q];
+      const float dT = dcol[a * Ns + s] * inv_div;
+      gmn += dT * v * (v - hi - EPS) / (den * den);
+      gmx -= dT * v * (v - lo) / (den * den);
+    }
+    const int ilo = amin[g], ihi = amax[g];
+    for (int s = 0; s < Ns; s++) {
+      const float v = Sm[((size_t)a * Ns + s) * Q + q];
+      const float dT = dcol[a * Ns + s] * inv_div;
+      float gg = dT * ((v - lo) / den + v / den);
+      if (s == ilo) gg += gmn;
+      if (s == ihi) gg += gmx;
+      dS[((size_t)a * Ns + s) * Q + q] = gg;
+    }
+  }
+  const int nm = Ne - l;                       // masked slots of this segment: exactly 0 (model.py:551)
+  for (int i = tid; i < F * nm; i += nt) {
+    const int f = i / nm, e = l + (i - f * nm);
+    dS[(size_t)f * Q + j * Ne + e] = 0.f;
+  }
+}
+
 inline size_t loss_tail_lds_bytes(int Na, int Ns, int Ne, int Lcap) {
   const size_t F = (size_t)Na * Ns, Q = (size_t)Na * Ne;
   return 4 * (F * Lcap + 4 * (size_t)Na * Lcap + 2 * (size_t)Na * Ns * Na + 3 * F + (Na + 1) + Lcap + Q) + 16;
@@ -722,6 +874,95 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
       if (grad_scale) v *= grad_scale[0];
       if (pre_scale) v *= *reinterpret_cast<const f32x4 *>(pre_scale + (size_t)r * D + d);
       *reinterpret_cast<f32x4 *>(dV + (size_t)r * D + d) = v;
+    }
+  }
+}
+
+// The same, one workgroup per (frame, slice of its rows): the frame's live (dS, arg-max, query) triples are read ONCE into LDS
+// and every wave scans them there for each of its rows -- the kernel above re-reads dS[f, :] and D_ind[f, :] from L2 for every
+// one of the frame's Nb rows (19 200 waves x 6 KB at C5 with all 512 slots live: 50 us).  Hits are taken in ascending live-slot
+// order like above, so dV is bit-identical to the per-row kernel's.
+__global__ __launch_bounds__(256) void sim_bwd_dv_frame_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
+                                                               const float *__restrict__ Wm, int F, int Nb, int Q, int D, int RS,
+                                                               int train, int n_centries, const float *__restrict__ ws, LossWs L,
+                                                               const float *__restrict__ pre_scale,
+                                                               const float *__restrict__ grad_scale, float *__restrict__ dV) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *sS = sm;
+  int *sD = reinterpret_cast<int *>(sm + Q), *sQ = sD + Q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.x / RS, part = blockIdx.x - f * RS;
+  const int *live = ws ? reinterpret_cast<const int *>(ws + L.live) : nullptr;
+  const int nq = live ? live[0] : Q;
+  for (int j = tid; j < nq; j += 256) {
+    const int q = live ? live[4 + j] : j;
+    sQ[j] = q;
+    sS[j] = dS[(size_t)f * Q + q];
+    sD[j] = (int)D_ind[(size_t)f * Q + q];
+  }
+  __syncthreads();
+  const int per = (Nb + RS - 1) / RS;
+  const int b_end = (part + 1) * per < Nb ? (part + 1) * per : Nb;
+  for (int b = part * per + wave; b < b_end; b += 4) {
+    const int r = f * Nb + b;
+    f32x4 acc[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < nq; qb += 64) {
+      const int j = qb + lane;
+      const float ds = j < nq ? sS[j] : 0.f;
+      const bool hit = j < nq && sD[j] == b && ds != 0.f;
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float w = __shfl(ds, i);
+        const float *wr = Wm + (size_t)sQ[qb + i] * D;
+#pragma unroll
+        for (int c = 0; c < MAXCH; c++) {
+          const int d = lane * 4 + c * 256;
+          if (d < D) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(wr + d);
+            acc[c] += w * x;
+          }
+        }
+      }
+    }
+    if (train && r < Nb) {  // clustering gradient lands on rows [0, Nb) only (reference quirk)
+      const int *cidx = reinterpret_cast<const int *>(ws + L.cidx);
+      const float cscale = ws[L.scal + 1];
+      const int Nsc = n_centries / Q;
+      const int ne = live ? nq * Nsc : n_centries;
+      for (int tb = 0; tb < ne; tb += 64) {
+        const int e = tb + lane;
+        int t = -1;
+        if (e < ne) t = live ? sQ[e / Nsc] * Nsc + e % Nsc : e;
+        const bool hit = t >= 0 && cidx[t] == r;
+        unsigned long long m = __ballot(hit);
+        while (m) {
+          const int i = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const float *gr = ws + L.dgc + (size_t)__shfl(t, i) * D;
+#pragma unroll
+          for (int c = 0; c < MAXCH; c++) {
+            const int d = lane * 4 + c * 256;
+            if (d < D) {
+              const f32x4 x = *reinterpret_cast<const f32x4 *>(gr + d);
+              acc[c] += cscale * x;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXCH; c++) {
+      const int d = lane * 4 + c * 256;
+      if (d < D) {
+        f32x4 v = acc[c];
+        if (grad_scale) v *= grad_scale[0];
+        if (pre_scale) v *= *reinterpret_cast<const f32x4 *>(pre_scale + (size_t)r * D + d);
+        *reinterpret_cast<f32x4 *>(dV + (size_t)r * D + d) = v;
+      }
     }
   }
 }
@@ -1122,14 +1363,28 @@ int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float 
   int Lcap = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
   if (Lcap < 1) Lcap = 1;
   const size_t tail_lds = loss_tail_lds_bytes(Na, Ns, Ne, Lcap);
-  if (tail_lds <= 150 * 1024) {     // everything on chip (see loss_tail_lds_kernel); else the global-memory version
+  const char *seg_env = nafae::experiment_env("NAFAE_LOSS_SEG");   // experiments build: 1 = always the per-segment kernels
+  if (tail_lds <= 150 * 1024 && !(seg_env && seg_env[0] == '1')) {     // everything on chip (see loss_tail_lds_kernel)
     if (tail_lds > 64 * 1024 &&
         nafae::allow_dynamic_lds(reinterpret_cast<const void *>(loss_tail_lds_kernel), 150 * 1024) != NAFAE_OK)
       return NAFAE_ELAUNCH;
     hipLaunchKernelGGL(loss_tail_lds_kernel, dim3(1), dim3(1024), tail_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws,
                        L, Lcap);
   } else {
-    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
+    const size_t fwd_lds = ((size_t)Na * Ns * Ne + 2 * (size_t)Na * Ne) * sizeof(float);
+    const size_t bwd_lds = ((size_t)Na * Ns * Na + 4 * (size_t)Na * Ns) * sizeof(float);
+    if (fwd_lds <= 150 * 1024 && bwd_lds <= 150 * 1024) {       // one workgroup per segment, two launches
+      if (fwd_lds > 64 * 1024 &&
+          nafae::allow_dynamic_lds(reinterpret_cast<const void *>(loss_seg_fwd_kernel), 150 * 1024) != NAFAE_OK)
+        return NAFAE_ELAUNCH;
+      if (bwd_lds > 64 * 1024 &&
+          nafae::allow_dynamic_lds(reinterpret_cast<const void *>(loss_seg_bwd_kernel), 150 * 1024) != NAFAE_OK)
+        return NAFAE_ELAUNCH;
+      hipLaunchKernelGGL(loss_seg_fwd_kernel, dim3(Na), dim3(256), fwd_lds, S(stream), S_max, ent_len, Na, Ns, Ne, ws, L);
+      hipLaunchKernelGGL(loss_seg_bwd_kernel, dim3(Na), dim3(256), bwd_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
+    } else {
+      hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
+    }
   }
   if (train) {
     if (Ns > 64) return NAFAE_ELIMIT;
@@ -1161,8 +1416,16 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
   if (cluster_rows && !workspace) return NAFAE_EINVAL;
   const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
   const int Q = Na * Ne, R = F * Nb;
-  hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, cluster_rows,
-                     Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
+  const char *dv_env = nafae::experiment_env("NAFAE_BWD_DV");          // experiments build: 1 = the per-row kernel (A/B)
+  if ((size_t)12 * Q <= 64 * 1024 && !(dv_env && dv_env[0] == '1')) {
+    int RS = (Nb + 31) / 32;                   // ~32 rows (8 per wave) per workgroup, at least ~1024 workgroups when F allows
+    while (RS > 1 && (long)F * RS > 2048) RS = (RS + 1) / 2;
+    hipLaunchKernelGGL(sim_bwd_dv_frame_kernel, dim3(F * RS), dim3(256), (size_t)12 * Q, S(stream), dS, D_ind, W, F, Nb, Q, D, RS,
+                       cluster_rows, Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
+  } else {
+    hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, cluster_rows,
+                       Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
+  }
   hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3(Q), dim3(256), (size_t)4 * D * sizeof(float), S(stream), dS, D_ind, V, ent_len, F, Nb,
                      Ne, Q, D, grad_scale, dW);
   return launched();

@@ -713,7 +713,7 @@ inline int fused_route(int F, int Nb, int Na, int Ne, int D, int Qh) {
   if (D % 32 != 0 || D > 512 || Na > NA_MAX || F < 1 || Nb < 1) return 0;
   if ((long)Nb * D >= (1L << 30) || (long)Na * Ne * D >= (1L << 30)) return 0;      // 32-bit element offsets inside the kernels
   if (Qh <= 32) return 1;
-  if (Nb > 64) return 2;
+  if (Nb > 64 && D % 64 == 0) return 2;      // (the frame kernel's staging loop takes the 32-k chunks two at a time)
   return 0;
 }
 }  // namespace

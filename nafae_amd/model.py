@@ -413,9 +413,7 @@ def stepRCNN(im_data, im_info, gt_boxes, num_boxes, ground_model, step_size=64, 
                     stage(i + 1)
                 b = i & 1
                 main.wait_event(landed[b])
-                x = dbuf[b][:e - s]
-                if raw:
-                    x = ops.frames_u8_to_nchw_f32(x)
+                x = dbuf[b][:e - s]              # raw uint8 HWC frames go straight into the first conv layer (-127.5 in-kernel)
                 rois, roi_scores, roi_feats, fc_feats = det(x, info_dev[s:e], gt_boxes, num_boxes)
                 consumed[b] = torch.cuda.Event()
                 consumed[b].record(main)

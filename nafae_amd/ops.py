@@ -134,13 +134,42 @@ def gemm_tn_rows(A, B, rows, count, alpha=1.0, out=None, accumulate=False):
     return out
 
 
-def conv1_3x3_relu(x_nchw, w27, bias):
-    _chk(x_nchw); _chk(w27); _chk(bias)
-    F, C, H, W = x_nchw.shape
-    if C != 3 or w27.numel() != 64 * 27:
+def _frames_kind(x):
+    """(in_kind, F, H, W) of a frame batch for the first conv layer: fp32 NCHW [F,3,H,W] (the reference's hand-over), raw uint8
+    HWC [F,H,W,3] (decoded frames; -127.5 inside the kernel) or fp32 HWC [F,H,W,3] (already normalised: resize output)."""
+    if x.dtype == torch.uint8:
+        _chk(x, torch.uint8, "frames")
+        if x.dim() != 4 or x.shape[3] != 3:
+            raise NafaeOpError("uint8 frames must be [F,H,W,3]")
+        return 1, x.shape[0], x.shape[1], x.shape[2]
+    _chk(x, name="frames")
+    if x.dim() == 4 and x.shape[1] == 3:
+        return 0, x.shape[0], x.shape[2], x.shape[3]
+    if x.dim() == 4 and x.shape[3] == 3:
+        return 2, x.shape[0], x.shape[1], x.shape[2]
+    raise NafaeOpError("frames must be fp32 [F,3,H,W], fp32 [F,H,W,3] or uint8 [F,H,W,3], got %s" % (tuple(x.shape),))
+
+
+def conv1_3x3_relu(x, w27, bias):
+    """First VGG layer from fp32 NCHW frames, or straight from decoded uint8 HWC frames / resized fp32 HWC frames."""
+    _chk(w27); _chk(bias)
+    kind, F, H, W = _frames_kind(x)
+    if w27.numel() != 64 * 27:
         raise NafaeOpError("conv1: expects Cin=3, Cout=64")
-    out = torch.empty(F, H, W, 64, device=x_nchw.device, dtype=torch.float32)
-    _rc(_lib.lib().nafae_conv1_3x3_relu(_p(x_nchw), _p(w27), _p(bias), _p(out), F, H, W, _stream()), "nafae_conv1_3x3_relu")
+    out = torch.empty(F, H, W, 64, device=x.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_conv1_3x3_relu_in(_p(x), kind, _p(w27), _p(bias), _p(out), F, H, W, _stream()), "nafae_conv1_3x3_relu_in")
+    return out
+
+
+def frames_resize_bilinear(frames_u8, Hd, Wd):
+    """uint8 [F,Hs,Ws,3] -> fp32 [F,Hd,Wd,3] minus 127.5 (cv2.resize INTER_LINEAR rule for float images, youcook2.py:212-217)."""
+    _chk(frames_u8, torch.uint8, "frames")
+    F, Hs, Ws, C = frames_u8.shape
+    if C != 3:
+        raise NafaeOpError("frames must be [F,H,W,3]")
+    out = torch.empty(F, Hd, Wd, 3, device=frames_u8.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_frames_resize_bilinear(_p(frames_u8), _p(out), F, Hs, Ws, int(Hd), int(Wd), _stream()),
+        "nafae_frames_resize_bilinear")
     return out
 
 
@@ -343,14 +372,14 @@ def conv3x3_bf16(X, Wt, bias, relu=True, want_f32=False, want_planes=True, use_w
     return cf, (C if want_planes else None)
 
 
-def conv1_3x3_relu_bf16(x_nchw, w27, bias, split=True, il=False):
-    _chk(x_nchw); _chk(w27); _chk(bias)
-    F, C, H, W = x_nchw.shape
-    if C != 3 or w27.numel() != 64 * 27:
+def conv1_3x3_relu_bf16(x, w27, bias, split=True, il=False):
+    _chk(w27); _chk(bias)
+    kind, F, H, W = _frames_kind(x)
+    if w27.numel() != 64 * 27:
         raise NafaeOpError("conv1: expects Cin=3, Cout=64")
-    P = _alloc_planes((F, H, W, 64), x_nchw.device, split, il)
-    _rc(_lib.lib().nafae_conv1_3x3_relu_bf16(_p(x_nchw), _p(w27), _p(bias), _p(P.hi), _p(P.lo), F, H, W, _stream()),
-        "nafae_conv1_3x3_relu_bf16")
+    P = _alloc_planes((F, H, W, 64), x.device, split, il)
+    _rc(_lib.lib().nafae_conv1_3x3_relu_bf16_in(_p(x), kind, _p(w27), _p(bias), _p(P.hi), _p(P.lo), F, H, W, _stream()),
+        "nafae_conv1_3x3_relu_bf16_in")
     return P
 
 

@@ -173,3 +173,140 @@ def test_stepRCNN_stream_vs_oracle_and_unbounded_chunk(gpu):
         assert relerr(fc7.numpy()[same], fc7_o.numpy()[same]) < 1e-4
     # the two chunkings agree with each other up to the stream-K summation order of the conv tiles
     assert relerr(a[2].cpu(), b[2].cpu()) < 1e-5
+
+
+def test_run_entry_trains_validates_and_resumes(gpu, tmp_path, monkeypatch):
+    """`python -m nafae_amd.run --cuda --phase train ...` (the reference's main(), model.py:994-1141) end to end on synthetic loader
+    tuples: two epochs of training with validation, the best checkpoint in the reference's place and format, `.optm/model.best`,
+    then `--phase val` from that checkpoint and `--resume` for one more epoch."""
+    from nafae_amd import run
+    from nafae_amd.config import reset_cfg
+    monkeypatch.chdir(tmp_path)
+    reset_cfg()
+    common = ['--cuda', '--checksession', '0', '--checkbatch', '7', '--Delta', '10', '--vis_lam', '4.13', '--bs', '2', '--sample_num', '3',
+              '--max_ent_len', '4', '--img_h', '96', '--img_w', '96', '--cfg', os.path.join(ROOT, 'cfgs', 'vgg16.yml'),
+              '--set', 'TEST.RPN_POST_NMS_TOP_N', '16']
+    lines = []
+    best = run.main(['--phase', 'train', '--epoch', '2'] + common, synthetic_batches=3, log=lambda *a: lines.append(' '.join(map(str, a))))
+    assert np.isfinite(best)
+    saved = [l for l in lines if l.startswith('saved ')]
+    assert saved and os.path.exists(saved[-1].split(' ', 1)[1])
+    ck = torch.load(saved[-1].split(' ', 1)[1], map_location='cpu')
+    assert set(ck.keys()) == {'session', 'epoch', 'model', 'optimizer', 'pooling_mode'} and len(ck['model']) == 59
+    assert float(open(os.path.join('.optm', 'model.best')).read()) == best
+    ep = ck['epoch']
+    reset_cfg()
+    v = run.main(['--phase', 'val', '--checkepoch', str(ep)] + common, synthetic_batches=2, log=lambda *a: None)
+    assert np.isfinite(v)
+    reset_cfg()
+    lines2 = []
+    run.main(['--phase', 'train', '--resume', '--checkepoch', str(ep), '--epoch', str(ep + 2)] + common, synthetic_batches=2,
+             log=lambda *a: lines2.append(' '.join(map(str, a))))
+    assert any(l.startswith('[train] epoch %d:' % (ep + 1)) for l in lines2) and not any(l.startswith('[train] epoch %d:' % ep) for l in lines2)
+    reset_cfg()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
+def test_frame_ingest_uint8_equals_fp32_path(gpu, precision):
+    """SURVEY.md section 8f.2, device half: decoded uint8 HWC frames go straight into the first conv layer (-127.5 applied to the
+    taps, youcook2.py:212-214 + model.py:692-698) -- no fp32 NCHW copy of the frames.  (float)u8 - 127.5 is exact, so the first
+    layer's output and everything downstream must equal the fp32-NCHW path BIT FOR BIT; also for fp32 HWC input."""
+    from nafae_amd import ops
+    gpu.TEST.RPN_POST_NMS_TOP_N = 16
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 255, (5, 96, 80, 3), generator=g, dtype=torch.int32).to(torch.uint8)
+    nchw = (u8.float() - 127.5).permute(0, 3, 1, 2).contiguous()
+    w = torch.randn(64, 27, generator=g) * 0.02
+    b = torch.randn(64, generator=g) * 0.1
+    u8d, nchwd, wd, bd = u8.cuda(), nchw.cuda(), w.cuda(), b.cuda()
+    hwc = (u8d.float() - 127.5).contiguous()
+    ref = ops.conv1_3x3_relu(nchwd, wd, bd)
+    assert torch.equal(ops.conv1_3x3_relu(u8d, wd, bd), ref) and torch.equal(ops.conv1_3x3_relu(hwc, wd, bd), ref)
+    want = torch.relu(torch.nn.functional.conv2d(nchw, w.view(64, 3, 3, 3), b, padding=1)).permute(0, 2, 3, 1)
+    assert float((ref.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    for split, il in ((True, True), (True, False), (False, False)):
+        p0 = ops.conv1_3x3_relu_bf16(nchwd, wd, bd, split=split, il=il)
+        for x in (u8d, hwc):
+            p1 = ops.conv1_3x3_relu_bf16(x, wd, bd, split=split, il=il)
+            assert torch.equal(p1.hi, p0.hi) and (p0.lo is None or il or torch.equal(p1.lo, p0.lo))
+    # whole detector: raw frames in == fp32 NCHW frames in
+    from nafae_amd import synthetic as syn
+    from nafae_amd.model import default_args
+    from nafae_amd.train import build_model
+    model = build_model(default_args(batch_size=1, sample_num=5, max_ent_len=4), seed=9)
+    fr = model.fasterRCNN
+    fr.precision = precision
+    info = torch.tensor([[96, 80, 1.0]] * 5).cuda()
+    a = fr(nchwd, info, None, None)
+    c = fr(u8d, info, None, None)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[3], c[3])
+
+
+@pytest.mark.parametrize("src,dst", [((120, 160), (96, 80)), ((64, 48), (96, 128)), ((97, 131), (224, 224)), ((224, 224), (224, 224))])
+def test_frame_resize_bilinear_follows_the_half_pixel_rule(gpu, src, dst):
+    """nafae_frames_resize_bilinear restates cv2.resize INTER_LINEAR for float images (youcook2.py:215-217; cv2 itself is absent:
+    UNPINNED against cv2).  torch's bilinear interpolate with align_corners=False implements the same documented rule (source
+    coordinate (d + 0.5) * scale - 0.5 clamped at 0, right / bottom neighbour clamped to the last pixel), so it serves as an
+    independent check, down- and up-scaling, odd sizes, identity."""
+    from nafae_amd import ops
+    g = torch.Generator().manual_seed(src[0] + dst[1])
+    u8 = torch.randint(0, 255, (3, src[0], src[1], 3), generator=g, dtype=torch.int32).to(torch.uint8)
+    out = ops.frames_resize_bilinear(u8.cuda(), dst[0], dst[1]).cpu()
+    ref = torch.nn.functional.interpolate(u8.float().permute(0, 3, 1, 2), size=dst, mode="bilinear", align_corners=False)
+    ref = ref.permute(0, 2, 3, 1) - 127.5
+    assert tuple(out.shape) == (3, dst[0], dst[1], 3)
+    assert float((out - ref).abs().max()) <= 2e-4          # (interpolation weights in fp32, products of 8-bit values)
+    if src == dst:
+        assert torch.equal(out, u8.float() - 127.5)
+
+
+def test_prepare_batch_raw_frames_resizes_on_the_gpu(gpu):
+    from nafae_amd.model import default_args
+    from nafae_amd.run import SyntheticGloVe
+    from nafae_amd.train import combine_batches_synthetic, prepare_batch
+    args = default_args(batch_size=2, sample_num=2, max_ent_len=4, img_h=96, img_w=96)
+    lb = list(combine_batches_synthetic(2, 2, 4, H=120, W=72, seed=3))
+    lb[0] = (lb[0] + 127.5).astype(np.uint8)
+    b = prepare_batch(tuple(lb), SyntheticGloVe(), args, raw_frames=True)
+    assert b.im_data.dtype == torch.float32 and tuple(b.im_data.shape) == (4, 96, 96, 3)      # fp32 HWC: the resize output
+    assert b.im_info.cpu().tolist() == [[96.0, 96.0, 1.0]] * 4
+    lb2 = list(combine_batches_synthetic(2, 2, 4, H=96, W=96, seed=3))
+    lb2[0] = (lb2[0] + 127.5).astype(np.uint8)
+    b2 = prepare_batch(tuple(lb2), SyntheticGloVe(), args, raw_frames=True)
+    assert b2.im_data.dtype == torch.uint8 and tuple(b2.im_data.shape) == (4, 96, 96, 3)      # right size: bytes as they are
+
+
+def test_frame_streamer_feeds_the_pipeline_identically(gpu):
+    """bench.py --stream-input: a different pinned-host uint8 batch every step through the copy stream and two device
+    buffers must train exactly like handing the same batches over one by one, device-resident (pipelined and sequential)."""
+    from nafae_amd.model import default_args
+    from nafae_amd.train import Batch, FrameStreamer, PipelinedTrainer, make_batch, setup_training, train_step
+    Na, Ns, Ne, Nb = 2, 3, 4, 16
+    gpu.TEST.RPN_POST_NMS_TOP_N = Nb
+    args = default_args(batch_size=Na, sample_num=Ns, max_ent_len=Ne, dropout_rate=0.0, Delta=10.0, vis_lam=4.13)
+    tmpl = make_batch(Na, Ns, Ne, H=96, W=96, seed=21, lens=[2, 3])
+    rs = np.random.RandomState(1)
+    host = [torch.from_numpy(rs.randint(0, 255, (Na * Ns, 96, 96, 3)).astype(np.uint8)).pin_memory() for _ in range(3)]
+    n = 5
+    # reference: sequential steps on device-resident uint8 batches
+    model, opt, crit, red = setup_training(args, seed=5)
+    ref = []
+    for k in range(n):
+        b = Batch(host[k % 3].cuda(), tmpl.im_info, tmpl.glove_feats, tmpl.entities_length)
+        ref.append(float(train_step(model, opt, crit, b, args, red)[0]))
+    want = torch.cat([p.detach().reshape(-1) for p in red.params]).clone()
+    for pipelined in (False, True):
+        model2, opt2, crit2, red2 = setup_training(args, seed=5)
+        feeder = FrameStreamer(host, tmpl, "cuda")
+        got = []
+        if pipelined:
+            pipe = PipelinedTrainer(model2, opt2, crit2, args, red2)
+            pipe.submit(feeder.next())
+            for i in range(n):
+                got.append(float(pipe.step(feeder.next() if i + 1 < n else None)[0]))
+        else:
+            for i in range(n):
+                got.append(float(train_step(model2, opt2, crit2, feeder.next(), args, red2)[0]))
+        torch.cuda.synchronize()
+        assert got == ref
+        assert torch.equal(torch.cat([p.detach().reshape(-1) for p in red2.params]), want)
