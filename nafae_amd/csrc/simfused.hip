@@ -38,13 +38,24 @@
 using namespace nafae;
 using namespace nafae_sim;
 
+#ifdef NAFAE_EXPERIMENTS
+// phase stamps (experiments build only; scripts/simfused_stamps.py): wall_clock64() = 100 MHz
+__device__ unsigned long long nafae_simfused_stamps[8 * 8192];
+#define FSTAMP(k)                                                                                    \
+  do {                                                                                               \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                \
+      nafae_simfused_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64();       \
+  } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------- few live columns
 constexpr int FEW_MAXL = 32;    // live columns the kernel takes (accumulators: 2 rows x FEW_MAXL per lane)
-constexpr int FEW_ROWS = 64;    // rows per workgroup: 4 waves x 2 octets x 8 rows
+constexpr int FEW_ROWS = 32;    // rows per workgroup: 2 octet pairs (x 2 K halves = 4 waves)
 constexpr int FEW_NCH = 16;     // 32-k chunks (D <= 512)
-constexpr int FEW_WIN = 8;      // chunks per octet held in registers
 
 // sum over the 8 lanes 8k .. 8k+7; every lane ends with the same bits (fixed tree; + is commutative)
 __device__ __forceinline__ float sum8(float x) {
@@ -80,13 +91,19 @@ __host__ __device__ inline FewLds few_lds(int D, int L, int Na) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// grid F * S workgroups of 256 threads; workgroup (f, s) owns rows [s*64, s*64+64) of frame f.  parts[(f*S + s)*32 + j] =
+// grid F * S workgroups of 256 threads; workgroup (f, s) owns rows [s*32, s*32+32) of frame f.  parts[(f*S + s)*32 + j] =
 // (best value, row as int bits) of live column j over those rows.  LT = live columns rounded up to a multiple of 4 (compile
 // time: the accumulators are registers and the body has no branch; columns L .. LT-1 run on zero-filled W).
+// Wave = (pair p of octets, K half kh): 16 rows x 8 chunks (256 k).  In-kernel stamps of the first form of this kernel (a wave
+// = 16 rows x all 16 chunks, 1.25 waves per SIMD at C5) showed it VALU-bound, not HBM-bound -- the windows took 3 us each at
+// C2's 16.8 MB and at C5's 39 MB alike: one wave alone on a SIMD issues a vector instruction every 4 cycles, two or more
+// every 2.  Splitting K over two waves doubles the waves per SIMD (2.5 at C5), needs no refill (a wave's whole share is
+// requested at once) and leaves the W reads per FMA unchanged; the two K halves are added in a fixed order in the epilogue.
 template <int LT>
-__global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
+__global__ __launch_bounds__(256, 3) void sim_few_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
                                                          const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
-                                                         int D, int S, int Lh, float2 *__restrict__ parts, int dbg) {
+                                                         int D, int S, int Lh, float2 *__restrict__ parts, int *__restrict__ qlist,
+                                                         float *__restrict__ S_max, int64_t *__restrict__ D_ind, int dbg) {
   (void)dbg;   // timing experiments (experiments build): 1 = no arithmetic (loads, staging and the epilogue only)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FewLds lo = few_lds(D, LT, Na);
@@ -99,30 +116,22 @@ __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict
   const int f = blockIdx.x / S, s = blockIdx.x - f * S;
   const int nch = D >> 5;
   const int sl = lane & 7, rg = lane >> 3;     // 16-B slot of the 128-B line, row of the octet
+  const int pr = wave >> 1, kh = wave & 1;     // octet pair, K half
+  FSTAMP(0);
   constexpr int Lp = LT | 1;                   // odd column pitch: the 8 slots of a ds_read_b128 group fall on distinct banks
+  constexpr int NCW = FEW_NCH / 2;             // chunks per wave
 
-  // ---- V: this wave's two octets.  A rolling window of FEW_WIN chunks per octet lives in registers (2 x 8 x 16 B per lane =
-  // 16 KB in flight per wave, 128 KB per CU); the loads of octet 0 go out before anything else.
-  const int row0 = s * FEW_ROWS + wave * 16 + rg, row1 = row0 + 8;
-  const bool oct0 = s * FEW_ROWS + wave * 16 < Nb, oct1 = s * FEW_ROWS + wave * 16 + 8 < Nb;   // wave-uniform
+  // ---- V: this wave's two octets x its 8 chunks.  No branch below: an octet beyond the frame reads the frame's last row (its
+  // rows are dropped by the row < Nb test at the end), a chunk beyond D re-reads the last chunk and meets a zero W row.
+  const int row0 = s * FEW_ROWS + pr * 16 + rg, row1 = row0 + 8;
   const float *v0 = V + ((size_t)f * Nb + (row0 < Nb ? row0 : Nb - 1)) * D + sl * 4;
   const float *v1 = V + ((size_t)f * Nb + (row1 < Nb ? row1 : Nb - 1)) * D + sl * 4;
-  // The loop body has NO branch: an octet beyond the frame reads the frame's last row (its rows are dropped by the row < Nb
-  // test at the end), a chunk beyond D re-reads the last chunk and meets a zero W row.
-  (void)oct0; (void)oct1;
-  f32x4 x0[FEW_WIN], x1[FEW_WIN];
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < FEW_WIN; c++) x0[c] = *reinterpret_cast<const f32x4 *>(v0 + (c < nch ? c : nch - 1) * 32);
-#pragma unroll
-  for (int c = 0; c < FEW_WIN; c++) x1[c] = *reinterpret_cast<const f32x4 *>(v1 + (c < nch ? c : nch - 1) * 32);
-  // (both windows are requested before anything else: the W staging below waits for its own loads with vmcnt, which retires
-  // in order -- with octet 1 requested behind it the kernel paid two HBM round trips back to back before the first FMA)
 
   build_prefix(ent_len, Na, Ne, prefix);
   __syncthreads();
   const int Ql = prefix[Na];
-  int L = Ql < Lh ? Ql : Lh;                   // (columns beyond the caller's bound are reported as NaN by the merge kernel)
+  int L = Ql < Lh ? Ql : Lh;                   // (columns beyond the caller's bound are reported as NaN below)
   L = L < LT ? L : LT;
   if (tid < FEW_MAXL) {
     int q = -1;
@@ -131,63 +140,86 @@ __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict
       q = a * Ne + (tid - prefix[a]);
     }
     qmap[tid] = q;
+    if (blockIdx.x == 0) {                      // the merge kernel's column -> query map (one workgroup writes it)
+      qlist[1 + tid] = q;
+      if (tid == 0) qlist[0] = L;
+    }
   }
   __syncthreads();
+  FSTAMP(1);
+  // ---- ORDER OF THE LOADS.  vmcnt retires in order, so whatever is requested BEFORE the W rows is waited for together with
+  // them.  W rows first (L2 hits), the V share right behind them, wait for W alone, stage it, then consume V as it arrives.
+  constexpr int WPT = (LT * (FEW_NCH * 8) + 255) / 256;          // float4s of W per thread at D = 512
+  f32x4 w[WPT];
+  {
+    const int k4n = D >> 2;
+    const int total = LT * k4n;
+#pragma unroll
+    for (int u = 0; u < WPT; u++) {
+      const int idx = tid + 256 * u;
+      const int j = idx / k4n, k4 = idx - j * k4n;
+      w[u] = (idx < total && j < L) ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)qmap[j] * D + k4 * 4) : z4;
+    }
+  }
+  f32x4 x0[NCW], x1[NCW];
+#pragma unroll
+  for (int u = 0; u < NCW; u++) {
+    const int c = kh * NCW + u;
+    x0[u] = *reinterpret_cast<const f32x4 *>(v0 + (c < nch ? c : nch - 1) * 32);
+  }
+#pragma unroll
+  for (int u = 0; u < NCW; u++) {
+    const int c = kh * NCW + u;
+    x1[u] = *reinterpret_cast<const f32x4 *>(v1 + (c < nch ? c : nch - 1) * 32);
+  }
+  if (s == 0) {      // this frame's masked slots: (0, 0) (model.py:551); live slots beyond the caller's bound: NaN, loud
+    const int Q = Na * Ne;
+    for (int q = tid; q < Q; q += 256) {
+      const int a = q / Ne, e = q - a * Ne;
+      const int l = prefix[a + 1] - prefix[a];
+      if (e >= l) {
+        S_max[(size_t)f * Q + q] = 0.f;
+        D_ind[(size_t)f * Q + q] = 0;
+      } else if (prefix[a] + e >= L) {
+        S_max[(size_t)f * Q + q] = NAN;
+        D_ind[(size_t)f * Q + q] = 0;
+      }
+    }
+  }
   // ---- W (live rows; zeros for the columns L .. LT-1) -> LDS as fp32, image [chunk][slot][column]
   {
     const int k4n = D >> 2;
     const int total = LT * k4n;
-    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
-      f32x4 w[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int idx = i0 + 256 * u;
-        const int j = idx / k4n, k4 = idx - j * k4n;
-        w[u] = (idx < total && j < L) ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)qmap[j] * D + k4 * 4) : z4;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int idx = i0 + 256 * u;
-        const int j = idx / k4n, k4 = idx - j * k4n;
-        if (idx < total) wimg[(size_t)k4 * Lp + j] = w[u];      // k4 = chunk * 8 + slot
-      }
+    for (int u = 0; u < WPT; u++) {
+      const int idx = tid + 256 * u;
+      const int j = idx / k4n, k4 = idx - j * k4n;
+      if (idx < total) wimg[(size_t)k4 * Lp + j] = w[u];        // k4 = chunk * 8 + slot
     }
     if (tid < Lp) wimg[(size_t)(D >> 2) * Lp + tid] = z4;       // the zero row
   }
   __syncthreads();
+  FSTAMP(2);
 
-  // ---- exact fp32 scores: a[o][j] = (even-k, odd-k) partial sums of this lane's k-slots of row o against live column j; two
-  // packed FMAs per (row, column, 16 B)
-  f32x2 a0[LT], a1[LT];
+  // ---- exact fp32 scores: a[o][j] = this lane's k-slots (of this wave's K half) of row o against live column j, one FMA chain
+  // per (row, column).  Steps of 4 columns; the W reads of step t + 1 are issued before the FMAs of step t and a scheduling
+  // fence closes every step (unfenced, hipcc hoisted the LDS reads of all 8 chunks above the arithmetic and spilled them).
+  float a0[LT], a1[LT];
 #pragma unroll
-  for (int j = 0; j < LT; j++) {
-    a0[j] = f32x2{0.f, 0.f};
-    a1[j] = f32x2{0.f, 0.f};
-  }
-  // Steps of 4 columns; the W reads of step t + 1 are issued before the FMAs of step t and a scheduling fence closes every
-  // step (unfenced, hipcc hoisted the LDS reads of a whole 8-chunk window above the arithmetic and spilled them).
-  // The two windows are unrolled (as a loop, the refilled registers were copied into place at the back edge -- behind a
-  // vmcnt(0) that drained the loads the next window needs).
+  for (int j = 0; j < LT; j++) a0[j] = a1[j] = 0.f;
   constexpr int NG = LT / 4;
-#pragma unroll
-  for (int c0 = 0; c0 < FEW_NCH; c0 += FEW_WIN) {
-    if (c0 >= nch) break;
 #ifdef NAFAE_EXPERIMENTS
-    if (dbg & 1) {                             // timing experiment: consume the loads, skip the arithmetic
+  if (dbg & 1) {                               // timing experiment: consume the loads, skip the arithmetic
 #pragma unroll
-      for (int u = 0; u < FEW_WIN; u++) {
-        a0[0] += x0[u].xy;
-        a1[0] += x1[u].xy;
-        int cn = c0 + u + FEW_WIN;
-        cn = cn < nch ? cn : nch - 1;
-        x0[u] = *reinterpret_cast<const f32x4 *>(v0 + cn * 32);
-        x1[u] = *reinterpret_cast<const f32x4 *>(v1 + cn * 32);
-      }
-      continue;
+    for (int u = 0; u < NCW; u++) {
+      a0[0] += x0[u][0];
+      a1[0] += x1[u][0];
     }
+  } else
 #endif
+  {
     auto wptr = [&](int u) {
-      const int c = c0 + u;
+      const int c = kh * NCW + u;
       return wimg + (size_t)(c < nch ? c * 8 + sl : nch * 8) * Lp;   // (a chunk beyond D: the zero row)
     };
     f32x4 wc[4], wn[4];
@@ -197,15 +229,11 @@ __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict
       for (int k = 0; k < 4; k++) wc[k] = wp[k];
     }
 #pragma unroll
-    for (int u = 0; u < FEW_WIN; u++) {
+    for (int u = 0; u < NCW; u++) {
       const f32x4 xa = x0[u], xb = x1[u];
-      int cn = c0 + u + FEW_WIN;               // refill the slot
-      cn = cn < nch ? cn : nch - 1;
-      x0[u] = *reinterpret_cast<const f32x4 *>(v0 + cn * 32);
-      x1[u] = *reinterpret_cast<const f32x4 *>(v1 + cn * 32);
 #pragma unroll
       for (int g = 0; g < NG; g++) {
-        if (g + 1 < NG || u + 1 < FEW_WIN) {
+        if (g + 1 < NG || u + 1 < NCW) {
           const f32x4 *wp = (g + 1 < NG) ? wptr(u) + 4 * (g + 1) : wptr(u + 1);
 #pragma unroll
           for (int k = 0; k < 4; k++) wn[k] = wp[k];
@@ -213,30 +241,38 @@ __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int j = g * 4 + k;
-          a0[j] = __builtin_elementwise_fma(xa.xy, wc[k].xy, a0[j]);
-          a0[j] = __builtin_elementwise_fma(xa.zw, wc[k].zw, a0[j]);
-          a1[j] = __builtin_elementwise_fma(xb.xy, wc[k].xy, a1[j]);
-          a1[j] = __builtin_elementwise_fma(xb.zw, wc[k].zw, a1[j]);
+          a0[j] = dot4(xa, wc[k], a0[j]);
+          a1[j] = dot4(xb, wc[k], a1[j]);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) wc[k] = wn[k];
+        // (the empty asm takes the step's eight accumulators as in/out operands: without that data dependence hipcc SANK the
+        // FMAs out of their steps and ran the block column by column -- every column's W values of all 8 chunks, read step by
+        // step, were spilled: 128 B of scratch per column)
+        asm volatile("" : "+v"(a0[g * 4]), "+v"(a0[g * 4 + 1]), "+v"(a0[g * 4 + 2]), "+v"(a0[g * 4 + 3]), "+v"(a1[g * 4]),
+                     "+v"(a1[g * 4 + 1]), "+v"(a1[g * 4 + 2]), "+v"(a1[g * 4 + 3])
+                     :
+                     : "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
-  // ---- rows x columns of this wave -> LDS (one lane per row writes), then column-wise: lane (j, half) scans 8 rows
+  FSTAMP(3);
+  // ---- rows x columns of this wave -> LDS (one lane per row writes); then, per octet pair, lane (j, half) adds the two K halves
+  // (kh = 0 first) and scans its 8 rows
   float *ws = scr + wave * 16 * FEW_MAXL;
 #pragma unroll
   for (int j = 0; j < LT; j++) {
-    const float s0 = sum8(a0[j].x + a0[j].y), s1 = sum8(a1[j].x + a1[j].y);
+    const float s0 = sum8(a0[j]), s1 = sum8(a1[j]);
     if (sl == 0) {
       ws[rg * FEW_MAXL + j] = s0;
       ws[(8 + rg) * FEW_MAXL + j] = s1;
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own LDS writes have completed (same-wave hand-off)
-  __builtin_amdgcn_wave_barrier();
-  {
+  FSTAMP(4);
+  __syncthreads();
+  if (wave < 2) {                              // wave p finishes octet pair p
+    const float *wa = scr + (2 * wave) * 16 * FEW_MAXL, *wb = wa + 16 * FEW_MAXL;
     const int j = lane & 31, half = lane >> 5;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -244,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict
 #pragma unroll
       for (int r = 0; r < 8; r++) {
         const int row = s * FEW_ROWS + wave * 16 + half * 8 + r;
-        const float v = ws[(half * 8 + r) * FEW_MAXL + j];
+        const float v = wa[(half * 8 + r) * FEW_MAXL + j] + wb[(half * 8 + r) * FEW_MAXL + j];
         if (row < Nb && better_nan(v, row, bv, bi)) {
           bv = v;
           bi = row;
@@ -259,50 +295,33 @@ __global__ __launch_bounds__(256, 2) void sim_few_kernel(const float *__restrict
     }
     if (lane < 32) wbest[wave * FEW_MAXL + lane] = make_float2(bv, __int_as_float(bi));
   }
+  FSTAMP(5);
   __syncthreads();
   if (tid < L) {
     float2 b = wbest[tid];
-#pragma unroll
-    for (int w = 1; w < 4; w++) {
-      const float2 o = wbest[w * FEW_MAXL + tid];
-      if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
-    }
+    const float2 o = wbest[FEW_MAXL + tid];
+    if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
     parts[((size_t)f * S + s) * FEW_MAXL + tid] = b;
   }
+  FSTAMP(6);
 }
 
-__global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__restrict__ parts, const int32_t *__restrict__ ent_len,
-                                                            int F, int Nb, int Na, int Ne, int S, int Lh,
-                                                            float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
-  __shared__ int prefix[NA_MAX + 1];
-  build_prefix(ent_len, Na, Ne, prefix);
-  __syncthreads();
-  const int Q = Na * Ne;
-  const long total = (long)F * Q;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int f = (int)(idx / Q), q = (int)(idx - (long)f * Q);
-    const int a = q / Ne, e = q - a * Ne;
-    if (e >= prefix[a + 1] - prefix[a]) {      // masked slot: the whole S_ column is 0 (model.py:551) -> (0, 0)
-      S_max[idx] = 0.f;
-      D_ind[idx] = 0;
-      continue;
-    }
-    const int j = prefix[a] + e;
-    if (j >= Lh) {                              // the caller's bound on the live columns was too small: loud, not truncated
-      S_max[idx] = NAN;
-      D_ind[idx] = 0;
-      continue;
-    }
-    float2 b = parts[((size_t)f * S) * FEW_MAXL + j];
-    for (int s = 1; s < S; s++) {
-      const float2 o = parts[((size_t)f * S + s) * FEW_MAXL + j];
-      if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
-    }
-    int bi = __float_as_int(b.y);
-    bi = bi < 0 ? 0 : (bi >= Nb ? Nb - 1 : bi);
-    S_max[idx] = b.x;
-    D_ind[idx] = (int64_t)bi;
+// one thread per (frame, live column): the best of the frame's S workgroups (ties -> smaller row, NaN first: torch.max's rules)
+__global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__restrict__ parts, const int *__restrict__ qlist, int F, int Nb,
+                                                            int Q, int S, float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int f = t / FEW_MAXL, j = t - f * FEW_MAXL;
+  if (f >= F || j >= qlist[0]) return;
+  const int q = qlist[1 + j];
+  float2 b = parts[((size_t)f * S) * FEW_MAXL + j];
+  for (int s = 1; s < S; s++) {
+    const float2 o = parts[((size_t)f * S + s) * FEW_MAXL + j];
+    if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
   }
+  int bi = __float_as_int(b.y);
+  bi = bi < 0 ? 0 : (bi >= Nb ? Nb - 1 : bi);
+  S_max[(size_t)f * Q + q] = b.x;
+  D_ind[(size_t)f * Q + q] = (int64_t)bi;
 }
 
 // ---------------------------------------------------------------------------------------------------- many live columns
@@ -433,6 +452,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
   __syncthreads();
   const float *Vf = V + (size_t)f * Nb * D;
   const int nsuper = (Nb + RT - 1) / RT;
+  FSTAMP(0);
 
   Top top[CW];
   bool nanf[CW];
@@ -447,6 +467,10 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
 
   if (wave >= 4) {
     // ================================================================ staging waves
+#ifdef NAFAE_EXPERIMENTS
+    if (dbg & 32) __builtin_amdgcn_s_setprio(1);       // timing experiment: staging waves win the issue arbitration
+    if (dbg & 128) __builtin_amdgcn_s_setprio(3);
+#endif
     const int ct = tid - 256;
     const int tr = ct >> 3, ts = ct & 7;       // thread (tr, ts) moves 16 B (4 k) of tile row tr + 32 i per slot
     const int swz = ((tr >> 1) & 7) ^ ((tr & 1) << 2);   // (+ the row's parity on bit 2: rows 2m, 2m+1 write different 64-B halves)
@@ -528,6 +552,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       convert(stage0, S0{});
       issue(clampc(2), S0{});
       lds_barrier();
+      FSTAMP(1);
       // trip ci (the MFMA waves compute chunk ci): convert chunk ci + 1 into the other stage, request chunk ci + 3
       for (int ci = 0; ci < nch; ci += 2) {
         convert(stage0 + STAGE, S1{});
@@ -537,9 +562,13 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
         issue(clampc(ci + 4), S0{});
         lds_barrier();
       }
+      FSTAMP(2);
     }
   } else {
     // ================================================================ MFMA waves
+#ifdef NAFAE_EXPERIMENTS
+    if (dbg & 64) __builtin_amdgcn_s_setprio(1);        // timing experiment: MFMA waves win the issue arbitration
+#endif
     const int aswz = ((lr >> 1) & 7) ^ ((lr & 1) << 2);
     const int a_base = (rh * RW * 32 + lr) * 128;
     const int b_base = (RT + ch * CW * 32 + lr) * 128;
@@ -558,6 +587,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
           for (int r = 0; r < 16; r++) acc[rb][cb][r] = 0.f;
       if (rt > 0) lds_barrier();
       lds_barrier();                           // chunk 0 is in stage 0
+      FSTAMP(1);
       for (int ci = 0; ci < nch; ci++) {
         const unsigned char *st = stage0 + (ci & 1) * STAGE;
 #ifdef NAFAE_EXPERIMENTS
@@ -588,6 +618,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
         }
         lds_barrier();
       }
+      FSTAMP(2);
       // ---- this lane's column: 16 rows per 32-row block, ascending.  Element id = rb * 16 + r; NaN / Inf anywhere in the column
       // makes nanacc NaN (x * 0), which sends the column to the exact slow path.
 #pragma unroll
@@ -621,6 +652,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
   }
 
   // ---- the four contributors of a column (row half x 16-row lane half) leave their statistics in LDS: 8 listed candidates
+  FSTAMP(3);
   __syncthreads();                             // the stages are free: reuse them as scratch
   Top *ctop = reinterpret_cast<Top *>(smem);                       // [4 contributors][GC]
   int *cnan = reinterpret_cast<int *>(smem + 4 * GC * sizeof(Top));   // [4][GC]
@@ -691,6 +723,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
   }
   __syncthreads();
 
+  FSTAMP(4);
   // ---- exact fp32, phase A: wave w takes columns [w * GC/8, (w+1) * GC/8), BATCH at a time: the W row and the winner's V row of
   // the whole batch are requested together
   constexpr int CPW = GC / 8, BATCH = 8;
@@ -745,8 +778,9 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       }
     }
   }
-  // ---- phase B: the slow list, one column at a time by the WHOLE workgroup: wave w evaluates the rows r = w (mod 8), four
-  // rows (eight 16-B loads per lane) in flight, exactly; torch.max's rules decide (NaN first, ties -> smaller index)
+  FSTAMP(5);
+  // ---- phase B: the slow list, one column at a time by the WHOLE workgroup: wave w evaluates the rows r = w (mod 8), eight
+  // rows (sixteen 16-B loads per lane) in flight, exactly; torch.max's rules decide (NaN first, ties -> smaller index)
   __syncthreads();
 #ifdef NAFAE_EXPERIMENTS
   if (dbg & 16) return;                        // timing experiment: no slow list
@@ -764,10 +798,10 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
     }
     float eb = -INFINITY;
     int ei = 0x7fffffff;
-    for (int r0 = wave; r0 < Nb; r0 += 32) {
-      f32x4 xr[4][FR_MAXT];
+    for (int r0 = wave; r0 < Nb; r0 += 64) {
+      f32x4 xr[8][FR_MAXT];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < 8; j++) {
         const int r = r0 + 8 * j < Nb ? r0 + 8 * j : Nb - 1;
 #pragma unroll
         for (int k = 0; k < FR_MAXT; k++) {
@@ -777,7 +811,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < 8; j++) {
         const int r = r0 + 8 * j;
         float acc = 0.f;
 #pragma unroll
@@ -808,6 +842,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
     }
     __syncthreads();
   }
+  FSTAMP(6);
 }
 
 template <int RW, int CW>
@@ -832,12 +867,12 @@ int launch_frame(const float *V, const float *W, const int32_t *ent_len, int F, 
 
 namespace nafae_sim {
 
-// L <= 32 live columns (the caller's bound), D % 32 == 0, D <= 512.  workspace: F * ceil(Nb / 64) * 32 * 8 bytes.
-int64_t few_workspace_bytes(int F, int Nb) { return (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * FEW_MAXL * 8; }
+// L <= 32 live columns (the caller's bound), D % 32 == 0, D <= 512.  workspace: F * ceil(Nb / 64) * 32 * 8 + 256 bytes.
+int64_t few_workspace_bytes(int F, int Nb) { return (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * FEW_MAXL * 8 + 256; }
 
 template <int LT>
 int launch_few_lt(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float2 *parts,
-                  hipStream_t st) {
+                  int *qlist, float *S_max, int64_t *D_ind, hipStream_t st) {
   const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
   const FewLds lo = few_lds(D, LT, Na);
   const void *k = reinterpret_cast<const void *>(sim_few_kernel<LT>);
@@ -847,7 +882,8 @@ int launch_few_lt(const float *V, const float *W, const int32_t *ent_len, int F,
   }
   int dbg = 0;
   if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
-  hipLaunchKernelGGL(sim_few_kernel<LT>, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, dbg);
+  hipLaunchKernelGGL(sim_few_kernel<LT>, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
+                     S_max, D_ind, dbg);
   return NAFAE_OK;
 }
 
@@ -855,24 +891,22 @@ int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, in
                int64_t *D_ind, void *workspace, hipStream_t st) {
   const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
   float2 *parts = reinterpret_cast<float2 *>(workspace);
+  int *qlist = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)F * S * FEW_MAXL * 8);
   int rc = NAFAE_ELIMIT;
   switch ((Lh + 3) / 4) {
-    case 1: rc = launch_few_lt<4>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
-    case 2: rc = launch_few_lt<8>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
-    case 3: rc = launch_few_lt<12>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
-    case 4: rc = launch_few_lt<16>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
-    case 5: rc = launch_few_lt<20>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
-    case 6: rc = launch_few_lt<24>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
-    case 7: rc = launch_few_lt<28>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
-    case 8: rc = launch_few_lt<32>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, st); break;
+    case 1: rc = launch_few_lt<4>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
+    case 2: rc = launch_few_lt<8>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
+    case 3: rc = launch_few_lt<12>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
+    case 4: rc = launch_few_lt<16>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
+    case 5: rc = launch_few_lt<20>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
+    case 6: rc = launch_few_lt<24>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
+    case 7: rc = launch_few_lt<28>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
+    case 8: rc = launch_few_lt<32>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
     default: break;
   }
   if (rc != NAFAE_OK) return rc;
-  const long total = (long)F * Na * Ne;
-  long blocks = (total + 255) / 256;
-  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-  hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, parts, ent_len, F, Nb, Na, Ne, S, Lh, S_max,
-                     D_ind);
+  hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)((F * FEW_MAXL + 255) / 256)), dim3(256), 0, st, parts, qlist, F, Nb,
+                     Na * Ne, S, S_max, D_ind);
   return launch_status();
 }
 
@@ -895,3 +929,9 @@ int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F,
 }
 
 }  // namespace nafae_sim
+
+#ifdef NAFAE_EXPERIMENTS
+extern "C" int nafae_simfused_debug_stamps(unsigned long long *out_host, int n) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(nafae_simfused_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#endif

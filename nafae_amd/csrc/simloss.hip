@@ -813,28 +813,42 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
   // in the workspace instead of all Q columns (C5: 17 of 512)
   const int *live = ws ? reinterpret_cast<const int *>(ws + L.live) : nullptr;
   const int nq = live ? live[0] : Q;
-  for (int qb = 0; qb < nq; qb += 64) {
-    const int j = qb + lane;
-    bool hit = false;
-    float ds = 0.f;
-    int q = 0;
-    if (j < nq) {
-      q = live ? live[4 + j] : j;
-      ds = dS[(size_t)f * Q + q];
-      hit = ((int)D_ind[(size_t)f * Q + q] == b) && ds != 0.f;
-    }
-    unsigned long long m = __ballot(hit);
-    while (m) {
-      const int i = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const float w = __shfl(ds, i);
-      const float *wr = Wm + (size_t)__shfl(q, i) * D;
+  // The (dS, arg-max) entries of up to 512 live slots are requested together before the first ballot (one dependent L2 round
+  // trip per 512 slots instead of one per 64: with all 512 slots of C5 live the row spent eight of them back to back).
+  for (int qb0 = 0; qb0 < nq; qb0 += 512) {
+    float dsv[8];
+    int qv[8];
+    bool hv[8];
 #pragma unroll
-      for (int c = 0; c < MAXCH; c++) {
-        const int d = lane * 4 + c * 256;
-        if (d < D) {
-          const f32x4 x = *reinterpret_cast<const f32x4 *>(wr + d);
-          acc[c] += w * x;
+    for (int u = 0; u < 8; u++) {
+      const int j = qb0 + u * 64 + lane;
+      dsv[u] = 0.f;
+      qv[u] = 0;
+      hv[u] = false;
+      if (j < nq) {
+        qv[u] = live ? live[4 + j] : j;
+        dsv[u] = dS[(size_t)f * Q + qv[u]];
+        hv[u] = ((int)D_ind[(size_t)f * Q + qv[u]] == b) && dsv[u] != 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (qb0 + u * 64 >= nq) break;
+      const float ds = dsv[u];
+      const int q = qv[u];
+      unsigned long long m = __ballot(hv[u]);
+      while (m) {
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float w = __shfl(ds, i);
+        const float *wr = Wm + (size_t)__shfl(q, i) * D;
+#pragma unroll
+        for (int c = 0; c < MAXCH; c++) {
+          const int d = lane * 4 + c * 256;
+          if (d < D) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(wr + d);
+            acc[c] += w * x;
+          }
         }
       }
     }
@@ -874,95 +888,6 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
       if (grad_scale) v *= grad_scale[0];
       if (pre_scale) v *= *reinterpret_cast<const f32x4 *>(pre_scale + (size_t)r * D + d);
       *reinterpret_cast<f32x4 *>(dV + (size_t)r * D + d) = v;
-    }
-  }
-}
-
-// The same, one workgroup per (frame, slice of its rows): the frame's live (dS, arg-max, query) triples are read ONCE into LDS
-// and every wave scans them there for each of its rows -- the kernel above re-reads dS[f, :] and D_ind[f, :] from L2 for every
-// one of the frame's Nb rows (19 200 waves x 6 KB at C5 with all 512 slots live: 50 us).  Hits are taken in ascending live-slot
-// order like above, so dV is bit-identical to the per-row kernel's.
-__global__ __launch_bounds__(256) void sim_bwd_dv_frame_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
-                                                               const float *__restrict__ Wm, int F, int Nb, int Q, int D, int RS,
-                                                               int train, int n_centries, const float *__restrict__ ws, LossWs L,
-                                                               const float *__restrict__ pre_scale,
-                                                               const float *__restrict__ grad_scale, float *__restrict__ dV) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float *sS = sm;
-  int *sD = reinterpret_cast<int *>(sm + Q), *sQ = sD + Q;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = blockIdx.x / RS, part = blockIdx.x - f * RS;
-  const int *live = ws ? reinterpret_cast<const int *>(ws + L.live) : nullptr;
-  const int nq = live ? live[0] : Q;
-  for (int j = tid; j < nq; j += 256) {
-    const int q = live ? live[4 + j] : j;
-    sQ[j] = q;
-    sS[j] = dS[(size_t)f * Q + q];
-    sD[j] = (int)D_ind[(size_t)f * Q + q];
-  }
-  __syncthreads();
-  const int per = (Nb + RS - 1) / RS;
-  const int b_end = (part + 1) * per < Nb ? (part + 1) * per : Nb;
-  for (int b = part * per + wave; b < b_end; b += 4) {
-    const int r = f * Nb + b;
-    f32x4 acc[MAXCH];
-#pragma unroll
-    for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int qb = 0; qb < nq; qb += 64) {
-      const int j = qb + lane;
-      const float ds = j < nq ? sS[j] : 0.f;
-      const bool hit = j < nq && sD[j] == b && ds != 0.f;
-      unsigned long long m = __ballot(hit);
-      while (m) {
-        const int i = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const float w = __shfl(ds, i);
-        const float *wr = Wm + (size_t)sQ[qb + i] * D;
-#pragma unroll
-        for (int c = 0; c < MAXCH; c++) {
-          const int d = lane * 4 + c * 256;
-          if (d < D) {
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(wr + d);
-            acc[c] += w * x;
-          }
-        }
-      }
-    }
-    if (train && r < Nb) {  // clustering gradient lands on rows [0, Nb) only (reference quirk)
-      const int *cidx = reinterpret_cast<const int *>(ws + L.cidx);
-      const float cscale = ws[L.scal + 1];
-      const int Nsc = n_centries / Q;
-      const int ne = live ? nq * Nsc : n_centries;
-      for (int tb = 0; tb < ne; tb += 64) {
-        const int e = tb + lane;
-        int t = -1;
-        if (e < ne) t = live ? sQ[e / Nsc] * Nsc + e % Nsc : e;
-        const bool hit = t >= 0 && cidx[t] == r;
-        unsigned long long m = __ballot(hit);
-        while (m) {
-          const int i = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          const float *gr = ws + L.dgc + (size_t)__shfl(t, i) * D;
-#pragma unroll
-          for (int c = 0; c < MAXCH; c++) {
-            const int d = lane * 4 + c * 256;
-            if (d < D) {
-              const f32x4 x = *reinterpret_cast<const f32x4 *>(gr + d);
-              acc[c] += cscale * x;
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < MAXCH; c++) {
-      const int d = lane * 4 + c * 256;
-      if (d < D) {
-        f32x4 v = acc[c];
-        if (grad_scale) v *= grad_scale[0];
-        if (pre_scale) v *= *reinterpret_cast<const f32x4 *>(pre_scale + (size_t)r * D + d);
-        *reinterpret_cast<f32x4 *>(dV + (size_t)r * D + d) = v;
-      }
     }
   }
 }
@@ -1416,16 +1341,8 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
   if (cluster_rows && !workspace) return NAFAE_EINVAL;
   const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
   const int Q = Na * Ne, R = F * Nb;
-  const char *dv_env = nafae::experiment_env("NAFAE_BWD_DV");          // experiments build: 1 = the per-row kernel (A/B)
-  if ((size_t)12 * Q <= 64 * 1024 && !(dv_env && dv_env[0] == '1')) {
-    int RS = (Nb + 31) / 32;                   // ~32 rows (8 per wave) per workgroup, at least ~1024 workgroups when F allows
-    while (RS > 1 && (long)F * RS > 2048) RS = (RS + 1) / 2;
-    hipLaunchKernelGGL(sim_bwd_dv_frame_kernel, dim3(F * RS), dim3(256), (size_t)12 * Q, S(stream), dS, D_ind, W, F, Nb, Q, D, RS,
-                       cluster_rows, Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
-  } else {
-    hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, cluster_rows,
-                       Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
-  }
+  hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, cluster_rows,
+                     Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
   hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3(Q), dim3(256), (size_t)4 * D * sizeof(float), S(stream), dS, D_ind, V, ent_len, F, Nb,
                      Ne, Q, D, grad_scale, dW);
   return launched();

@@ -355,8 +355,8 @@ def test_stepRCNN_streamed_host_input(gpu):
 
 
 def test_prepare_batch_raw_frames_equals_host_preprocessing(gpu):
-    """prepare_batch (model.py:684-747): uint8 frames normalised on the GPU == the reference's host-side float path, and the
-    resulting Batch drives a training step."""
+    """prepare_batch (model.py:684-747): decoded uint8 frames handed to the GPU as they are (the -127.5 and the HWC reading happen
+    inside the first conv layer) == the reference's host-side float path: same values, and the two Batches train identically."""
     import argparse
     from nafae_amd.model import default_args
     from nafae_amd.train import combine_batches_synthetic, prepare_batch, setup_training, train_step
@@ -368,10 +368,13 @@ def test_prepare_batch_raw_frames_equals_host_preprocessing(gpu):
     bf = prepare_batch(tuple(lb), glove, args)
     u8 = (lb[0] + 127.5).astype(np.uint8)
     br = prepare_batch((u8,) + tuple(lb[1:]), glove, args, raw_frames=True)
-    assert torch.equal(bf.im_data, br.im_data) and torch.equal(bf.glove_feats, br.glove_feats)
-    model, opt, crit, red = setup_training(args, seed=3)
-    loss = train_step(model, opt, crit, br, args, red)[0]
-    assert np.isfinite(float(loss))
+    assert br.im_data.dtype == torch.uint8 and tuple(br.im_data.shape) == (4, 224, 224, 3)
+    assert torch.equal(bf.im_data, (br.im_data.float() - 127.5).permute(0, 3, 1, 2)) and torch.equal(bf.glove_feats, br.glove_feats)
+    losses = []
+    for b in (br, bf):
+        model, opt, crit, red = setup_training(args, seed=3)
+        losses.append(float(train_step(model, opt, crit, b, args, red)[0]))
+    assert np.isfinite(losses[0]) and losses[0] == losses[1]
 
 
 def test_train_epoch_pipelined_equals_sequential(gpu):

@@ -203,7 +203,9 @@ def test_run_entry_trains_validates_and_resumes(gpu, tmp_path, monkeypatch):
     run.main(['--phase', 'train', '--resume', '--checkepoch', str(ep), '--epoch', str(ep + 2)] + common, synthetic_batches=2,
              log=lambda *a: lines2.append(' '.join(map(str, a))))
     assert any(l.startswith('[train] epoch %d:' % (ep + 1)) for l in lines2) and not any(l.startswith('[train] epoch %d:' % ep) for l in lines2)
-    reset_cfg()
+    reset_cfg()                                    # leave the module's cfg as the `gpu` fixture set it up
+    from nafae_amd.config import cfg_from_file
+    cfg_from_file(os.path.join(ROOT, 'cfgs', 'vgg16.yml'))
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
