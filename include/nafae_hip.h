@@ -256,14 +256,27 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
 /* The production form of the call above (the host mirror uses this one), in terms of the F whole frames a caller holds
  * (F = Na*Ns on one GPU; a rank's share in the frame-sharded multi-GPU mode, where Na stays the GLOBAL segment count):
  *   - contracts V only against the LIVE query slots (e < ent_len[a]); masked slots are written as (0, 0);
- *   - bf16x3 arithmetic on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate) with a top-2 per 32-row block;
- *     wherever a runner-up lies within 2^-15*D + 2^-11*|score| of the winner, the candidates are re-evaluated with exact
- *     fp32 FMA dot products, so D_ind is decided in fp32 where bf16x3 cannot separate them (precondition for the bound:
- *     |V|, |W| <= 1, which tanh outputs satisfy; model.py:628,642);
+ *   - routing (simmax.hip fused_route / make_plan), Qh = the live-column count the launch is sized for
+ *     (max_live_cols if >= 0, else Na*Ne):
+ *       Qh <= 32, D % 32 == 0, D <= 512        exact-fp32 few-column kernel + merge (simfused.hip sim_few_kernel): every
+ *                                                score is a k-ordered fp32 FMA chain, no filter, no margin;
+ *       Qh > 32, Nb > 64, D % 64 == 0, D <= 512 one launch, one workgroup per frame (sim_frame_kernel): bf16x3 products on the
+ *                                                bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate) as a FILTER that
+ *                                                keeps the best three rows per contributor; the winner and every listed row within
+ *                                                margin = 2^-14 * D * max|V_frame| * max|W_group| + 2^-11 * |score| of it are
+ *                                                re-evaluated with exact fp32 dot products; a column whose unlisted rows could lie
+ *                                                inside the margin, or that saw a NaN/Inf product, is evaluated exactly over all
+ *                                                Nb rows.  The maxima are MEASURED while staging: no precondition on |V|, |W|;
+ *       other shapes with D % 32 == 0, D <= 1024, Na <= 2048: the second-generation tile kernels (simmax.hip; margin
+ *                                                2^-15 * D + 2^-11 * |score|, which assumes |V|, |W| <= 1 -- tanh outputs,
+ *                                                model.py:628,642);
+ *       anything else (D % 4 == 0): the exact-fp32 kernel of nafae_sim_max_fwd_frames.
+ *     In every route D_ind follows torch.max: the first maximal row, a NaN score is the maximum (first NaN wins);
  *   - max_live_cols: an UPPER BOUND on the number of live slots, sum_a min(max(ent_len[a],0),Ne), if the host knows it
- *     (it sizes the launch; a bound that is too small loses columns), or -1 = unknown (sized for all Na*Ne);
- *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes, no initialisation needed.
- * Shapes it does not take (D % 32 != 0, D > 1024, Na > 2048) run the exact-fp32 kernel of nafae_sim_max_fwd_frames.  */
+ *     (it sizes the launch), or -1 = unknown (sized for all Na*Ne).  A bound that is too small is a caller error that is
+ *     made visible: the live columns beyond it come back as (NaN, 0), never as a plausible wrong maximum;
+ *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes (the largest any route needs), no initialisation
+ *     needed.  */
 int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D);
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
                          int max_live_cols, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
