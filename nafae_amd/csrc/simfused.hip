@@ -2,15 +2,16 @@
 // 580-583, 610-612), third generation, gfx950.  Two kernels that replace simmax.hip's part / tile + finish pairs where they apply
 // (simmax.hip's make_plan routes; its kernels stay as the fallback for the shapes these do not take):
 //
-//   sim_few_kernel (+ sim_few_merge_kernel)   L <= 32 live query slots -- every BASELINE configuration with entity lengths from the
-//       data set's histogram (C2: 19 of 128 slots live, C5: 17 of 512).  The problem is then a pure stream of V (C5: 39 MB
-//       against 0.7 GFLOP), so the kernel has no filter and no second pass over V at all: every (proposal, live query) score is
-//       an EXACT fp32 FMA dot product on the vector ALU while the rows stream through registers -- each wave owns 16 rows (two
-//       octets; a load instruction covers 8 rows x one full 128-B line), W (live rows only) sits in LDS as fp32 in a
-//       conflict-free [chunk][slot][column] image, one ds_read_b128 of W feeds 8 FMAs.  A workgroup owns 64 consecutive rows of
-//       ONE frame and leaves its per-column (max, arg-max) in the workspace; the merge kernel takes the best of a frame's
-//       workgroups (ties -> smaller index, NaN -> first NaN: torch.max's rules) and zero-fills the masked slots.
-//       All of V is requested within the first microsecond (320 workgroups x 4 waves x 32 KB in flight at C5).
+//   sim_live_kernel / sim_few_kernel (+ sim_few_merge_kernel)   L <= 32 live query slots -- every BASELINE configuration with
+//       entity lengths from the data set's histogram (C2: 19 of 128 slots live, C5: 17 of 512).  The problem is then a pure
+//       stream of V (C5: 39 MB against 0.7 GFLOP), so there is no filter and no second pass over V at all: every (proposal,
+//       live query) score is an fp32 dot product computed while the rows stream through registers.  A workgroup owns 32
+//       consecutive rows of ONE frame and leaves its per-column (max, arg-max) in the workspace; the merge kernel takes the
+//       best of a frame's workgroups (ties -> smaller index, NaN -> first NaN: torch.max's rules) and the masked slots are
+//       zero-filled.  All of V is requested within the first two microseconds.
+//         sim_live_kernel (D % 128 == 0): fp32 MFMA, a wave = 32 rows x a quarter of K (see the kernel);
+//         sim_few_kernel<LT> (other D % 32 == 0): vector-ALU FMA chains, a wave = 16 rows x half of K, W (live rows only) in
+//         LDS as fp32 in a conflict-free [chunk][slot][column] image, one ds_read_b128 of W feeds 8 FMAs.
 //
 //   sim_frame_kernel<RW, CW>   L > 32 (C5 with every slot live: 512 columns).  One workgroup = (frame, group of 64*CW live
 //       columns): it streams ALL rows of its frame, so the per-frame max, the exact-fp32 re-evaluation of the winner and the
@@ -311,17 +312,216 @@ __global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__rest
                                                             int Q, int S, float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int f = t / FEW_MAXL, j = t - f * FEW_MAXL;
-  if (f >= F || j >= qlist[0]) return;
+  if (f >= F) return;
+  // (the records of the columns j >= L are inside the workspace, unwritten: every load below is issued before the first
+  // result is looked at -- one memory latency instead of three dependent ones)
+  const int L = qlist[0];
   const int q = qlist[1 + j];
   float2 b = parts[((size_t)f * S) * FEW_MAXL + j];
-  for (int s = 1; s < S; s++) {
-    const float2 o = parts[((size_t)f * S + s) * FEW_MAXL + j];
-    if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
+  constexpr int SB = 16;
+  for (int s0 = 1; s0 < S; s0 += SB) {
+    float2 o[SB];
+#pragma unroll
+    for (int u = 0; u < SB; u++) o[u] = parts[((size_t)f * S + (s0 + u < S ? s0 + u : S - 1)) * FEW_MAXL + j];
+#pragma unroll
+    for (int u = 0; u < SB; u++)
+      if (s0 + u < S && better_nan(o[u].x, __float_as_int(o[u].y), b.x, __float_as_int(b.y))) b = o[u];
   }
+  if (j >= L) return;
   int bi = __float_as_int(b.y);
   bi = bi < 0 ? 0 : (bi >= Nb ? Nb - 1 : bi);
   S_max[(size_t)f * Q + q] = b.x;
   D_ind[(size_t)f * Q + q] = (int64_t)bi;
+}
+
+// ---------------------------------------------------------------------------------------------------- few live columns, fp32 MFMA
+// The same job as sim_few_kernel (workgroup (f, s) = rows [s*32, s*32+32) of frame f against the L <= 32 live columns, same
+// `parts` records for sim_few_merge_kernel) on the fp32 matrix cores, for D % 128 == 0: v_mfma_f32_32x32x2_f32 multiplies and
+// accumulates in fp32, so every score is still an fp32 dot product (no filter, no margin, no second pass) -- but the
+// 19 200 x 512 x 32 products of C5 cost 4 us of MFMA issue spread over the chip instead of 17 us of vector FMAs.
+// Wave q of the workgroup owns the K quarter [q*D/4, (q+1)*D/4) of the 32 rows, in windows of one 128-B line per row:
+//   V: a load instruction covers 8 rows x one full line (8 lanes x 16 B per row); the wave drops the window into its PRIVATE
+//      LDS region (row pitch 144 B) and reads it back as A fragments -- lane (r = lane & 31, h = lane >> 5) takes the 16 B at
+//      slot 2j + h of row r: both directions conflict-free, no barrier (the LDS executes one wave's instructions in order).
+//      The MFMAs of a line start when that line has arrived (counted vmcnt), so what is left to do after the last byte of
+//      the chip-wide stream has landed is a quarter of a wave's work, not all of it;
+//   W: lane (r, h) loads the same k (slot 2j + h of the quarter) of live column r straight from global memory into the B
+//      operand registers -- 64 KB of live W rows, L2 hits;
+//   element e of step j multiplies k = q*D/4 + 8j + 4h + e on both sides: no transpose anywhere.
+// The first V line is requested before the prologue (entity-length prefix, column lookup), W and the other lines behind it
+// (vmcnt retires in order: waiting for W then also covers line 0, which is wanted first anyway).  The four K quarters are
+// added in wave order in the epilogue, then one wave takes the column maxima over the 32 rows (torch.max's rules).
+constexpr int LIVE_PITCH = 144;                 // bytes per row of a window: one 128-B line + 16
+constexpr int LIVE_WIN = 32 * LIVE_PITCH;       // per wave (the wave's accumulator tile, 4 KB, goes there afterwards)
+struct LiveLds {
+  int win, prefix, total;
+};
+__host__ __device__ inline LiveLds live_lds(int Na) {
+  LiveLds o;
+  int p = 0;
+  o.win = p;    p += 4 * LIVE_WIN;          // [wave] window; afterwards the wave's accumulator tile [register][lane]
+  o.prefix = p; p += ((Na + 1) * 4 + 15) & ~15;
+  o.total = p;
+  return o;
+}
+
+__global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
+                                                          const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
+                                                          int D, int S, int Lh, float2 *__restrict__ parts, int *__restrict__ qlist,
+                                                          float *__restrict__ S_max, int64_t *__restrict__ D_ind, int dbg) {
+  (void)dbg;   // timing experiment (experiments build): 1 = no MFMA (loads, transposition and the epilogue only)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const LiveLds lo = live_lds(Na);
+  int *prefix = reinterpret_cast<int *>(smem + lo.prefix);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char *win = smem + lo.win + wave * LIVE_WIN;
+  const int f = blockIdx.x / S, s = blockIdx.x - f * S;
+  const int r31 = lane & 31, hi = lane >> 5;
+  const int nl = D >> 7;                       // 128-B lines of one wave's K quarter (<= 4)
+  const int nj = D >> 5;                       // 8-k steps of it (<= 16)
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  FSTAMP(0);
+  // ---- V.  Lane (t = lane >> 3, sl = lane & 7): 16-B slot sl of the line; row group g holds the rows
+  // (t & 1) * 8 + (t >> 1) + 4 * (g & 1) + 16 * (g >> 1), so that 16 consecutive lanes write rows a and a + 8 (disjoint banks).
+  // A row beyond the frame reads the frame's last row (dropped in the epilogue), a line beyond D re-reads the last line
+  // (multiplied as zeros).
+  const int t8 = lane >> 3, sl = lane & 7;
+  const int rl = (t8 & 1) * 8 + (t8 >> 1);
+  const float *vq = V + (size_t)f * Nb * D + (size_t)wave * (D >> 2) + sl * 4;
+  f32x4 x[16];
+  auto v_request = [&](int li) {               // line li of the K quarter, all 32 rows
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int r = s * FEW_ROWS + rl + 4 * (g & 1) + 16 * (g >> 1);
+      x[li * 4 + g] = *reinterpret_cast<const f32x4 *>(vq + (size_t)(r < Nb ? r : Nb - 1) * D + (li < nl ? li : nl - 1) * 32);
+    }
+  };
+  // ---- The entity lengths are the FIRST load of the kernel: vmcnt retires in order, so waiting for them then leaves the V
+  // window requested right behind them in flight (requested after it, they would be waited for together with it; as scalar
+  // loads they queued behind the chip-wide flood of V requests: 10 us in the slowest workgroups).
+  int el = 0;
+  if (tid < 64 && tid < Na) el = ent_len[tid];
+  v_request(0);
+  if (Na <= 64) {
+    if (wave == 0) {
+      const int xl = el < 0 ? 0 : (el > Ne ? Ne : el);
+      int incl = xl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (lane < Na) prefix[lane] = incl - xl;
+      if (lane == 63) prefix[Na] = incl;
+    }
+  } else {
+    build_prefix(ent_len, Na, Ne, prefix);
+  }
+  __syncthreads();
+  const int Ql = prefix[Na];
+  int L = Ql < Lh ? Ql : Lh;                   // (columns beyond the caller's bound are reported as NaN below)
+  L = L < FEW_MAXL ? L : FEW_MAXL;
+  // every lane looks up the query row of ITS column (no column map in LDS, no second barrier)
+  int cq = 0;
+  if (L > 0) {
+    const int c = r31 < L ? r31 : L - 1;
+    const int a = find_seg(prefix, Na, c);
+    cq = a * Ne + (c - prefix[a]);
+  }
+  if (blockIdx.x == 0 && tid < FEW_MAXL) {      // the merge kernel's column -> query map (one workgroup writes it)
+    qlist[1 + tid] = tid < L ? cq : -1;
+    if (tid == 0) qlist[0] = L;
+  }
+  FSTAMP(1);
+  // ---- W: a lane beyond the live columns reads the last live one (the columns of an MFMA tile are independent; dropped below)
+  const float *wp = Wm + (size_t)cq * D + (size_t)wave * (D >> 2) + hi * 4;
+  f32x4 w[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) w[j] = *reinterpret_cast<const f32x4 *>(wp + 8 * (j < nj ? j : nj - 1));
+  v_request(1);
+  v_request(2);
+  v_request(3);
+  if (s == 0) {      // this frame's masked slots: (0, 0) (model.py:551); live slots beyond the caller's bound: NaN, loud
+    const int Q = Na * Ne;
+    for (int q = tid; q < Q; q += 256) {
+      const int a = q / Ne, e = q - a * Ne;
+      const int l = prefix[a + 1] - prefix[a];
+      if (e >= l) {
+        S_max[(size_t)f * Q + q] = 0.f;
+        D_ind[(size_t)f * Q + q] = 0;
+      } else if (prefix[a] + e >= L) {
+        S_max[(size_t)f * Q + q] = NAN;
+        D_ind[(size_t)f * Q + q] = 0;
+      }
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+  for (int li = 0; li < 4; li++) {             // window = one line of the 32 rows: 4 steps of 8 k
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+      *reinterpret_cast<f32x4 *>(win + (rl + 4 * (g & 1) + 16 * (g >> 1)) * LIVE_PITCH + sl * 16) = x[li * 4 + g];
+    f32x4 a[4];
+#pragma unroll
+    for (int jw = 0; jw < 4; jw++) a[jw] = *reinterpret_cast<const f32x4 *>(win + r31 * LIVE_PITCH + (2 * jw + hi) * 16);
+#ifdef NAFAE_EXPERIMENTS
+    if (dbg & 1) {                             // timing experiment: consume the operands, no MFMA
+#pragma unroll
+      for (int jw = 0; jw < 4; jw++) acc[li * 4 + jw] = a[jw][0] + w[li * 4 + jw][0];
+    } else
+#endif
+#pragma unroll
+    for (int jw = 0; jw < 4; jw++) {
+      const int j = li * 4 + jw;
+      f32x4 av = a[jw], bv = w[j];
+      if (j >= nj) {
+        av = z4;
+        bv = z4;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+    }
+  }
+  FSTAMP(2);
+  // ---- K quarters: waves 1 .. 3 leave their tiles in their own LDS region for wave 0; ((q0 + q1) + q2) + q3
+  if (wave > 0) {
+    float *red = reinterpret_cast<float *>(win);
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  FSTAMP(3);
+  if (wave == 0) {
+#pragma unroll
+    for (int u = 1; u < 4; u++) {
+      const float *red = reinterpret_cast<const float *>(smem + lo.win + u * LIVE_WIN);
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] += red[r * 64 + lane];
+    }
+    // lane (column r31, half hi) holds rows (r & 3) + 8 * (r >> 2) + 4 * hi of the tile, ascending in r
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      // rows arrive in ascending order: the first valid one is taken, a later one wins only if strictly greater, or NaN while
+      // the best is not NaN yet
+      const int rr = s * FEW_ROWS + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float v = acc[r];
+      const bool take = (rr < Nb) & ((bi == 0x7fffffff) | (!(bv != bv) & ((v != v) | (v > bv))));
+      bv = take ? v : bv;
+      bi = take ? rr : bi;
+    }
+    const float ov = __shfl_xor(bv, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (better_nan(ov, oi, bv, bi)) {
+      bv = ov;
+      bi = oi;
+    }
+    if (lane < L) parts[((size_t)f * S + s) * FEW_MAXL + lane] = make_float2(bv, __int_as_float(bi));
+  }
+  FSTAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------------- many live columns
@@ -893,6 +1093,17 @@ int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, in
   float2 *parts = reinterpret_cast<float2 *>(workspace);
   int *qlist = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)F * S * FEW_MAXL * 8);
   int rc = NAFAE_ELIMIT;
+  const char *fe = nafae::experiment_env("NAFAE_SIM_FEW");
+  if (D % 128 == 0 && !(fe && fe[0] == 'v')) {
+    const LiveLds lo = live_lds(Na);
+    int dbg = 0;
+    if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
+    hipLaunchKernelGGL(sim_live_kernel, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
+                       S_max, D_ind, dbg);
+    hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)((F * FEW_MAXL + 255) / 256)), dim3(256), 0, st, parts, qlist, F, Nb,
+                       Na * Ne, S, S_max, D_ind);
+    return launch_status();
+  }
   switch ((Lh + 3) / 4) {
     case 1: rc = launch_few_lt<4>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
     case 2: rc = launch_few_lt<8>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;

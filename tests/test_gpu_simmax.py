@@ -45,6 +45,9 @@ CASES = [
     (3, 2, 16, 4, 40, [1, 4, 2]),               # D % 32 != 0: falls back to the exact-fp32 kernel
     (2, 2, 32, 8, 512, [0, 0]),                 # nothing live
     (5, 1, 10, 3, 64, [3, 3, 3, 3, 3]),         # every slot live
+    (70, 1, 40, 2, 128, [(i % 3 == 0) + (i % 35 == 0) for i in range(70)]),   # more than 64 segments, 26 live columns (fp32-MFMA kernel)
+    (3, 2, 45, 12, 384, [12, 7, 12]),           # 31 live columns, D = 384: three 128-B lines per K quarter
+    (2, 3, 31, 20, 256, [20, 12]),              # 32 live columns exactly
 ]
 
 
