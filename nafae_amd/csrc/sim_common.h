@@ -69,13 +69,22 @@ __device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8 &h
   }
 }
 
+// hi = bf16(x), lo = bf16(x - hi), two elements per instruction: v_cvt_pk_bf16_f32 packs a pair, the pair's two halves widened
+// back (shift / mask) feed one v_pk_add_f32 -- 10 vector instructions per float4 (element by element hipcc emitted 16: the
+// conversions once per element to rebuild float(hi), once more per pair to pack).  Same bits as the element-wise form.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const f32x4 x, bf16x4 &hi, bf16x4 &lo) {
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const __bf16 h = (__bf16)x[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(x[e] - (float)h);
-  }
+  const f32x2_ x01 = {x[0], x[1]}, x23 = {x[2], x[3]};
+  const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x01, bf16x2_));
+  const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x23, bf16x2_));
+  const f32x2_ r01 = x01 - f32x2_{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
+  const f32x2_ r23 = x23 - f32x2_{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+  const unsigned q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2_));
+  const unsigned q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2_));
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  hi = __builtin_bit_cast(bf16x4, (u32x2_){p0, p1});
+  lo = __builtin_bit_cast(bf16x4, (u32x2_){q0, q1});
 }
 
 template <int CTRL>

@@ -596,12 +596,25 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// 16-B slot swizzle of a 128-B stage row.  u = (row >> 1) & 7 enumerates the 8 slots over 16 consecutive rows (8 even + 8 odd
+// rows: the 16 lanes of a ds_read_b128 group hit all 64 banks once); its bits are ROTATED (u0 -> bit 2) so that the rows r and
+// r + 2 a staging wave writes in one ds_write_b64 put their 64-B plane halves into different halves of the row -- with the
+// plain value the four even rows of a write shared 16 banks (4 cycles per write instead of 2); the row's parity flips bit 2.
+__device__ __forceinline__ int frame_swz(int row) {
+  const int u = (row >> 1) & 7;
+  return (((u & 1) << 2) | (u >> 1)) ^ ((row & 1) << 2);
+}
+
 // grid ceil(F/8)*8*G workgroups of 512 threads (one per CU: ~120 KB of LDS); workgroup = (frame f, column group g).
 // Waves 0-3 (one per SIMD) issue the MFMAs: wave = (row half rh, column half ch), RW x CW accumulator tiles.  Waves 4-7 (their
 // SIMD partners) STAGE: global_load_dwordx4 (8 lanes per 128-B line) -> split into bf16 hi / lo -> ds_write_b64 into the other
 // LDS stage, two chunks of loads in flight.  The hardware interleaves the partner's vector work with the MFMA wave's matrix
 // work; as one instruction stream hipcc ran the conversion, the MFMAs and the loads of a chunk one after the other.
 // LDS: [2 stages][(RT + GC) rows][128 B: hi p0..p3 | lo p0..p3, 16-B slots XOR-swizzled by (row >> 1) & 7][qmap GC][prefix]
+// Where a trip of the k-loop goes (dbg bit 256, scripts/simfused_trip.py; C5 all live, shader cycles per trip): MFMA waves issue
+// reads + 60 MFMAs in 2 400; a staging wave's split + ds_write takes 1 500 alone and 3 400 beside a running MFMA wave (the two
+// share the SIMD's vector issue and overlap by a third only); the loads are never waited for -- with the conversion
+// compiled out the loop is MFMA-bound (20.6 us against 33), and a third register set of loads in flight changed nothing.
 template <int RW, int CW>
 __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
                                                         const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
@@ -673,7 +686,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
 #endif
     const int ct = tid - 256;
     const int tr = ct >> 3, ts = ct & 7;       // thread (tr, ts) moves 16 B (4 k) of tile row tr + 32 i per slot
-    const int swz = ((tr >> 1) & 7) ^ ((tr & 1) << 2);   // (+ the row's parity on bit 2: rows 2m, 2m+1 write different 64-B halves)
+    const int swz = frame_swz(tr);
     const int wr_hi = tr * 128 + ((ts >> 1) ^ swz) * 16 + (ts & 1) * 8;
     const int wr_lo = tr * 128 + ((4 + (ts >> 1)) ^ swz) * 16 + (ts & 1) * 8;
     int woff[NSW];
@@ -747,20 +760,51 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       // wait-count pass had to assume the younger set of loads might not exist and waited vmcnt(13..0) in every convert,
       // i.e. for BOTH sets, which halves the prefetch distance.
       auto clampc = [&](int c) { return c < nch ? c : nch - 1; };
-      issue(0, S0{});
-      issue(1, S1{});
-      convert(stage0, S0{});
-      issue(clampc(2), S0{});
-      lds_barrier();
-      FSTAMP(1);
-      // trip ci (the MFMA waves compute chunk ci): convert chunk ci + 1 into the other stage, request chunk ci + 3
-      for (int ci = 0; ci < nch; ci += 2) {
-        convert(stage0 + STAGE, S1{});
-        issue(clampc(ci + 3), S1{});
-        lds_barrier();
+      {
+        issue(0, S0{});
+        issue(1, S1{});
         convert(stage0, S0{});
-        issue(clampc(ci + 4), S0{});
+        issue(clampc(2), S0{});
         lds_barrier();
+        FSTAMP(1);
+#ifdef NAFAE_EXPERIMENTS
+        if (dbg & 256) {                       // timing experiment: where a staging wave's trip goes (shader-clock cycles, summed)
+          long long t_wait = 0, t_conv = 0, t_bar = 0;
+          for (int ci = 0; ci < nch; ci += 2) {
+            long long ta = clock64();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSV + NSW) : "memory");
+            long long tb = clock64();
+            convert(stage0 + STAGE, S1{});
+            issue(clampc(ci + 3), S1{});
+            long long tc = clock64();
+            lds_barrier();
+            long long td = clock64();
+            t_wait += tb - ta; t_conv += tc - tb; t_bar += td - tc;
+            ta = clock64();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSV + NSW) : "memory");
+            tb = clock64();
+            convert(stage0, S0{});
+            issue(clampc(ci + 4), S0{});
+            tc = clock64();
+            lds_barrier();
+            td = clock64();
+            t_wait += tb - ta; t_conv += tc - tb; t_bar += td - tc;
+          }
+          if (lane == 0 && blockIdx.x < 1024) {
+            unsigned long long *o = nafae_simfused_stamps + (blockIdx.x * 8 + wave) * 8;
+            o[3] = t_wait; o[4] = t_conv; o[5] = t_bar;
+          }
+        } else
+#endif
+        // trip ci (the MFMA waves compute chunk ci): convert chunk ci + 1 into the other stage, request chunk ci + 3
+        for (int ci = 0; ci < nch; ci += 2) {
+          convert(stage0 + STAGE, S1{});
+          issue(clampc(ci + 3), S1{});
+          lds_barrier();
+          convert(stage0, S0{});
+          issue(clampc(ci + 4), S0{});
+          lds_barrier();
+        }
       }
       FSTAMP(2);
     }
@@ -769,7 +813,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
 #ifdef NAFAE_EXPERIMENTS
     if (dbg & 64) __builtin_amdgcn_s_setprio(1);        // timing experiment: MFMA waves win the issue arbitration
 #endif
-    const int aswz = ((lr >> 1) & 7) ^ ((lr & 1) << 2);
+    const int aswz = frame_swz(lr);
     const int a_base = (rh * RW * 32 + lr) * 128;
     const int b_base = (RT + ch * CW * 32 + lr) * 128;
     int fo[2][2];                              // [plane][k-step]: byte offset of this lane's 16-B piece inside its row
@@ -788,8 +832,14 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
       if (rt > 0) lds_barrier();
       lds_barrier();                           // chunk 0 is in stage 0
       FSTAMP(1);
+#ifdef NAFAE_EXPERIMENTS
+      long long m_comp = 0, m_bar = 0, m_t0 = 0;
+#endif
       for (int ci = 0; ci < nch; ci++) {
         const unsigned char *st = stage0 + (ci & 1) * STAGE;
+#ifdef NAFAE_EXPERIMENTS
+        if (dbg & 256) m_t0 = clock64();
+#endif
 #ifdef NAFAE_EXPERIMENTS
         if (dbg & 2) {                         // timing experiment: no fragment reads, no MFMAs
           lds_barrier();
@@ -816,9 +866,25 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
             }
           }
         }
+#ifdef NAFAE_EXPERIMENTS
+        if (dbg & 256) {
+          const long long t1 = clock64();
+          lds_barrier();
+          const long long t2 = clock64();
+          m_comp += t1 - m_t0;
+          m_bar += t2 - t1;
+          continue;
+        }
+#endif
         lds_barrier();
       }
       FSTAMP(2);
+#ifdef NAFAE_EXPERIMENTS
+      if ((dbg & 256) && lane == 0 && blockIdx.x < 1024) {
+        unsigned long long *o = nafae_simfused_stamps + (blockIdx.x * 8 + wave) * 8;
+        o[3] = m_comp; o[4] = m_bar; o[5] = 0;
+      }
+#endif
       // ---- this lane's column: 16 rows per 32-row block, ascending.  Element id = rb * 16 + r; NaN / Inf anywhere in the column
       // makes nanacc NaN (x * 0), which sends the column to the exact slow path.
 #pragma unroll
@@ -852,6 +918,9 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
   }
 
   // ---- the four contributors of a column (row half x 16-row lane half) leave their statistics in LDS: 8 listed candidates
+#ifdef NAFAE_EXPERIMENTS
+  if (dbg & 256) return;                       // (trip-time experiment: slots 3..5 hold cycle sums)
+#endif
   FSTAMP(3);
   __syncthreads();                             // the stages are free: reuse them as scratch
   Top *ctop = reinterpret_cast<Top *>(smem);                       // [4 contributors][GC]
