@@ -309,9 +309,9 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float *__restrict
 // of re-reading S_max from L2 in every phase (six dependent global round trips per entry in the kernel above: 70 us at C5).
 // Same arithmetic, same summation order over the live slots.  dS is written for every (frame, slot): 0 for masked ones.
 // Lcap = the host's upper bound on L (LDS is sized with it); L > Lcap is reported as NaN loss, never silently truncated.
-__global__ __launch_bounds__(1024) void loss_tail_lds_kernel(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len,
-                                                             int Na, int Ns, int Ne, float Delta, float *__restrict__ dS,
-                                                             float *__restrict__ ws, LossWs L, int Lcap) {
+__device__ __forceinline__ void loss_tail_lds_body(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len,
+                                                   int Na, int Ns, int Ne, float Delta, float *__restrict__ dS,
+                                                   float *__restrict__ ws, LossWs L, int Lcap) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Q = Na * Ne, F = Na * Ns;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -487,10 +487,10 @@ __global__ __launch_bounds__(1024) void loss_tail_lds_kernel(const float *__rest
 // Same arithmetic and summation order as loss_tail_lds_kernel; the kernel boundary is the only synchronisation.
 __device__ __forceinline__ int clamp_len(int l, int Ne) { return l < 0 ? 0 : (l > Ne ? Ne : l); }
 
-__global__ __launch_bounds__(256) void loss_seg_fwd_kernel(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len, int Na,
-                                                           int Ns, int Ne, float *__restrict__ ws, LossWs L) {
+__device__ __forceinline__ void loss_seg_fwd_body(int j, const float *__restrict__ Sm, const int32_t *__restrict__ ent_len, int Na,
+                                                  int Ns, int Ne, float *__restrict__ ws, LossWs L) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int j = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   const int Q = Na * Ne, F = Na * Ns;
   const int lraw = ent_len[j];
   const int l = clamp_len(lraw, Ne);
@@ -664,16 +664,19 @@ __device__ __forceinline__ float block_sum_n(float v, float *red) {
 // All Ns gathered rows are requested in ONE pass (independent 16-B loads, one barrier) and the per-row reductions (norm,
 // g . dG) are wave reductions -- a wave owns rows w, w+4, ... -- instead of Ns sequential block reductions with a global
 // round trip each (the first version: 36 us, most of it that serialised gather).
-__global__ __launch_bounds__(512) void cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
-                                                      const float *__restrict__ V,
-                                                      const int32_t *__restrict__ ent_len, int Na, int Ns, int Ne,
-                                                      int D, float *__restrict__ ws, LossWs L) {
+// The min / max of the slot's OWN segment (what model.py:567 normalises with) are taken here from the Ns values the kernel loads
+// anyway, with the loss tail's loop (first occurrence, `<` / `>`: the same bits) -- so the kernel does not depend on the tail and
+// runs beside it in one launch (loss_lds_cluster_kernel / loss_segf_cluster_kernel below).
+__device__ __forceinline__ void cluster_body(int ae, const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
+                                             const float *__restrict__ V,
+                                             const int32_t *__restrict__ ent_len, int Na, int Ns, int Ne,
+                                             int D, float *__restrict__ ws, LossWs L) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ float red[16];
   __shared__ float s_sn[64], s_nrm[64], s_dot[64];
   __shared__ int s_idx[64];
   float *g = sm, *G = sm + (size_t)Ns * D, *tot = G + (size_t)Ns * D;
-  const int ae = blockIdx.x, a = ae / Ne, en = ae - a * Ne;
+  const int a = ae / Ne, en = ae - a * Ne;
   const int Q = Na * Ne, q = a * Ne + en;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nt = blockDim.x, nw = nt >> 6;
   float *part_sum = ws + L.part_sum, *part_cnt = ws + L.part_cnt;
@@ -687,15 +690,23 @@ __global__ __launch_bounds__(512) void cluster_kernel(const float *__restrict__ 
     for (int s = tid; s < Ns; s += nt) cidx[s] = -1;
     return;
   }
-  const float lo = ws[L.mn + a * Q + q], hi = ws[L.mx + a * Q + q];
   for (int s = tid; s < Ns; s += nt) {
     const size_t o = ((size_t)a * Ns + s) * Q + q;
-    s_sn[s] = (Sm[o] - lo) / (hi - lo + EPS);  // model.py:567 (no grad)
+    s_dot[s] = Sm[o];                          // (parked here until the normalisation below)
     const int ix = (int)D_ind[o];              // in [0, Nb): indexes V WITHOUT a frame offset (model.py:562-569)
     s_idx[s] = ix;
     cidx[s] = ix;
   }
   __syncthreads();
+  {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int s = 0; s < Ns; s++) {
+      const float v = s_dot[s];
+      if (v < lo) lo = v;
+      if (v > hi) hi = v;
+    }
+    for (int s = tid; s < Ns; s += nt) s_sn[s] = (s_dot[s] - lo) / (hi - lo + EPS);  // model.py:567 (no grad)
+  }
   const int d4n = D >> 2;
   for (int i = tid; i < Ns * d4n; i += nt) {
     const int s = i / d4n, d4 = i - s * d4n;
@@ -761,6 +772,45 @@ __global__ __launch_bounds__(512) void cluster_kernel(const float *__restrict__ 
   }
 }
 
+__global__ __launch_bounds__(512) void cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
+                                                      const float *__restrict__ V,
+                                                      const int32_t *__restrict__ ent_len, int Na, int Ns, int Ne,
+                                                      int D, float *__restrict__ ws, LossWs L) {
+  cluster_body(blockIdx.x, Sm, D_ind, V, ent_len, Na, Ns, Ne, D, ws, L);
+}
+
+__global__ __launch_bounds__(1024) void loss_tail_lds_kernel(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len,
+                                                             int Na, int Ns, int Ne, float Delta, float *__restrict__ dS,
+                                                             float *__restrict__ ws, LossWs L, int Lcap) {
+  loss_tail_lds_body(Sm, ent_len, Na, Ns, Ne, Delta, dS, ws, L, Lcap);
+}
+
+__global__ __launch_bounds__(256) void loss_seg_fwd_kernel(const float *__restrict__ Sm, const int32_t *__restrict__ ent_len, int Na,
+                                                           int Ns, int Ne, float *__restrict__ ws, LossWs L) {
+  loss_seg_fwd_body(blockIdx.x, Sm, ent_len, Na, Ns, Ne, ws, L);
+}
+
+// Ranking term and clustering term in ONE launch (training): they share their inputs and nothing else, so back to back on a
+// stream the second only waited for the first (12 + 16 us at C5).  Workgroup 0 (resp. the first Na) = the loss tail, the
+// others = one query slot of the clustering term each; the dynamic LDS is the larger of the two needs.
+__global__ __launch_bounds__(1024) void loss_lds_cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
+                                                                const float *__restrict__ V, const int32_t *__restrict__ ent_len,
+                                                                int Na, int Ns, int Ne, int D, float Delta, float *__restrict__ dS,
+                                                                float *__restrict__ ws, LossWs L, int Lcap) {
+  if (blockIdx.x == 0)
+    loss_tail_lds_body(Sm, ent_len, Na, Ns, Ne, Delta, dS, ws, L, Lcap);
+  else
+    cluster_body(blockIdx.x - 1, Sm, D_ind, V, ent_len, Na, Ns, Ne, D, ws, L);
+}
+__global__ __launch_bounds__(512) void loss_segf_cluster_kernel(const float *__restrict__ Sm, const int64_t *__restrict__ D_ind,
+                                                                const float *__restrict__ V, const int32_t *__restrict__ ent_len,
+                                                                int Na, int Ns, int Ne, int D, float *__restrict__ ws, LossWs L) {
+  if ((int)blockIdx.x < Na)
+    loss_seg_fwd_body(blockIdx.x, Sm, ent_len, Na, Ns, Ne, ws, L);
+  else
+    cluster_body(blockIdx.x - Na, Sm, D_ind, V, ent_len, Na, Ns, Ne, D, ws, L);
+}
+
 __global__ __launch_bounds__(64) void loss_final_kernel(float *__restrict__ ws, LossWs L, int Na, int Ne, float vis_lam, int train,
                                                         float *__restrict__ loss_out) {
   // one wave: lane-strided partial sums in a fixed order, then a fixed shuffle tree (deterministic)
@@ -796,14 +846,18 @@ __global__ __launch_bounds__(64) void loss_final_kernel(float *__restrict__ ws, 
 constexpr int MAXCH = 8;  // D <= 2048 : float4 chunks per lane
 
 // one wave per region row r
-__global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
-                                                         const float *__restrict__ Wm, int R, int Nb, int Q, int D,
-                                                         int train, int n_centries, const float *__restrict__ ws,
-                                                         LossWs L, const float *__restrict__ pre_scale,
-                                                         const float *__restrict__ grad_scale,
-                                                         float *__restrict__ dV) {
+// (Measured and NOT adopted, twice: a workgroup per (frame, 16-row slice) that stages the frame's (dS, arg-max, query) entries in
+// LDS once and lets its waves scan them from there -- it takes the 115 MB of per-row entry re-reads at C5 with all slots live
+// off the L2, but a wave then walks its four rows one after the other, each with its dependent W-row round trips: 157 us
+// against 52 us for this form, whose 19 200 independent waves hide those round trips behind each other.)
+__device__ __forceinline__ void sim_bwd_dv_body(int blk, const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
+                                                const float *__restrict__ Wm, int R, int Nb, int Q, int D,
+                                                int train, int n_centries, const float *__restrict__ ws,
+                                                LossWs L, const float *__restrict__ pre_scale,
+                                                const float *__restrict__ grad_scale,
+                                                float *__restrict__ dV) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int r = blk * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   const int f = r / Nb, b = r - f * Nb;
   f32x4 acc[MAXCH];
@@ -895,13 +949,12 @@ __global__ __launch_bounds__(256) void sim_bwd_dv_kernel(const float *__restrict
 // one WORKGROUP per query column q: its 4 waves take the frames f = w, w+4, ... four at a time (the arg-max row gathers of
 // four frames are in flight together), and the four partial rows are added in wave order through LDS -- a fixed order.
 // (The first version walked the F frames of a column serially in one wave: F dependent L2 round trips, 63 us at C5.)
-__global__ __launch_bounds__(256) void sim_bwd_dw_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
-                                                         const float *__restrict__ V, const int32_t *__restrict__ ent_len,
-                                                         int F, int Nb, int Ne, int Q, int D,
-                                                         const float *__restrict__ grad_scale, float *__restrict__ dW) {
+__device__ __forceinline__ void sim_bwd_dw_body(int q, const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
+                                                const float *__restrict__ V, const int32_t *__restrict__ ent_len,
+                                                int F, int Nb, int Ne, int Q, int D,
+                                                const float *__restrict__ grad_scale, float *__restrict__ dW) {
   extern __shared__ __attribute__((aligned(16))) float red[];      // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = blockIdx.x;
   const int a = q / Ne, en = q - a * Ne;
   if (en >= ent_len[a]) {                        // masked slot: dS is 0 for every frame
     for (int d = threadIdx.x * 4; d < D; d += 1024) *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -946,6 +999,20 @@ __global__ __launch_bounds__(256) void sim_bwd_dw_kernel(const float *__restrict
     t += *reinterpret_cast<const f32x4 *>(&red[3 * D + d]);
     *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = grad_scale ? t * grad_scale[0] : t;
   }
+}
+
+// dV and dW in ONE launch: neither needs the other (both read dS and the arg-max), so as two launches on a stream the second
+// only waited for the first.  The first Q workgroups take a query column each, the others four region rows each.
+__global__ __launch_bounds__(256) void sim_bwd_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
+                                                      const float *__restrict__ V, const float *__restrict__ Wm,
+                                                      const int32_t *__restrict__ ent_len, int F, int R, int Nb, int Ne, int Q, int D,
+                                                      int train, int n_centries, const float *__restrict__ ws, LossWs L,
+                                                      const float *__restrict__ pre_scale, const float *__restrict__ grad_scale,
+                                                      float *__restrict__ dV, float *__restrict__ dW) {
+  if ((int)blockIdx.x < Q)
+    sim_bwd_dw_body(blockIdx.x, dS, D_ind, V, ent_len, F, Nb, Ne, Q, D, grad_scale, dW);
+  else
+    sim_bwd_dv_body(blockIdx.x - Q, dS, D_ind, Wm, R, Nb, Q, D, train, n_centries, ws, L, pre_scale, grad_scale, dV);
 }
 
 // ------------------------------------------------------------------------------------------------ embedding tails
@@ -1288,13 +1355,21 @@ int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float 
   int Lcap = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
   if (Lcap < 1) Lcap = 1;
   const size_t tail_lds = loss_tail_lds_bytes(Na, Ns, Ne, Lcap);
+  bool cluster_done = false;
   const char *seg_env = nafae::experiment_env("NAFAE_LOSS_SEG");   // experiments build: 1 = always the per-segment kernels
   if (tail_lds <= 150 * 1024 && !(seg_env && seg_env[0] == '1')) {     // everything on chip (see loss_tail_lds_kernel)
     if (tail_lds > 64 * 1024 &&
         nafae::allow_dynamic_lds(reinterpret_cast<const void *>(loss_tail_lds_kernel), 150 * 1024) != NAFAE_OK)
       return NAFAE_ELAUNCH;
-    hipLaunchKernelGGL(loss_tail_lds_kernel, dim3(1), dim3(1024), tail_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws,
-                       L, Lcap);
+    const size_t clds = (size_t)(2 * Ns + 1) * D * sizeof(float);
+    if (train && Ns <= 64 && tail_lds <= 64 * 1024 && clds <= 64 * 1024) {     // both terms in one launch
+      hipLaunchKernelGGL(loss_lds_cluster_kernel, dim3(1 + Na * Ne), dim3(1024), tail_lds > clds ? tail_lds : clds, S(stream), S_max,
+                         D_ind, V, ent_len, Na, Ns, Ne, D, Delta, dS, ws, L, Lcap);
+      cluster_done = true;
+    } else {
+      hipLaunchKernelGGL(loss_tail_lds_kernel, dim3(1), dim3(1024), tail_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws,
+                         L, Lcap);
+    }
   } else {
     const size_t fwd_lds = ((size_t)Na * Ns * Ne + 2 * (size_t)Na * Ne) * sizeof(float);
     const size_t bwd_lds = ((size_t)Na * Ns * Na + 4 * (size_t)Na * Ns) * sizeof(float);
@@ -1305,13 +1380,20 @@ int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float 
       if (bwd_lds > 64 * 1024 &&
           nafae::allow_dynamic_lds(reinterpret_cast<const void *>(loss_seg_bwd_kernel), 150 * 1024) != NAFAE_OK)
         return NAFAE_ELAUNCH;
-      hipLaunchKernelGGL(loss_seg_fwd_kernel, dim3(Na), dim3(256), fwd_lds, S(stream), S_max, ent_len, Na, Ns, Ne, ws, L);
+      const size_t clds = (size_t)(2 * Ns + 1) * D * sizeof(float);
+      if (train && Ns <= 64 && fwd_lds <= 64 * 1024 && clds <= 64 * 1024) {     // forward of the ranking term + clustering term
+        hipLaunchKernelGGL(loss_segf_cluster_kernel, dim3(Na + Na * Ne), dim3(512), fwd_lds > clds ? fwd_lds : clds, S(stream),
+                           S_max, D_ind, V, ent_len, Na, Ns, Ne, D, ws, L);
+        cluster_done = true;
+      } else {
+        hipLaunchKernelGGL(loss_seg_fwd_kernel, dim3(Na), dim3(256), fwd_lds, S(stream), S_max, ent_len, Na, Ns, Ne, ws, L);
+      }
       hipLaunchKernelGGL(loss_seg_bwd_kernel, dim3(Na), dim3(256), bwd_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
     } else {
       hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
     }
   }
-  if (train) {
+  if (train && !cluster_done) {
     if (Ns > 64) return NAFAE_ELIMIT;
     const size_t lds = (size_t)(2 * Ns + 1) * D * sizeof(float);
     if (lds > 64 * 1024) {
@@ -1341,10 +1423,9 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
   if (cluster_rows && !workspace) return NAFAE_EINVAL;
   const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
   const int Q = Na * Ne, R = F * Nb;
-  hipLaunchKernelGGL(sim_bwd_dv_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), dS, D_ind, W, R, Nb, Q, D, cluster_rows,
-                     Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale, grad_scale, dV);
-  hipLaunchKernelGGL(sim_bwd_dw_kernel, dim3(Q), dim3(256), (size_t)4 * D * sizeof(float), S(stream), dS, D_ind, V, ent_len, F, Nb,
-                     Ne, Q, D, grad_scale, dW);
+  hipLaunchKernelGGL(sim_bwd_kernel, dim3(Q + (R + 3) / 4), dim3(256), (size_t)4 * D * sizeof(float), S(stream), dS, D_ind, V, W,
+                     ent_len, F, R, Nb, Ne, Q, D, cluster_rows, Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale,
+                     grad_scale, dV, dW);
   return launched();
 }
 
