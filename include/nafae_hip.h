@@ -258,19 +258,23 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
  *   - contracts V only against the LIVE query slots (e < ent_len[a]); masked slots are written as (0, 0);
  *   - routing (simmax.hip fused_route / make_plan), Qh = the live-column count the launch is sized for
  *     (max_live_cols if >= 0, else Na*Ne):
- *       Qh <= 32, D % 32 == 0, D <= 512        exact-fp32 few-column kernel + merge (simfused.hip sim_few_kernel): every
- *                                                score is a k-ordered fp32 FMA chain, no filter, no margin;
- *       Qh > 32, Nb > 64, D % 64 == 0, D <= 512 one launch, one workgroup per frame (sim_frame_kernel): bf16x3 products on the
- *                                                bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate) as a FILTER that
- *                                                keeps the best three rows per contributor; the winner and every listed row within
+ *       Qh <= 32, D % 32 == 0, D <= 512         fp32 few-column kernel + merge (simfused.hip): every score is an fp32 dot
+ *                                                product, no filter, no margin -- on the fp32 matrix cores (sim_live_kernel)
+ *                                                when D % 128 == 0, as vector-ALU FMA chains (sim_few_kernel) otherwise;
+ *       Qh > 32, Nb > 64, D % 64 == 0, D <= 512  one launch, one workgroup per (frame, 64 / 128 live columns)
+ *                                                (sim_frame_kernel): bf16x3 products on the bf16 matrix cores (hi*hi + hi*lo +
+ *                                                lo*hi, fp32 accumulate) as a FILTER that keeps the best three rows per
+ *                                                contributor; the winner and every listed row within
  *                                                margin = 2^-14 * D * max|V_frame| * max|W_group| + 2^-11 * |score| of it are
  *                                                re-evaluated with exact fp32 dot products; a column whose unlisted rows could lie
  *                                                inside the margin, or that saw a NaN/Inf product, is evaluated exactly over all
  *                                                Nb rows.  The maxima are MEASURED while staging: no precondition on |V|, |W|;
- *       other shapes with D % 32 == 0, D <= 1024, Na <= 2048: the second-generation tile kernels (simmax.hip; margin
- *                                                2^-15 * D + 2^-11 * |score|, which assumes |V|, |W| <= 1 -- tanh outputs,
+ *       other shapes with D % 32 == 0, D <= 512, Nb <= 2048 (in practice Qh > 32 with Nb <= 64 or D % 64 != 0), if the plan fits
+ *                                                160 KB of LDS: the second-generation tile kernels (simmax.hip make_plan;
+ *                                                margin 2^-15 * D + 2^-11 * |score|, which assumes |V|, |W| <= 1 -- tanh outputs,
  *                                                model.py:628,642);
- *       anything else (D % 4 == 0): the exact-fp32 kernel of nafae_sim_max_fwd_frames.
+ *       anything else (D % 32 != 0, D > 512, Na > 2048, Nb > 2048): the exact-fp32 first-generation kernel of
+ *                                                nafae_sim_max_fwd_frames (any D % 4 == 0; F <= 65535, else NAFAE_ELIMIT).
  *     In every route D_ind follows torch.max: the first maximal row, a NaN score is the maximum (first NaN wins);
  *   - max_live_cols: an UPPER BOUND on the number of live slots, sum_a min(max(ent_len[a],0),Ne), if the host knows it
  *     (it sizes the launch), or -1 = unknown (sized for all Na*Ne).  A bound that is too small is a caller error that is

@@ -850,26 +850,79 @@ constexpr int MAXCH = 8;  // D <= 2048 : float4 chunks per lane
 // LDS once and lets its waves scan them from there -- it takes the 115 MB of per-row entry re-reads at C5 with all slots live
 // off the L2, but a wave then walks its four rows one after the other, each with its dependent W-row round trips: 157 us
 // against 52 us for this form, whose 19 200 independent waves hide those round trips behind each other.)
+// CP = 1: one wave per row r = 4 * blk + wave (the rows that carry no clustering gradient).  CP = 4: the WORKGROUP blk is row
+// r = blk of frame 0, a row the clustering term lands on: wave 0 takes the slot hits and the first quarter of the clustering
+// entries, waves 1-3 the other quarters; the partial rows are added in wave order through LDS (with all 512 slots of C5 live
+// such a row has 4 096 entries to scan and ~14 rows to gather -- as one wave per row the 300 of them were the critical path).
+template <int MC, int CP>
 __device__ __forceinline__ void sim_bwd_dv_body(int blk, const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
                                                 const float *__restrict__ Wm, int R, int Nb, int Q, int D,
                                                 int train, int n_centries, const float *__restrict__ ws,
                                                 LossWs L, const float *__restrict__ pre_scale,
                                                 const float *__restrict__ grad_scale,
                                                 float *__restrict__ dV) {
+  constexpr int NBT = MC <= 2 ? 4 : 2;         // hits whose W rows are in flight together
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
   const int lane = threadIdx.x & 63;
-  const int r = blk * 4 + (threadIdx.x >> 6);
+  int *lq = reinterpret_cast<int *>(dyn) + (threadIdx.x >> 6) * 1024;   // this wave's hit list: [512] query slot,
+  float *lw = reinterpret_cast<float *>(lq + 512);                      //                       [512] dS
+  const int wave = threadIdx.x >> 6;
+  const int r = CP == 1 ? blk * 4 + wave : blk;
   if (r >= R) return;
+  if (CP == 1 && train && r < Nb) return;      // (a clustering row: a CP = 4 workgroup writes it)
   const int f = r / Nb, b = r - f * Nb;
-  f32x4 acc[MAXCH];
+  f32x4 acc[MC];
 #pragma unroll
-  for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < MC; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // a block of 64 candidates: the hits (row index `id` of the source matrix, weight `wt`) are appended to the wave's list in lane
+  // order; returns the new list length
+  auto push_hits = [&](bool hit, int id, float wt, int H) {
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int pos = H + __popcll(m & ((1ull << lane) - 1ull));
+      lq[pos] = id;
+      lw[pos] = wt;
+    }
+    return H + __popcll(m);
+  };
+  // acc += wt * src[id] over the list, in list order, NBT source rows requested together
+  auto gather_hits = [&](int H, const float *__restrict__ src) {
+    for (int i = 0; i < H; i += NBT) {
+      float w[NBT];
+      const float *wr[NBT];
+#pragma unroll
+      for (int t = 0; t < NBT; t++) {
+        const int k = i + t < H ? i + t : H - 1;
+        w[t] = lw[k];
+        wr[t] = src + (size_t)lq[k] * D;
+      }
+      f32x4 x[NBT][MC];
+#pragma unroll
+      for (int t = 0; t < NBT; t++)
+#pragma unroll
+        for (int c = 0; c < MC; c++) {
+          const int d = lane * 4 + c * 256;
+          if (d < D) x[t][c] = *reinterpret_cast<const f32x4 *>(wr[t] + d);
+        }
+#pragma unroll
+      for (int t = 0; t < NBT; t++)
+        if (i + t < H) {
+#pragma unroll
+          for (int c = 0; c < MC; c++) {
+            const int d = lane * 4 + c * 256;
+            if (d < D) acc[c] += w[t] * x[t][c];
+          }
+        }
+    }
+  };
   // only live query slots can carry gradient (dS of a masked slot is exactly 0): scan the compact list the loss tail left
   // in the workspace instead of all Q columns (C5: 17 of 512)
   const int *live = ws ? reinterpret_cast<const int *>(ws + L.live) : nullptr;
   const int nq = live ? live[0] : Q;
+  const bool ident = !live || nq == Q;        // every slot live: the list is 0 .. Q-1, one dependent round trip fewer
   // The (dS, arg-max) entries of up to 512 live slots are requested together before the first ballot (one dependent L2 round
   // trip per 512 slots instead of one per 64: with all 512 slots of C5 live the row spent eight of them back to back).
-  for (int qb0 = 0; qb0 < nq; qb0 += 512) {
+  for (int qb0 = 0; qb0 < (CP == 1 || wave == 0 ? nq : 0); qb0 += 512) {
     float dsv[8];
     int qv[8];
     bool hv[8];
@@ -880,62 +933,67 @@ __device__ __forceinline__ void sim_bwd_dv_body(int blk, const float *__restrict
       qv[u] = 0;
       hv[u] = false;
       if (j < nq) {
-        qv[u] = live ? live[4 + j] : j;
+        qv[u] = ident ? j : live[4 + j];
         dsv[u] = dS[(size_t)f * Q + qv[u]];
         hv[u] = ((int)D_ind[(size_t)f * Q + qv[u]] == b) && dsv[u] != 0.f;
       }
     }
+    // The row's hits, compacted in ascending slot order into this wave's LDS list, then taken NBT at a time with their W rows
+    // requested TOGETHER (one by one, every hit was a dependent L2 round trip).
+    int H = 0;
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (qb0 + u * 64 >= nq) break;
-      const float ds = dsv[u];
-      const int q = qv[u];
-      unsigned long long m = __ballot(hv[u]);
-      while (m) {
-        const int i = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const float w = __shfl(ds, i);
-        const float *wr = Wm + (size_t)__shfl(q, i) * D;
-#pragma unroll
-        for (int c = 0; c < MAXCH; c++) {
-          const int d = lane * 4 + c * 256;
-          if (d < D) {
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(wr + d);
-            acc[c] += w * x;
-          }
-        }
-      }
-    }
+    for (int u = 0; u < 8; u++) H = push_hits(hv[u], qv[u], dsv[u], H);
+    gather_hits(H, Wm);
   }
-  if (train && r < Nb) {  // clustering gradient lands on rows [0, Nb) only (reference quirk)
+  if (CP > 1) {           // clustering gradient lands on rows [0, Nb) only (reference quirk)
     const int *cidx = reinterpret_cast<const int *>(ws + L.cidx);
     const float cscale = ws[L.scal + 1];
-    // entries t = (slot q, frame s) of live slots only: q*Ns + s (masked slots hold cidx = -1 and no gradient)
+    // entries t = (slot q, frame s) of live slots only: q*Ns + s (masked slots hold cidx = -1 and no gradient).  Scanned 512 at
+    // a time like the slots above (64 at a time, each block a dependent round trip, the 4 096 entries of C5 with every slot live
+    // made the 300 rows of frame 0 the kernel's critical path: 52 us).
     const int Nsc = n_centries / Q;
     const int ne = live ? nq * Nsc : n_centries;
-    for (int tb = 0; tb < ne; tb += 64) {
-      const int e = tb + lane;
-      int t = -1;
-      if (e < ne) t = live ? live[4 + e / Nsc] * Nsc + e % Nsc : e;
-      const bool hit = t >= 0 && cidx[t] == r;
-      unsigned long long m = __ballot(hit);
-      while (m) {
-        const int i = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const float *gr = ws + L.dgc + (size_t)__shfl(t, i) * D;
+    const int per = ((ne + CP - 1) / CP + 511) / 512 * 512;      // entries per wave, whole passes
+    const int e_end = (wave + 1) * per < ne ? (wave + 1) * per : ne;
+    for (int tb0 = wave * per; tb0 < e_end; tb0 += 512) {
+      int tv[8];
+      bool hv[8];
 #pragma unroll
-        for (int c = 0; c < MAXCH; c++) {
-          const int d = lane * 4 + c * 256;
-          if (d < D) {
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(gr + d);
-            acc[c] += cscale * x;
-          }
+      for (int u = 0; u < 8; u++) {
+        const int e = tb0 + u * 64 + lane;
+        tv[u] = 0;
+        hv[u] = false;
+        if (e < e_end) {
+          tv[u] = ident ? e : live[4 + e / Nsc] * Nsc + e % Nsc;
+          hv[u] = cidx[tv[u]] == r;
         }
       }
+      int H = 0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) H = push_hits(hv[u], tv[u], cscale, H);
+      gather_hits(H, ws + L.dgc);
     }
+    // waves 1 .. 3 hand their partial rows to wave 0: ((w0 + w1) + w2) + w3
+    float *part = dyn + 4 * 1024;                // [3][D], behind the four hit lists
+    if (wave > 0) {
+#pragma unroll
+      for (int c = 0; c < MC; c++) {
+        const int d = lane * 4 + c * 256;
+        if (d < D) *reinterpret_cast<f32x4 *>(part + (size_t)(wave - 1) * D + d) = acc[c];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int u = 0; u < CP - 1; u++)
+#pragma unroll
+      for (int c = 0; c < MC; c++) {
+        const int d = lane * 4 + c * 256;
+        if (d < D) acc[c] += *reinterpret_cast<const f32x4 *>(part + (size_t)u * D + d);
+      }
   }
 #pragma unroll
-  for (int c = 0; c < MAXCH; c++) {
+  for (int c = 0; c < MC; c++) {
     const int d = lane * 4 + c * 256;
     if (d < D) {
       f32x4 v = acc[c];
@@ -949,6 +1007,7 @@ __device__ __forceinline__ void sim_bwd_dv_body(int blk, const float *__restrict
 // one WORKGROUP per query column q: its 4 waves take the frames f = w, w+4, ... four at a time (the arg-max row gathers of
 // four frames are in flight together), and the four partial rows are added in wave order through LDS -- a fixed order.
 // (The first version walked the F frames of a column serially in one wave: F dependent L2 round trips, 63 us at C5.)
+template <int MC>
 __device__ __forceinline__ void sim_bwd_dw_body(int q, const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
                                                 const float *__restrict__ V, const int32_t *__restrict__ ent_len,
                                                 int F, int Nb, int Ne, int Q, int D,
@@ -960,9 +1019,9 @@ __device__ __forceinline__ void sim_bwd_dw_body(int q, const float *__restrict__
     for (int d = threadIdx.x * 4; d < D; d += 1024) *reinterpret_cast<f32x4 *>(dW + (size_t)q * D + d) = f32x4{0.f, 0.f, 0.f, 0.f};
     return;
   }
-  f32x4 acc[MAXCH];
+  f32x4 acc[MC];
 #pragma unroll
-  for (int c = 0; c < MAXCH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < MC; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int f0 = wave; f0 < F; f0 += 16) {
     float ds[4];
     const float *vr[4];
@@ -975,7 +1034,7 @@ __device__ __forceinline__ void sim_bwd_dw_body(int q, const float *__restrict__
     }
     // all four rows are requested before the first is used; a frame with ds == 0 (inactive hinge, or beyond F) adds +-0
 #pragma unroll
-    for (int c = 0; c < MAXCH; c++) {
+    for (int c = 0; c < MC; c++) {
       const int d = lane * 4 + c * 256;
       if (d < D) {
         f32x4 r[4];
@@ -987,7 +1046,7 @@ __device__ __forceinline__ void sim_bwd_dw_body(int q, const float *__restrict__
     }
   }
 #pragma unroll
-  for (int c = 0; c < MAXCH; c++) {
+  for (int c = 0; c < MC; c++) {
     const int d = lane * 4 + c * 256;
     if (d < D) *reinterpret_cast<f32x4 *>(&red[wave * D + d]) = acc[c];
   }
@@ -1002,17 +1061,23 @@ __device__ __forceinline__ void sim_bwd_dw_body(int q, const float *__restrict__
 }
 
 // dV and dW in ONE launch: neither needs the other (both read dS and the arg-max), so as two launches on a stream the second
-// only waited for the first.  The first Q workgroups take a query column each, the others four region rows each.
-__global__ __launch_bounds__(256) void sim_bwd_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
+// only waited for the first.  Roles by workgroup index: the rows the clustering gradient lands on (one each), the query
+// columns (one each), the other region rows (four each).
+template <int MC>
+__global__ __launch_bounds__(256, MC <= 2 ? 6 : 2) void sim_bwd_kernel(const float *__restrict__ dS, const int64_t *__restrict__ D_ind,
                                                       const float *__restrict__ V, const float *__restrict__ Wm,
                                                       const int32_t *__restrict__ ent_len, int F, int R, int Nb, int Ne, int Q, int D,
                                                       int train, int n_centries, const float *__restrict__ ws, LossWs L,
                                                       const float *__restrict__ pre_scale, const float *__restrict__ grad_scale,
                                                       float *__restrict__ dV, float *__restrict__ dW) {
-  if ((int)blockIdx.x < Q)
-    sim_bwd_dw_body(blockIdx.x, dS, D_ind, V, ent_len, F, Nb, Ne, Q, D, grad_scale, dW);
+  const int ncl = train ? (Nb < R ? Nb : R) : 0;           // clustering rows: the first workgroups (the longest ones)
+  const int bid = blockIdx.x;
+  if (bid < ncl)
+    sim_bwd_dv_body<MC, 4>(bid, dS, D_ind, Wm, R, Nb, Q, D, train, n_centries, ws, L, pre_scale, grad_scale, dV);
+  else if (bid < ncl + Q)
+    sim_bwd_dw_body<MC>(bid - ncl, dS, D_ind, V, ent_len, F, Nb, Ne, Q, D, grad_scale, dW);
   else
-    sim_bwd_dv_body(blockIdx.x - Q, dS, D_ind, Wm, R, Nb, Q, D, train, n_centries, ws, L, pre_scale, grad_scale, dV);
+    sim_bwd_dv_body<MC, 1>(bid - ncl - Q, dS, D_ind, Wm, R, Nb, Q, D, train, n_centries, ws, L, pre_scale, grad_scale, dV);
 }
 
 // ------------------------------------------------------------------------------------------------ embedding tails
@@ -1423,9 +1488,19 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
   if (cluster_rows && !workspace) return NAFAE_EINVAL;
   const LossWs L = loss_ws(Na, Ns, Nb, Ne, D);
   const int Q = Na * Ne, R = F * Nb;
-  hipLaunchKernelGGL(sim_bwd_kernel, dim3(Q + (R + 3) / 4), dim3(256), (size_t)4 * D * sizeof(float), S(stream), dS, D_ind, V, W,
-                     ent_len, F, R, Nb, Ne, Q, D, cluster_rows, Q * Ns, reinterpret_cast<const float *>(workspace), L, pre_scale,
-                     grad_scale, dV, dW);
+  const size_t dv_lds = 16384 + (size_t)3 * D * sizeof(float), dw_lds = (size_t)4 * D * sizeof(float);   // dV: 4 hit lists + [3][D]; dW: [4][D]
+  const size_t bwd_lds = dv_lds > dw_lds ? dv_lds : dw_lds;
+  const int ncl = cluster_rows ? (Nb < R ? Nb : R) : 0;
+  // (MC = float4 chunks per lane: 2 covers D <= 512 in 50-odd registers, i.e. 8 waves per SIMD instead of 5 -- the rows' dependent
+  // round trips are hidden by the number of rows in flight)
+  if (D <= 512)
+    hipLaunchKernelGGL(sim_bwd_kernel<2>, dim3(ncl + Q + (R + 3) / 4), dim3(256), bwd_lds, S(stream), dS, D_ind, V,
+                       W, ent_len, F, R, Nb, Ne, Q, D, cluster_rows, Q * Ns, reinterpret_cast<const float *>(workspace), L,
+                       pre_scale, grad_scale, dV, dW);
+  else
+    hipLaunchKernelGGL(sim_bwd_kernel<MAXCH>, dim3(ncl + Q + (R + 3) / 4), dim3(256), bwd_lds, S(stream), dS, D_ind,
+                       V, W, ent_len, F, R, Nb, Ne, Q, D, cluster_rows, Q * Ns, reinterpret_cast<const float *>(workspace), L,
+                       pre_scale, grad_scale, dV, dW);
   return launched();
 }
 
