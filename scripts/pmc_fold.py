@@ -14,7 +14,8 @@ def per_kernel_means(path, substr):
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if substr in row["Kernel_Name"]:
-                vals[row["Counter_Name"]][row["Kernel_Name"].split("(")[0][-40:]].append(float(row["Counter_Value"]))
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                vals[row["Counter_Name"]][name.split("(")[0]].append(float(row["Counter_Value"]))
     out = {}
     for c, ks in vals.items():
         out[c] = {k: (sum(v[1:]) / len(v[1:]) if len(v) > 1 else v[0]) for k, v in ks.items()}
