@@ -462,7 +462,7 @@ def run_rank(a):
         if world == 1:
             # the similarity kernel alone at this workload's shape, and at C5 (the HBM-roofline configuration)
             so = sim_loss_only(Na, Ns, Nb, Ne, dev, pmc_key="sim_%s_hist" % workload)
-            out["roofline_sim"] = {"kernel": "sim_few_kernel + sim_few_merge_kernel (nafae_sim_max_fwd_ws: exact-fp32 few-live-column route; stand-alone, this workload's shape and entity-length histogram)",
+            out["roofline_sim"] = {"kernel": "sim_live_kernel + sim_few_merge_kernel (nafae_sim_max_fwd_ws: fp32-MFMA few-live-column route; stand-alone, this workload's shape and entity-length histogram)",
                                    "bound": "hbm", "achieved": so["fwd_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": so["fwd_hbm_frac"], "avg_ms": so["fwd_ms"], "algorithmic_bytes": so["fwd_algorithmic_bytes"],
                                    "traffic": so["fwd_traffic"], "traffic_source": so["fwd_traffic_source"],
