@@ -225,6 +225,9 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
             "fwd_dense_flops_frac_of_fp32_mfma": round(fl / (t_f * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             "fwd_dense_flops_frac_of_bf16_mfma": round(fl / (t_f * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
             "fwd_live_bf16x3_mfma_frac": round(3.0 * 2.0 * R * live * D / (t_f * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            # <= 32 live columns run on the fp32 matrix cores in 32-column tiles (sim_live_kernel): the issued fraction of that peak
+            "fwd_live_fp32_mfma_issue_frac": (round(2.0 * R * 32 * D / (t_f * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+                                              if live <= 32 and D % 128 == 0 else None),
             "fwd_bwd_ms": round(t_fb, 5), "fwd_bwd_pairs_per_s": round(R * Q / (t_fb * 1e-3), 1),
             "fwd_bwd_hbm_frac": round(by_fb / (t_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 

@@ -258,9 +258,8 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
  *   - contracts V only against the LIVE query slots (e < ent_len[a]); masked slots are written as (0, 0);
  *   - routing (simmax.hip fused_route / make_plan), Qh = the live-column count the launch is sized for
  *     (max_live_cols if >= 0, else Na*Ne):
- *       Qh <= 32, D % 32 == 0, D <= 512         fp32 few-column kernel + merge (simfused.hip): every score is an fp32 dot
- *                                                product, no filter, no margin -- on the fp32 matrix cores (sim_live_kernel)
- *                                                when D % 128 == 0, as vector-ALU FMA chains (sim_few_kernel) otherwise;
+ *       Qh <= 32, D % 32 == 0, D <= 512         fp32 few-column kernel + merge (simfused.hip sim_live_kernel): every score
+ *                                                is an fp32 dot product on the fp32 matrix cores, no filter, no margin;
  *       Qh > 32, Nb > 64, D % 64 == 0, D <= 512  one launch, one workgroup per (frame, 64 / 128 live columns)
  *                                                (sim_frame_kernel): bf16x3 products on the bf16 matrix cores (hi*hi + hi*lo +
  *                                                lo*hi, fp32 accumulate) as a FILTER that keeps the best three rows per

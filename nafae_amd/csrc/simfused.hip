@@ -2,16 +2,14 @@
 // 580-583, 610-612), third generation, gfx950.  Two kernels that replace simmax.hip's part / tile + finish pairs where they apply
 // (simmax.hip's make_plan routes; its kernels stay as the fallback for the shapes these do not take):
 //
-//   sim_live_kernel / sim_few_kernel (+ sim_few_merge_kernel)   L <= 32 live query slots -- every BASELINE configuration with
-//       entity lengths from the data set's histogram (C2: 19 of 128 slots live, C5: 17 of 512).  The problem is then a pure
-//       stream of V (C5: 39 MB against 0.7 GFLOP), so there is no filter and no second pass over V at all: every (proposal,
-//       live query) score is an fp32 dot product computed while the rows stream through registers.  A workgroup owns 32
-//       consecutive rows of ONE frame and leaves its per-column (max, arg-max) in the workspace; the merge kernel takes the
-//       best of a frame's workgroups (ties -> smaller index, NaN -> first NaN: torch.max's rules) and the masked slots are
-//       zero-filled.  All of V is requested within the first two microseconds.
-//         sim_live_kernel (D % 128 == 0): fp32 MFMA, a wave = 32 rows x a quarter of K (see the kernel);
-//         sim_few_kernel<LT> (other D % 32 == 0): vector-ALU FMA chains, a wave = 16 rows x half of K, W (live rows only) in
-//         LDS as fp32 in a conflict-free [chunk][slot][column] image, one ds_read_b128 of W feeds 8 FMAs.
+//   sim_live_kernel (+ sim_few_merge_kernel)   L <= 32 live query slots -- every BASELINE configuration with entity lengths from
+//       the data set's histogram (C2: 19 of 128 slots live, C5: 17 of 512).  The problem is then a pure stream of V (C5: 39 MB
+//       against 0.7 GFLOP), so there is no filter and no second pass over V at all: every (proposal, live query) score is an
+//       fp32 dot product on the fp32 matrix cores while the rows stream through (a wave = 32 rows x a quarter of K, see the
+//       kernel).  A workgroup owns 32 consecutive rows of ONE frame and leaves its per-column (max, arg-max) in the workspace;
+//       the merge kernel takes the best of a frame's workgroups (ties -> smaller index, NaN -> first NaN: torch.max's rules) and
+//       the masked slots are zero-filled.  All of V is requested within the first two microseconds.  (Its first form, fp32 FMA
+//       chains on the vector ALU with W as an LDS image, was VALU-bound at 17 us for C5 and is gone.)
 //
 //   sim_frame_kernel<RW, CW>   L > 32 (C5 with every slot live: 512 columns).  One workgroup = (frame, group of 64*CW live
 //       columns): it streams ALL rows of its frame, so the per-frame max, the exact-fp32 re-evaluation of the winner and the
@@ -53,259 +51,9 @@ __device__ unsigned long long nafae_simfused_stamps[8 * 8192];
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------------- few live columns
-constexpr int FEW_MAXL = 32;    // live columns the kernel takes (accumulators: 2 rows x FEW_MAXL per lane)
-constexpr int FEW_ROWS = 32;    // rows per workgroup: 2 octet pairs (x 2 K halves = 4 waves)
-constexpr int FEW_NCH = 16;     // 32-k chunks (D <= 512)
-
-// sum over the 8 lanes 8k .. 8k+7; every lane ends with the same bits (fixed tree; + is commutative)
-__device__ __forceinline__ float sum8(float x) {
-  x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
-  x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
-  x += dpp_mov<0x141>(x);   // row_half_mirror: lane i <-> 7 - i of its 8
-  return x;
-}
-
-__device__ __forceinline__ float dot4(const f32x4 x, const f32x4 w, float acc) {
-  acc = fmaf(x[0], w[0], acc);
-  acc = fmaf(x[1], w[1], acc);
-  acc = fmaf(x[2], w[2], acc);
-  acc = fmaf(x[3], w[3], acc);
-  return acc;
-}
-
-struct FewLds {
-  int wimg, wbest, scr, qmap, prefix, total;
-};
-__host__ __device__ inline FewLds few_lds(int D, int L, int Na) {
-  FewLds o;
-  const int Lp = L | 1;
-  o.wimg = 0;
-  int p = D * Lp * 4 + Lp * 16 + 64;        // [D/32][8][Lp] float4, then Lp zero float4s (the W "row" of a chunk beyond D)
-  o.wbest = p;  p += 4 * FEW_MAXL * 8;      // [wave][column] (value, row)
-  o.scr = p;    p += 4 * 16 * FEW_MAXL * 4; // [wave][row of the wave][column] transposition scratch
-  o.qmap = p;   p += FEW_MAXL * 4;
-  o.prefix = p; p += ((Na + 1) * 4 + 15) & ~15;
-  o.total = p;
-  return o;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// grid F * S workgroups of 256 threads; workgroup (f, s) owns rows [s*32, s*32+32) of frame f.  parts[(f*S + s)*32 + j] =
-// (best value, row as int bits) of live column j over those rows.  LT = live columns rounded up to a multiple of 4 (compile
-// time: the accumulators are registers and the body has no branch; columns L .. LT-1 run on zero-filled W).
-// Wave = (pair p of octets, K half kh): 16 rows x 8 chunks (256 k).  In-kernel stamps of the first form of this kernel (a wave
-// = 16 rows x all 16 chunks, 1.25 waves per SIMD at C5) showed it VALU-bound, not HBM-bound -- the windows took 3 us each at
-// C2's 16.8 MB and at C5's 39 MB alike: one wave alone on a SIMD issues a vector instruction every 4 cycles, two or more
-// every 2.  Splitting K over two waves doubles the waves per SIMD (2.5 at C5), needs no refill (a wave's whole share is
-// requested at once) and leaves the W reads per FMA unchanged; the two K halves are added in a fixed order in the epilogue.
-template <int LT>
-__global__ __launch_bounds__(256, 3) void sim_few_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
-                                                         const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
-                                                         int D, int S, int Lh, float2 *__restrict__ parts, int *__restrict__ qlist,
-                                                         float *__restrict__ S_max, int64_t *__restrict__ D_ind, int dbg) {
-  (void)dbg;   // timing experiments (experiments build): 1 = no arithmetic (loads, staging and the epilogue only)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const FewLds lo = few_lds(D, LT, Na);
-  f32x4 *wimg = reinterpret_cast<f32x4 *>(smem + lo.wimg);
-  float2 *wbest = reinterpret_cast<float2 *>(smem + lo.wbest);
-  float *scr = reinterpret_cast<float *>(smem + lo.scr);
-  int *qmap = reinterpret_cast<int *>(smem + lo.qmap);
-  int *prefix = reinterpret_cast<int *>(smem + lo.prefix);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = blockIdx.x / S, s = blockIdx.x - f * S;
-  const int nch = D >> 5;
-  const int sl = lane & 7, rg = lane >> 3;     // 16-B slot of the 128-B line, row of the octet
-  const int pr = wave >> 1, kh = wave & 1;     // octet pair, K half
-  FSTAMP(0);
-  constexpr int Lp = LT | 1;                   // odd column pitch: the 8 slots of a ds_read_b128 group fall on distinct banks
-  constexpr int NCW = FEW_NCH / 2;             // chunks per wave
-
-  // ---- V: this wave's two octets x its 8 chunks.  No branch below: an octet beyond the frame reads the frame's last row (its
-  // rows are dropped by the row < Nb test at the end), a chunk beyond D re-reads the last chunk and meets a zero W row.
-  const int row0 = s * FEW_ROWS + pr * 16 + rg, row1 = row0 + 8;
-  const float *v0 = V + ((size_t)f * Nb + (row0 < Nb ? row0 : Nb - 1)) * D + sl * 4;
-  const float *v1 = V + ((size_t)f * Nb + (row1 < Nb ? row1 : Nb - 1)) * D + sl * 4;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-
-  build_prefix(ent_len, Na, Ne, prefix);
-  __syncthreads();
-  const int Ql = prefix[Na];
-  int L = Ql < Lh ? Ql : Lh;                   // (columns beyond the caller's bound are reported as NaN below)
-  L = L < LT ? L : LT;
-  if (tid < FEW_MAXL) {
-    int q = -1;
-    if (tid < L) {
-      const int a = find_seg(prefix, Na, tid);
-      q = a * Ne + (tid - prefix[a]);
-    }
-    qmap[tid] = q;
-    if (blockIdx.x == 0) {                      // the merge kernel's column -> query map (one workgroup writes it)
-      qlist[1 + tid] = q;
-      if (tid == 0) qlist[0] = L;
-    }
-  }
-  __syncthreads();
-  FSTAMP(1);
-  // ---- ORDER OF THE LOADS.  vmcnt retires in order, so whatever is requested BEFORE the W rows is waited for together with
-  // them.  W rows first (L2 hits), the V share right behind them, wait for W alone, stage it, then consume V as it arrives.
-  constexpr int WPT = (LT * (FEW_NCH * 8) + 255) / 256;          // float4s of W per thread at D = 512
-  f32x4 w[WPT];
-  {
-    const int k4n = D >> 2;
-    const int total = LT * k4n;
-#pragma unroll
-    for (int u = 0; u < WPT; u++) {
-      const int idx = tid + 256 * u;
-      const int j = idx / k4n, k4 = idx - j * k4n;
-      w[u] = (idx < total && j < L) ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)qmap[j] * D + k4 * 4) : z4;
-    }
-  }
-  f32x4 x0[NCW], x1[NCW];
-#pragma unroll
-  for (int u = 0; u < NCW; u++) {
-    const int c = kh * NCW + u;
-    x0[u] = *reinterpret_cast<const f32x4 *>(v0 + (c < nch ? c : nch - 1) * 32);
-  }
-#pragma unroll
-  for (int u = 0; u < NCW; u++) {
-    const int c = kh * NCW + u;
-    x1[u] = *reinterpret_cast<const f32x4 *>(v1 + (c < nch ? c : nch - 1) * 32);
-  }
-  if (s == 0) {      // this frame's masked slots: (0, 0) (model.py:551); live slots beyond the caller's bound: NaN, loud
-    const int Q = Na * Ne;
-    for (int q = tid; q < Q; q += 256) {
-      const int a = q / Ne, e = q - a * Ne;
-      const int l = prefix[a + 1] - prefix[a];
-      if (e >= l) {
-        S_max[(size_t)f * Q + q] = 0.f;
-        D_ind[(size_t)f * Q + q] = 0;
-      } else if (prefix[a] + e >= L) {
-        S_max[(size_t)f * Q + q] = NAN;
-        D_ind[(size_t)f * Q + q] = 0;
-      }
-    }
-  }
-  // ---- W (live rows; zeros for the columns L .. LT-1) -> LDS as fp32, image [chunk][slot][column]
-  {
-    const int k4n = D >> 2;
-    const int total = LT * k4n;
-#pragma unroll
-    for (int u = 0; u < WPT; u++) {
-      const int idx = tid + 256 * u;
-      const int j = idx / k4n, k4 = idx - j * k4n;
-      if (idx < total) wimg[(size_t)k4 * Lp + j] = w[u];        // k4 = chunk * 8 + slot
-    }
-    if (tid < Lp) wimg[(size_t)(D >> 2) * Lp + tid] = z4;       // the zero row
-  }
-  __syncthreads();
-  FSTAMP(2);
-
-  // ---- exact fp32 scores: a[o][j] = this lane's k-slots (of this wave's K half) of row o against live column j, one FMA chain
-  // per (row, column).  Steps of 4 columns; the W reads of step t + 1 are issued before the FMAs of step t and a scheduling
-  // fence closes every step (unfenced, hipcc hoisted the LDS reads of all 8 chunks above the arithmetic and spilled them).
-  float a0[LT], a1[LT];
-#pragma unroll
-  for (int j = 0; j < LT; j++) a0[j] = a1[j] = 0.f;
-  constexpr int NG = LT / 4;
-#ifdef NAFAE_EXPERIMENTS
-  if (dbg & 1) {                               // timing experiment: consume the loads, skip the arithmetic
-#pragma unroll
-    for (int u = 0; u < NCW; u++) {
-      a0[0] += x0[u][0];
-      a1[0] += x1[u][0];
-    }
-  } else
-#endif
-  {
-    auto wptr = [&](int u) {
-      const int c = kh * NCW + u;
-      return wimg + (size_t)(c < nch ? c * 8 + sl : nch * 8) * Lp;   // (a chunk beyond D: the zero row)
-    };
-    f32x4 wc[4], wn[4];
-    {
-      const f32x4 *wp = wptr(0);
-#pragma unroll
-      for (int k = 0; k < 4; k++) wc[k] = wp[k];
-    }
-#pragma unroll
-    for (int u = 0; u < NCW; u++) {
-      const f32x4 xa = x0[u], xb = x1[u];
-#pragma unroll
-      for (int g = 0; g < NG; g++) {
-        if (g + 1 < NG || u + 1 < NCW) {
-          const f32x4 *wp = (g + 1 < NG) ? wptr(u) + 4 * (g + 1) : wptr(u + 1);
-#pragma unroll
-          for (int k = 0; k < 4; k++) wn[k] = wp[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int j = g * 4 + k;
-          a0[j] = dot4(xa, wc[k], a0[j]);
-          a1[j] = dot4(xb, wc[k], a1[j]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) wc[k] = wn[k];
-        // (the empty asm takes the step's eight accumulators as in/out operands: without that data dependence hipcc SANK the
-        // FMAs out of their steps and ran the block column by column -- every column's W values of all 8 chunks, read step by
-        // step, were spilled: 128 B of scratch per column)
-        asm volatile("" : "+v"(a0[g * 4]), "+v"(a0[g * 4 + 1]), "+v"(a0[g * 4 + 2]), "+v"(a0[g * 4 + 3]), "+v"(a1[g * 4]),
-                     "+v"(a1[g * 4 + 1]), "+v"(a1[g * 4 + 2]), "+v"(a1[g * 4 + 3])
-                     :
-                     : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  FSTAMP(3);
-  // ---- rows x columns of this wave -> LDS (one lane per row writes); then, per octet pair, lane (j, half) adds the two K halves
-  // (kh = 0 first) and scans its 8 rows
-  float *ws = scr + wave * 16 * FEW_MAXL;
-#pragma unroll
-  for (int j = 0; j < LT; j++) {
-    const float s0 = sum8(a0[j]), s1 = sum8(a1[j]);
-    if (sl == 0) {
-      ws[rg * FEW_MAXL + j] = s0;
-      ws[(8 + rg) * FEW_MAXL + j] = s1;
-    }
-  }
-  FSTAMP(4);
-  __syncthreads();
-  if (wave < 2) {                              // wave p finishes octet pair p
-    const float *wa = scr + (2 * wave) * 16 * FEW_MAXL, *wb = wa + 16 * FEW_MAXL;
-    const int j = lane & 31, half = lane >> 5;
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    if (j < L) {
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const int row = s * FEW_ROWS + wave * 16 + half * 8 + r;
-        const float v = wa[(half * 8 + r) * FEW_MAXL + j] + wb[(half * 8 + r) * FEW_MAXL + j];
-        if (row < Nb && better_nan(v, row, bv, bi)) {
-          bv = v;
-          bi = row;
-        }
-      }
-    }
-    const float ov = __shfl_xor(bv, 32);
-    const int oi = __shfl_xor(bi, 32);
-    if (better_nan(ov, oi, bv, bi)) {
-      bv = ov;
-      bi = oi;
-    }
-    if (lane < 32) wbest[wave * FEW_MAXL + lane] = make_float2(bv, __int_as_float(bi));
-  }
-  FSTAMP(5);
-  __syncthreads();
-  if (tid < L) {
-    float2 b = wbest[tid];
-    const float2 o = wbest[FEW_MAXL + tid];
-    if (better_nan(o.x, __float_as_int(o.y), b.x, __float_as_int(b.y))) b = o;
-    parts[((size_t)f * S + s) * FEW_MAXL + tid] = b;
-  }
-  FSTAMP(6);
-}
+// ---------------------------------------------------------------------------------------------------- few live columns: merge
+constexpr int FEW_MAXL = 32;    // live columns the kernel takes (one 32-column MFMA tile)
+constexpr int FEW_ROWS = 32;    // rows per workgroup (one 32-row MFMA tile; its 4 waves split K)
 
 // one thread per (frame, live column): the best of the frame's S workgroups (ties -> smaller row, NaN first: torch.max's rules)
 __global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__restrict__ parts, const int *__restrict__ qlist, int F, int Nb,
@@ -335,11 +83,11 @@ __global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------- few live columns, fp32 MFMA
-// The same job as sim_few_kernel (workgroup (f, s) = rows [s*32, s*32+32) of frame f against the L <= 32 live columns, same
-// `parts` records for sim_few_merge_kernel) on the fp32 matrix cores, for D % 128 == 0: v_mfma_f32_32x32x2_f32 multiplies and
-// accumulates in fp32, so every score is still an fp32 dot product (no filter, no margin, no second pass) -- but the
-// 19 200 x 512 x 32 products of C5 cost 4 us of MFMA issue spread over the chip instead of 17 us of vector FMAs.
-// Wave q of the workgroup owns the K quarter [q*D/4, (q+1)*D/4) of the 32 rows, in windows of one 128-B line per row:
+// Workgroup (f, s) = rows [s*32, s*32+32) of frame f against the L <= 32 live columns; `parts` records for sim_few_merge_kernel.
+// v_mfma_f32_32x32x2_f32 multiplies and accumulates in fp32, so every score is an fp32 dot product (no filter, no margin, no
+// second pass) -- the 19 200 x 512 x 32 products of C5 cost 4 us of MFMA issue spread over the chip (as vector FMAs: 17 us).
+// Wave q of the workgroup owns a quarter of K -- whole 128-B lines, [q*NL/4, (q+1)*NL/4) of a row's NL = D/32 -- of the 32 rows,
+// in windows of one line per row:
 //   V: a load instruction covers 8 rows x one full line (8 lanes x 16 B per row); the wave drops the window into its PRIVATE
 //      LDS region (row pitch 144 B) and reads it back as A fragments -- lane (r = lane & 31, h = lane >> 5) takes the 16 B at
 //      slot 2j + h of row r: both directions conflict-free, no barrier (the LDS executes one wave's instructions in order).
@@ -347,7 +95,7 @@ __global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__rest
 //      the chip-wide stream has landed is a quarter of a wave's work, not all of it;
 //   W: lane (r, h) loads the same k (slot 2j + h of the quarter) of live column r straight from global memory into the B
 //      operand registers -- 64 KB of live W rows, L2 hits;
-//   element e of step j multiplies k = q*D/4 + 8j + 4h + e on both sides: no transpose anywhere.
+//   element e of step j multiplies k = (first k of the wave) + 8j + 4h + e on both sides: no transpose anywhere.
 // The first V line is requested before the prologue (entity-length prefix, column lookup), W and the other lines behind it
 // (vmcnt retires in order: waiting for W then also covers line 0, which is wanted first anyway).  The four K quarters are
 // added in wave order in the epilogue, then one wave takes the column maxima over the 32 rows (torch.max's rules).
@@ -377,8 +125,14 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
   unsigned char *win = smem + lo.win + wave * LIVE_WIN;
   const int f = blockIdx.x / S, s = blockIdx.x - f * S;
   const int r31 = lane & 31, hi = lane >> 5;
-  const int nl = D >> 7;                       // 128-B lines of one wave's K quarter (<= 4)
-  const int nj = D >> 5;                       // 8-k steps of it (<= 16)
+  // this wave's share of K: whole 128-B lines, [l0, l1) of the D / 32 lines of a row (a quarter of them when D % 128 == 0; a
+  // wave may get none -- it then reads a valid line and multiplies it as zeros)
+  const int NLT = D >> 5;
+  const int l0 = (wave * NLT) >> 2, l1 = ((wave + 1) * NLT) >> 2;
+  const int nl = l1 - l0;                      // lines of this wave (<= 4)
+  const int nj = nl * 4;                       // 8-k steps (<= 16)
+  const int lb = l0 < NLT ? l0 : NLT - 1;      // first line to address
+  const int nlc = nl > 0 ? nl - 1 : 0, njc = nj > 0 ? nj - 1 : 0;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   FSTAMP(0);
   // ---- V.  Lane (t = lane >> 3, sl = lane & 7): 16-B slot sl of the line; row group g holds the rows
@@ -387,13 +141,13 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
   // (multiplied as zeros).
   const int t8 = lane >> 3, sl = lane & 7;
   const int rl = (t8 & 1) * 8 + (t8 >> 1);
-  const float *vq = V + (size_t)f * Nb * D + (size_t)wave * (D >> 2) + sl * 4;
+  const float *vq = V + (size_t)f * Nb * D + (size_t)lb * 32 + sl * 4;
   f32x4 x[16];
   auto v_request = [&](int li) {               // line li of the K quarter, all 32 rows
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int r = s * FEW_ROWS + rl + 4 * (g & 1) + 16 * (g >> 1);
-      x[li * 4 + g] = *reinterpret_cast<const f32x4 *>(vq + (size_t)(r < Nb ? r : Nb - 1) * D + (li < nl ? li : nl - 1) * 32);
+      x[li * 4 + g] = *reinterpret_cast<const f32x4 *>(vq + (size_t)(r < Nb ? r : Nb - 1) * D + (li < nl ? li : nlc) * 32);
     }
   };
   // ---- The entity lengths are the FIRST load of the kernel: vmcnt retires in order, so waiting for them then leaves the V
@@ -434,10 +188,10 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
   }
   FSTAMP(1);
   // ---- W: a lane beyond the live columns reads the last live one (the columns of an MFMA tile are independent; dropped below)
-  const float *wp = Wm + (size_t)cq * D + (size_t)wave * (D >> 2) + hi * 4;
+  const float *wp = Wm + (size_t)cq * D + (size_t)lb * 32 + hi * 4;
   f32x4 w[16];
 #pragma unroll
-  for (int j = 0; j < 16; j++) w[j] = *reinterpret_cast<const f32x4 *>(wp + 8 * (j < nj ? j : nj - 1));
+  for (int j = 0; j < 16; j++) w[j] = *reinterpret_cast<const f32x4 *>(wp + 8 * (j < nj ? j : njc));
   v_request(1);
   v_request(2);
   v_request(3);
@@ -1139,52 +893,16 @@ namespace nafae_sim {
 // L <= 32 live columns (the caller's bound), D % 32 == 0, D <= 512.  workspace: F * ceil(Nb / 64) * 32 * 8 + 256 bytes.
 int64_t few_workspace_bytes(int F, int Nb) { return (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * FEW_MAXL * 8 + 256; }
 
-template <int LT>
-int launch_few_lt(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float2 *parts,
-                  int *qlist, float *S_max, int64_t *D_ind, hipStream_t st) {
-  const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
-  const FewLds lo = few_lds(D, LT, Na);
-  const void *k = reinterpret_cast<const void *>(sim_few_kernel<LT>);
-  if (lo.total > 64 * 1024) {
-    const int rc = allow_dynamic_lds(k, 160 * 1024);
-    if (rc != NAFAE_OK) return rc;
-  }
-  int dbg = 0;
-  if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
-  hipLaunchKernelGGL(sim_few_kernel<LT>, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
-                     S_max, D_ind, dbg);
-  return NAFAE_OK;
-}
-
 int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
                int64_t *D_ind, void *workspace, hipStream_t st) {
   const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
   float2 *parts = reinterpret_cast<float2 *>(workspace);
   int *qlist = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)F * S * FEW_MAXL * 8);
-  int rc = NAFAE_ELIMIT;
-  const char *fe = nafae::experiment_env("NAFAE_SIM_FEW");
-  if (D % 128 == 0 && !(fe && fe[0] == 'v')) {
-    const LiveLds lo = live_lds(Na);
-    int dbg = 0;
-    if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
-    hipLaunchKernelGGL(sim_live_kernel, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
-                       S_max, D_ind, dbg);
-    hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)((F * FEW_MAXL + 255) / 256)), dim3(256), 0, st, parts, qlist, F, Nb,
-                       Na * Ne, S, S_max, D_ind);
-    return launch_status();
-  }
-  switch ((Lh + 3) / 4) {
-    case 1: rc = launch_few_lt<4>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    case 2: rc = launch_few_lt<8>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    case 3: rc = launch_few_lt<12>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    case 4: rc = launch_few_lt<16>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    case 5: rc = launch_few_lt<20>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    case 6: rc = launch_few_lt<24>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    case 7: rc = launch_few_lt<28>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    case 8: rc = launch_few_lt<32>(V, W, ent_len, F, Nb, Na, Ne, D, Lh, parts, qlist, S_max, D_ind, st); break;
-    default: break;
-  }
-  if (rc != NAFAE_OK) return rc;
+  const LiveLds lo = live_lds(Na);
+  int dbg = 0;
+  if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
+  hipLaunchKernelGGL(sim_live_kernel, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
+                     S_max, D_ind, dbg);
   hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)((F * FEW_MAXL + 255) / 256)), dim3(256), 0, st, parts, qlist, F, Nb,
                      Na * Ne, S, S_max, D_ind);
   return launch_status();

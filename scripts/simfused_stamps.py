@@ -25,9 +25,7 @@ st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
 st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
 few = sum(lens) <= 32
-valu = os.environ.get("NAFAE_SIM_FEW", "")[:1] == "v"
-names = ((["start", "prefix+qmap", "W staged", "FMAs", "row sums", "pair best", "end"] if valu else
-          ["start", "prefix+qmap", "MFMAs done", "K quarters in LDS", "end", "-", "-"]) if few else
+names = (["start", "prefix+qmap", "MFMAs done", "K quarters in LDS", "end", "-", "-"] if few else
          ["start", "chunk 0 staged", "k-loop", "scan", "records", "phase A", "end (slow list)"])
 print(name, kind, "waves stamped:", len(st), "(waves 0-3 of a frame-kernel workgroup issue MFMAs, 4-7 stage)")
 for k in range(7):

@@ -388,6 +388,27 @@ def test_dvsa_against_oracle_larger(ops, Na, Ns, Nb, Ne):
             assert relerr(dW, w.grad) < 5 * TOL
 
 
+@pytest.mark.parametrize("D", [32, 96, 256, 1024])
+def test_dvsa_other_embedding_widths(ops, D):
+    """The whole similarity + loss + backward chain at embedding widths other than the reference's 512: D = 32 / 96 take the
+    vector-ALU few-column kernel, 256 the fp32-MFMA one, 1024 the exact-fp32 fallback forward and the 8-chunk backward kernel."""
+    from nafae_amd import synthetic as syn
+    from oracle import dvsa as O
+    Na, Ns, Nb, Ne = 3, 4, 40, 6
+    V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, D, seed=D)
+    lens = [2, 6, 0]
+    for train in (True, False):
+        v, w = V.clone().requires_grad_(), W.clone().requires_grad_()
+        Di, Ds, L = O.dvsa_forward(v, w, lens, Na, Nb, Ne, 10.0, 4.13, "train" if train else "eval")
+        L.backward()
+        S_max, D_ind, loss, dV, dW = _run_dvsa(ops, V, W, lens, Na, Ns, Nb, Ne, 10.0, 4.13, train)
+        assert relerr(S_max, Ds.detach()) < TOL
+        assert torch.equal(D_ind, Di)
+        assert abs(float(loss[0]) - L.item()) < TOL * abs(L.item())
+        assert relerr(dV, v.grad) < 5 * TOL
+        assert relerr(dW, w.grad) < 5 * TOL
+
+
 def test_dvsa_degenerate_shapes(ops):
     """The degenerate shapes SURVEY.md section 8a records as probed on the reference: Ns = 2 makes the clustering term
     identically 1 with zero gradient; Na = 1 makes the ranking term 2*Delta (loss 200 at Delta = 10); Ns = 1 and an
