@@ -258,9 +258,11 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
  *   - contracts V only against the LIVE query slots (e < ent_len[a]); masked slots are written as (0, 0);
  *   - routing (simmax.hip fused_route / make_plan), Qh = the live-column count the launch is sized for
  *     (max_live_cols if >= 0, else Na*Ne):
- *       Qh <= 32, D % 32 == 0, D <= 512         fp32 few-column kernel + merge (simfused.hip sim_live_kernel): every score
- *                                                is an fp32 dot product on the fp32 matrix cores, no filter, no margin;
- *       Qh > 32, Nb > 64, D % 64 == 0, D <= 512  one launch, one workgroup per (frame, 64 / 128 live columns)
+ *       D % 32 == 0, D <= 512, and Qh <= 64 or a shape the next route does not take:
+ *                                                fp32 live-column kernel + merge (simfused.hip sim_live_kernel), ceil(Qh / 32)
+ *                                                column blocks: every score is an fp32 dot product on the fp32 matrix cores,
+ *                                                no filter, no margin;
+ *       Qh > 64, Nb > 64, D % 64 == 0, D <= 512  one launch, one workgroup per (frame, 64 / 128 live columns)
  *                                                (sim_frame_kernel): bf16x3 products on the bf16 matrix cores (hi*hi + hi*lo +
  *                                                lo*hi, fp32 accumulate) as a FILTER that keeps the best three rows per
  *                                                contributor; the winner and every listed row within
@@ -268,18 +270,14 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
  *                                                re-evaluated with exact fp32 dot products; a column whose unlisted rows could lie
  *                                                inside the margin, or that saw a NaN/Inf product, is evaluated exactly over all
  *                                                Nb rows.  The maxima are MEASURED while staging: no precondition on |V|, |W|;
- *       other shapes with D % 32 == 0, D <= 512, Nb <= 2048 (in practice Qh > 32 with Nb <= 64 or D % 64 != 0), if the plan fits
- *                                                160 KB of LDS: the second-generation tile kernels (simmax.hip make_plan;
- *                                                margin 2^-15 * D + 2^-11 * |score|, which assumes |V|, |W| <= 1 -- tanh outputs,
- *                                                model.py:628,642);
- *       anything else (D % 32 != 0, D > 512, Na > 2048, Nb > 2048): the exact-fp32 first-generation kernel of
- *                                                nafae_sim_max_fwd_frames (any D % 4 == 0; F <= 65535, else NAFAE_ELIMIT).
+ *       anything else (D % 32 != 0, D > 512, Na > 2048): the exact-fp32 first-generation kernel of nafae_sim_max_fwd_frames
+ *                                                (any D % 4 == 0; F <= 65535, else NAFAE_ELIMIT).
  *     In every route D_ind follows torch.max: the first maximal row, a NaN score is the maximum (first NaN wins);
  *   - max_live_cols: an UPPER BOUND on the number of live slots, sum_a min(max(ent_len[a],0),Ne), if the host knows it
  *     (it sizes the launch), or -1 = unknown (sized for all Na*Ne).  A bound that is too small is a caller error that is
  *     made visible: the live columns beyond it come back as (NaN, 0), never as a plausible wrong maximum;
- *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes (the largest any route needs), no initialisation
- *     needed.  */
+ *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes (the per-row-block records of the live-column route at
+ *     Qh = Na*Ne: F * ceil(Nb/32) * ceil(Q/32) * 256 bytes + the column map), no initialisation needed.  */
 int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D);
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
                          int max_live_cols, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,

@@ -55,22 +55,26 @@ namespace {
 constexpr int FEW_MAXL = 32;    // live columns the kernel takes (one 32-column MFMA tile)
 constexpr int FEW_ROWS = 32;    // rows per workgroup (one 32-row MFMA tile; its 4 waves split K)
 
-// one thread per (frame, live column): the best of the frame's S workgroups (ties -> smaller row, NaN first: torch.max's rules)
+// one thread per (frame, live column): the best of the frame's S row-block workgroups (ties -> smaller row, NaN first: torch.max's
+// rules).  parts[((f * S + s) * CB + cb) * 32 + c] = (value, row) of column cb * 32 + c over the rows of block s.
 __global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__restrict__ parts, const int *__restrict__ qlist, int F, int Nb,
-                                                            int Q, int S, float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
+                                                            int Q, int S, int CB, float *__restrict__ S_max,
+                                                            int64_t *__restrict__ D_ind) {
+  const int LC = CB * FEW_MAXL;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int f = t / FEW_MAXL, j = t - f * FEW_MAXL;
+  const int f = t / LC, j = t - f * LC;
   if (f >= F) return;
   // (the records of the columns j >= L are inside the workspace, unwritten: every load below is issued before the first
   // result is looked at -- one memory latency instead of three dependent ones)
   const int L = qlist[0];
   const int q = qlist[1 + j];
-  float2 b = parts[((size_t)f * S) * FEW_MAXL + j];
+  const size_t cbo = (size_t)(j >> 5) * FEW_MAXL + (j & 31), stride = (size_t)CB * FEW_MAXL;
+  float2 b = parts[((size_t)f * S) * stride + cbo];
   constexpr int SB = 16;
   for (int s0 = 1; s0 < S; s0 += SB) {
     float2 o[SB];
 #pragma unroll
-    for (int u = 0; u < SB; u++) o[u] = parts[((size_t)f * S + (s0 + u < S ? s0 + u : S - 1)) * FEW_MAXL + j];
+    for (int u = 0; u < SB; u++) o[u] = parts[((size_t)f * S + (s0 + u < S ? s0 + u : S - 1)) * stride + cbo];
 #pragma unroll
     for (int u = 0; u < SB; u++)
       if (s0 + u < S && better_nan(o[u].x, __float_as_int(o[u].y), b.x, __float_as_int(b.y))) b = o[u];
@@ -173,19 +177,23 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
   }
   __syncthreads();
   const int Ql = prefix[Na];
-  int L = Ql < Lh ? Ql : Lh;                   // (columns beyond the caller's bound are reported as NaN below)
-  L = L < FEW_MAXL ? L : FEW_MAXL;
+  const int CB = gridDim.y, cb = blockIdx.y;   // 32-column blocks of the live columns: this workgroup takes block cb
+  int L = Ql < Lh ? Ql : Lh;                   // live columns the launch covers (those beyond the caller's bound: NaN, below)
+  L = L < CB * FEW_MAXL ? L : CB * FEW_MAXL;
+  int Lc = L - cb * FEW_MAXL;                  // ... of which in this block
+  Lc = Lc < 0 ? 0 : (Lc > FEW_MAXL ? FEW_MAXL : Lc);
   // every lane looks up the query row of ITS column (no column map in LDS, no second barrier)
   int cq = 0;
-  if (L > 0) {
-    const int c = r31 < L ? r31 : L - 1;
+  if (Lc > 0) {
+    const int c = cb * FEW_MAXL + (r31 < Lc ? r31 : Lc - 1);
     const int a = find_seg(prefix, Na, c);
     cq = a * Ne + (c - prefix[a]);
   }
-  if (blockIdx.x == 0 && tid < FEW_MAXL) {      // the merge kernel's column -> query map (one workgroup writes it)
-    qlist[1 + tid] = tid < L ? cq : -1;
-    if (tid == 0) qlist[0] = L;
+  if (blockIdx.x == 0 && tid < FEW_MAXL) {      // the merge kernel's column -> query map (the frame-0 workgroups write it)
+    qlist[1 + cb * FEW_MAXL + tid] = tid < Lc ? cq : -1;
+    if (cb == 0 && tid == 0) qlist[0] = L;
   }
+  if (Lc == 0 && !(s == 0 && cb == 0)) return;  // an over-provisioned column block (block (s = 0, cb = 0) still zero-fills)
   FSTAMP(1);
   // ---- W: a lane beyond the live columns reads the last live one (the columns of an MFMA tile are independent; dropped below)
   const float *wp = Wm + (size_t)cq * D + (size_t)lb * 32 + hi * 4;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
   v_request(1);
   v_request(2);
   v_request(3);
-  if (s == 0) {      // this frame's masked slots: (0, 0) (model.py:551); live slots beyond the caller's bound: NaN, loud
+  if (s == 0 && cb == 0) {   // this frame's masked slots: (0, 0) (model.py:551); live slots beyond the caller's bound: NaN, loud
     const int Q = Na * Ne;
     for (int q = tid; q < Q; q += 256) {
       const int a = q / Ne, e = q - a * Ne;
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
       bv = ov;
       bi = oi;
     }
-    if (lane < L) parts[((size_t)f * S + s) * FEW_MAXL + lane] = make_float2(bv, __int_as_float(bi));
+    if (lane < Lc) parts[(((size_t)f * S + s) * CB + cb) * FEW_MAXL + lane] = make_float2(bv, __int_as_float(bi));
   }
   FSTAMP(4);
 }
@@ -890,21 +898,27 @@ int launch_frame(const float *V, const float *W, const int32_t *ent_len, int F, 
 
 namespace nafae_sim {
 
-// L <= 32 live columns (the caller's bound), D % 32 == 0, D <= 512.  workspace: F * ceil(Nb / 64) * 32 * 8 + 256 bytes.
-int64_t few_workspace_bytes(int F, int Nb) { return (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * FEW_MAXL * 8 + 256; }
+// Any number of live columns Lh (the caller's bound) in blocks of 32, D % 32 == 0, D <= 512.  A block re-reads V (from L2 when
+// the blocks of a row block run together), so beyond a few blocks launch_frames is the better route where it applies.
+// workspace: the (max, arg-max) records [F][S][CB][32] of 8 bytes, then the column -> query map.
+int64_t few_workspace_bytes(int F, int Nb, int Q) {
+  const int64_t CB = (Q + FEW_MAXL - 1) / FEW_MAXL;
+  return (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * CB * FEW_MAXL * 8 + (CB * FEW_MAXL + 1) * 4 + 252;
+}
 
 int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
                int64_t *D_ind, void *workspace, hipStream_t st) {
   const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
+  const int CB = (Lh + FEW_MAXL - 1) / FEW_MAXL;
   float2 *parts = reinterpret_cast<float2 *>(workspace);
-  int *qlist = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)F * S * FEW_MAXL * 8);
+  int *qlist = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)F * S * CB * FEW_MAXL * 8);
   const LiveLds lo = live_lds(Na);
   int dbg = 0;
   if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
-  hipLaunchKernelGGL(sim_live_kernel, dim3(F * S), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
+  hipLaunchKernelGGL(sim_live_kernel, dim3(F * S, CB), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
                      S_max, D_ind, dbg);
-  hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)((F * FEW_MAXL + 255) / 256)), dim3(256), 0, st, parts, qlist, F, Nb,
-                     Na * Ne, S, S_max, D_ind);
+  hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)(((long)F * CB * FEW_MAXL + 255) / 256)), dim3(256), 0, st, parts, qlist, F,
+                     Nb, Na * Ne, S, CB, S_max, D_ind);
   return launch_status();
 }
 

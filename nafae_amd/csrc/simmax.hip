@@ -1,702 +1,28 @@
-// simmax.hip -- region x query similarity reduced to per-frame max / arg-max (DVSA.forward, reference
-// model.py:548-551, 580-583, 610-612), second generation, gfx950.
+// simmax.hip -- entry points and routing of the region x query similarity reduced to per-frame max / arg-max (DVSA.forward,
+// reference model.py:548-551, 580-583, 610-612), gfx950.  The kernels are in simfused.hip (sim_live_kernel + merge: fp32 matrix
+// cores, any number of live columns in blocks of 32; sim_frame_kernel: bf16x3 filter + exact fp32 finish per frame, for many
+// live columns) and simloss.hip (sim_max_kernel: the exact-fp32 first-generation kernel, the fallback for the shapes those do
+// not take).  In every route only the LIVE query slots (e < ent_len[a]) are contracted -- the reference zero-fills the S_ column
+// of a padded slot after the product (model.py:551), ~85 % of the columns at 2.07 entities per segment -- S_ is never written,
+// S_max is an fp32 dot product and D_ind follows torch.max (first maximal row, NaN first).
 //
-// What changed against sim_max_kernel (simloss.hip, kept as the exact-fp32 variant and as the fallback for odd shapes):
+// (Round 2's second-generation kernels -- a part / tile kernel streaming V into bf16x3 MFMA fragments, a W pre-pass and a finish
+// kernel that re-gathered the winners' rows -- lived here until the round-3 kernels covered every shape they took; their filter
+// margin assumed |V|, |W| <= 1, which no remaining route does.)
 //
-//   * LIVE COLUMNS ONLY.  The reference zero-fills every S_ column of a padded query slot (a, e >= len_a) after the
-//     product (model.py:551) -- with max_ent_len 13 and 2.07 entities per segment on average, ~85 % of the columns.
-//     The kernel builds the list of live columns from ent_len on the device and contracts V against those alone;
-//     masked slots are written as (0, 0) by the finish kernel.  Results are identical, the product shrinks.
-//   * V IS STREAMED ONCE, STRAIGHT INTO MFMA FRAGMENTS.  A wave owns 32 proposals of one frame.  Lane (r, h) of the
-//     v_mfma_f32_32x32x16_bf16 A operand needs 8 consecutive k of row r, i.e. 32 contiguous bytes of fp32 V: the wave
-//     loads them with global_load_dwordx4 directly (no LDS round trip, no barrier in the k-loop), four 128-B-line
-//     "chunks" (32 k each) in flight per wave, and splits them in registers into bf16 hi/lo.
-//   * W (live columns of one column group, all of K) is converted once per workgroup into LDS as bf16 hi/lo planes in
-//     fragment order: lane (c, h) reads its 16-B B fragment with one conflict-free ds_read_b128 per plane.
-//   * bf16x3 ARITHMETIC: hi*hi + hi*lo + lo*hi, fp32 accumulate -- 3 bf16 MFMAs instead of 16 MFMA-cycles of fp32.
-//     Every (frame, query) keeps the TOP-2 (value, index) per 32-row block; the finish kernel merges the blocks of a
-//     frame and re-evaluates with exact fp32 FMA dot products the winner and every listed runner-up within `margin` of it,
-//     taking the largest (ties -> smaller index, torch.max's rule).  So bf16x3 only FILTERS: S_max is always an fp32 dot
-//     product, and D_ind is decided by fp32 arithmetic wherever bf16x3 could not separate the candidates.
-//     margin = 2^-15 * D + 2^-11 * |score|: twice the rigorous bf16x3 bound 2^-16 * sum|v||w| for |v|,|w| <= 1 (tanh
-//     outputs, model.py:628,642), plus a relative guard.
-//   * Parallelism follows the problem, not a fixed grid: 4 waves per workgroup = RBW row blocks x KS k-splits (K is split
-//     over waves when there are too few row blocks to fill the chip; the partial accumulators are summed through LDS in a
-//     fixed order); a workgroup walks RPW consecutive row groups so that W is converted once; workgroups of the same
-//     rows but different column groups are placed on the same XCD (blockIdx % 8) so that V comes out of that XCD's L2.
-//
-// Algorithmic bytes: 4*D*(R+Q) + 12*F*Q.  Everything here is deterministic (no atomics).
+// Algorithmic bytes: 4*D*(R+Q) + 12*F*Q.  Everything is deterministic (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#include <type_traits>
+#include <stdlib.h>
 
 #include "hip_util.h"
-
 #include "sim_common.h"
 
 using namespace nafae;
 using namespace nafae_sim;
 
-#ifdef NAFAE_EXPERIMENTS
-// phase stamps of sim_part_kernel (experiments build only; scripts/sim_stamps.py): wall_clock64() = 100 MHz
-__device__ unsigned long long nafae_sim_stamps[8 * 4096];
-#define STAMP(k)                                                                              \
-  do {                                                                                        \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)                                          \
-      nafae_sim_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64();     \
-  } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
-
-namespace {
-
-// partial result of one 32-row block for one live column: top-2 (value, proposal index), 16 bytes
-__device__ __forceinline__ f32x4 pack_part(float m1, int i1, float m2, int i2) {
-  f32x4 p = {m1, m2, __int_as_float(i1), __int_as_float(i2)};
-  return p;
-}
-
-// ---------------------------------------------------------------------------------------------------- partial kernel
-// grid: ceil(NSG / 8) * 8 * G workgroups of NW waves (NW = 4 or 8 = blockDim.x / 64), NSG = number of row super-groups (RPW
-// row groups each); a row group = RBW = NW / KS row blocks of 32 proposals.  One 32-column group of live queries per workgroup.
-// LDS: [W planes: D * 32 * 4 B][qmap: 32 ints][scratch: max((Na+1) ints, (NW - RBW) * 4 KB)][V rings: NW * NB * 4 KB]
-//
-// V path: each wave streams ITS 32 rows through its own LDS ring of NB chunks (a chunk = 32 rows x 32 k fp32 = 4 KB) with
-// LDS-DMA (global_load_lds_dwordx4): an instruction covers 8 rows x one full 128-B line, so every L1/TA request is a whole
-// line (loading the MFMA A fragments straight from global memory touches 32 lines per instruction for 32 B each and ran at
-// ~13 B/clk/CU, measured -- the kernel was TA bound at 1/5 of the L2 rate).  The 16-B slots of a row are XOR-swizzled by
-// (row >> 1) & 7 on the SOURCE address (DMA destinations are lane-linear), and un-swizzled by the ds_read_b128 fragment
-// reads, which are then conflict-free in every 16-lane group.  The ring is wave-private: the wave's own counted
-// s_waitcnt vmcnt orders its DMA against its reads, no barrier in the k-loop.
-constexpr int CHUNK_BYTES = 32 * 128;
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int NB>
-__global__ __launch_bounds__(512) void sim_part_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
-                                                       const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
-                                                       int D, int nrb, int G, int KS, int RPW, int Qpad, int scratch_bytes,
-                                                       f32x4 *__restrict__ part) {
-  constexpr int NC = 32;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *wl = smem;                                           // bf16 fragments of W
-  int *qmap = reinterpret_cast<int *>(smem + (size_t)D * NC * 4);
-  unsigned char *scr = smem + (size_t)D * NC * 4 + NC * 4;            // prefix table, later the k-split partials
-  int *prefix = reinterpret_cast<int *>(scr);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NT = blockDim.x, NW = NT >> 6;
-  unsigned char *ring = scr + scratch_bytes + (size_t)wave * NB * CHUNK_BYTES;   // this wave's V ring
-  const int lr = lane & 31, h = lane >> 5;
-  const int RBW = NW / KS;
-  const int rbi = wave / KS, ks = wave - rbi * KS;
-  const int TRB = F * nrb;
-  const int NRG = (TRB + RBW - 1) / RBW;
-  const int NSG = (NRG + RPW - 1) / RPW;
-  const int blk8 = blockIdx.x >> 3;
-  const int sg = (blk8 / G) * 8 + (blockIdx.x & 7);
-  const int g = blk8 % G;
-  if (sg >= NSG) return;
-  STAMP(0);
-
-  // ---- live columns of this column group: exclusive prefix of the clamped entity counts (wave 0), then the column map
-  if (wave == 0) {
-    int carry = 0;
-    for (int base = 0; base < Na; base += 64) {
-      const int a = base + lane;
-      int x = a < Na ? ent_len[a] : 0;
-      x = x < 0 ? 0 : (x > Ne ? Ne : x);
-      int incl = x;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-      }
-      if (a < Na) prefix[a] = carry + incl - x;
-      carry += __shfl(incl, 63);
-    }
-    if (lane == 0) prefix[Na] = carry;
-  }
-  __syncthreads();
-  STAMP(1);
-  const int Ql = prefix[Na];
-  if (g * NC >= Ql) return;              // over-provisioned column group (the host only knows an upper bound)
-  if (tid < NC) {
-    const int c = g * NC + tid;
-    int q = -1;
-    if (c < Ql) {
-      const int a = find_seg(prefix, Na, c);
-      q = a * Ne + (c - prefix[a]);
-    }
-    qmap[tid] = q;
-  }
-  __syncthreads();
-  STAMP(2);
-
-  const int nchunks = D >> 5;
-  const int cpw = nchunks / KS;          // 32-k chunks this wave contracts
-  const int c0 = ks * cpw;
-
-  // ---- this wave's rows for row group `rho`; DMA lane l of instruction j moves row 8j + l/8, physical slot l%8
-  const float *vsrc[4];
-  bool active;
-  int rb, b0;
-  auto set_rows = [&](int rho) {
-    rb = rho * RBW + rbi;
-    active = rb < TRB;
-    const int rbc = active ? rb : TRB - 1;
-    const int f = rbc / nrb;
-    b0 = (rbc - f * nrb) * 32;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int rl = 8 * j + (lane >> 3);
-      int row = b0 + rl;
-      row = row < Nb ? row : Nb - 1;
-      const int slot = (lane & 7) ^ ((rl >> 1) & 7);
-      vsrc[j] = V + ((size_t)f * Nb + row) * D + (size_t)c0 * 32 + slot * 4;
-    }
-  };
-  auto dma_piece = [&](int ci, int j) {  // 8 rows x 128 B of chunk ci of this wave's k-range -> ring slot ci % NB
-    unsigned char *dst = ring + (size_t)(ci % NB) * CHUNK_BYTES;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc[j] + (size_t)ci * 32),
-                                     (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
-  };
-  auto dma_chunk = [&](int ci) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) dma_piece(ci, j);
-  };
-  const int rho0 = sg * RPW;
-  set_rows(rho0);
-
-  // ---- W -> bf16 hi/lo fragments in LDS: 16-B slot of (k-step s, half hh, plane, column cl) at (((s*2+hh)*2+plane)*NC+cl)*16.
-  // U independent 16-B loads per thread are issued before the first one is converted; (column, k4) advance incrementally.
-  // The V ring is started right BEHIND the first batch of W loads: the conversion's wait then covers both (vmcnt retires in
-  // order), and the first chunks are in LDS when the k-loop starts.
-  {
-    constexpr int U = 16;
-    const int k4n = D >> 2;
-    const int total = NC * k4n;
-    const int dcl = NT / k4n, dk4 = NT - dcl * k4n;       // one step of NT float4s in (column, k4) coordinates
-    int cl = tid / k4n, k4 = tid - cl * k4n;
-    bool ring_started = false;
-    for (int base = tid; base < total || !ring_started; base += NT * U) {
-      f32x4 w[U];
-      int off[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const bool ok = cl < NC;
-        const int q = ok ? qmap[cl] : -1;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        w[u] = q >= 0 ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + k4 * 4) : z;
-        const int k = k4 * 4;
-        off[u] = ok ? (((k >> 3) * 2) * NC + cl) * 16 + (k & 4) * 2 : -1;
-        cl += dcl;
-        k4 += dk4;
-        if (k4 >= k4n) {
-          k4 -= k4n;
-          cl += 1;
-        }
-      }
-      if (!ring_started) {
-        for (int ci = 0; ci < NB && ci < cpw; ci++) dma_chunk(ci);
-        ring_started = true;
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        bf16x4 whi, wlo;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const __bf16 t = (__bf16)w[u][e];
-          whi[e] = t;
-          wlo[e] = (__bf16)(w[u][e] - (float)t);
-        }
-        if (off[u] >= 0) {
-          *reinterpret_cast<bf16x4 *>(wl + off[u]) = whi;
-          *reinterpret_cast<bf16x4 *>(wl + off[u] + NC * 16) = wlo;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  STAMP(3);
-
-  const unsigned char *bbase = wl + (size_t)(h * 2 * NC + lr) * 16;   // + s*4*NC*16 + plane*NC*16
-  const int aswz = (lr >> 1) & 7;
-  for (int rr = 0; rr < RPW; rr++) {
-    const int rho = rho0 + rr;
-    if (rho >= NRG) break;
-    if (rr > 0) {
-      set_rows(rho);
-      for (int ci = 0; ci < NB && ci < cpw; ci++) dma_chunk(ci);
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-
-    // One chunk; MORE (a refill exists) and the wait count are compile-time -- two copies of the body, no runtime branch
-    // between the fragment reads and the MFMAs (see sim_tile_kernel).
-    auto chunk = [&](int ci, auto more_tag, auto wait_tag) {
-      constexpr bool MORE = decltype(more_tag)::value;
-      wait_vm<decltype(wait_tag)::value>();
-      const unsigned char *ap = ring + (size_t)(ci % NB) * CHUNK_BYTES + lr * 128;
-      f32x4 x[4];
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int s0 = 4 * t + 2 * h;
-        x[2 * t] = *reinterpret_cast<const f32x4 *>(ap + ((s0 ^ aswz) << 4));
-        x[2 * t + 1] = *reinterpret_cast<const f32x4 *>(ap + (((s0 + 1) ^ aswz) << 4));
-      }
-      bf16x8 bhi[2], blo[2];
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const unsigned char *bp = bbase + (size_t)((c0 + ci) * 2 + t) * (4 * NC * 16);
-        bhi[t] = *reinterpret_cast<const bf16x8 *>(bp);
-        blo[t] = *reinterpret_cast<const bf16x8 *>(bp + NC * 16);
-      }
-      bf16x8 ahi[2], alo[2];
-      split8(x[0], x[1], ahi[0], alo[0]);
-      split8(x[2], x[3], ahi[1], alo[1]);
-      // the fragments are in registers (the MFMAs below wait for them): the slot can be refilled, one staging instruction
-      // per MFMA so that its issue cost overlaps queued matrix work
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], bhi[t], acc, 0, 0, 0);
-        if (MORE) dma_piece(ci + NB, 2 * t);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], blo[t], acc, 0, 0, 0);
-        if (MORE) dma_piece(ci + NB, 2 * t + 1);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], bhi[t], acc, 0, 0, 0);
-      }
-    };
-    using T = std::true_type;
-    using Fl = std::false_type;
-    // (an inactive wave -- row block beyond the batch -- runs the same code on clamped rows; its result is dropped)
-    const int nmain = cpw - NB > 0 ? cpw - NB : 0;          // chunks that still have a refill
-    int ci = 0;
-    for (; ci < nmain; ci++) chunk(ci, T{}, std::integral_constant<int, 4 * (NB - 1)>{});
-    // no refill any more: chunk ci is done once the (cpw - 1 - ci) younger chunks are all that is outstanding; waiting for
-    // everything is at most NB - 1 chunks early
-    for (; ci < cpw; ci++) chunk(ci, Fl{}, std::integral_constant<int, 0>{});
-    STAMP(4);
-
-    if (KS > 1) {          // sum the k-splits of a row block in a fixed order (ks = 1, 2, ... onto ks = 0)
-      float *sc = reinterpret_cast<float *>(scr);
-      __syncthreads();     // (first trip: everyone is done with the prefix table that aliases the scratch)
-      if (ks > 0) {
-        float *dst = sc + (size_t)(rbi * (KS - 1) + (ks - 1)) * 16 * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < 16; r++) dst[r * 64] = acc[r];
-      }
-      __syncthreads();
-      if (ks == 0) {
-        for (int k = 1; k < KS; k++) {
-          const float *src = sc + (size_t)(rbi * (KS - 1) + (k - 1)) * 16 * 64 + lane;
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[r] += src[r * 64];
-        }
-      }
-    }
-
-    STAMP(5);
-    if (ks == 0 && active) {
-      float m1 = -INFINITY, m2 = -INFINITY;
-      int i1 = 0, i2 = 0;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {       // this lane's rows in ascending order
-        const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = acc[r];
-        if (row < Nb) {
-          if (v > m1) {
-            m2 = m1; i2 = i1; m1 = v; i1 = row;
-          } else if (v > m2) {
-            m2 = v; i2 = row;
-          }
-        }
-      }
-      // merge with the other half of the column (lane ^ 32), ordering (value desc, index asc)
-      const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
-      const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
-      float n1, n2;
-      int k1, k2;
-      if (better(o1, j1, m1, i1)) {
-        n1 = o1; k1 = j1;
-        if (better(m1, i1, o2, j2)) { n2 = m1; k2 = i1; } else { n2 = o2; k2 = j2; }
-      } else {
-        n1 = m1; k1 = i1;
-        if (better(m2, i2, o1, j1)) { n2 = m2; k2 = i2; } else { n2 = o1; k2 = j1; }
-      }
-      const int c = g * NC + lr;
-      if (h == 0 && c < Ql) part[(size_t)rb * Qpad + c] = pack_part(n1, k1, n2, k2);
-    }
-    STAMP(6);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------- dense path
-// More than 64 live query slots (C5 with every slot live: 512): one 32-column group per workgroup would stream V 16 times and
-// repeat the fp32 -> bf16 hi/lo split of every V fragment for each of them (VALU-bound).  Here a workgroup owns 128 rows x 128
-// live columns: the split of an A fragment is amortised over 4 column blocks (24 MFMAs per 32-k chunk and wave), V is re-read
-// Q/128 times, and BOTH operands arrive by LDS-DMA in one ring of NB chunks -- W is converted once per call into bf16 hi/lo
-// planes in fragment order by sim_wprep_kernel (the k-loop must not contain ordinary global loads: beside outstanding LDS-DMA
-// the compiler waits vmcnt(0) at their first use and drains the ring), so a chunk of W is a linear 16 KB copy.
-constexpr int TILE_COLS = 128;
-constexpr int WCHUNK_BYTES = 2 * 2 * 2 * TILE_COLS * 16;   // [k-step][half][plane][column][16 B] = 16 KB per 32 k
-
-// grid (nchunks, G128); writes wprep[(cg * nchunks + ci) * 16 KB ...] and, once, the live-column count into hdr[0]
-__global__ __launch_bounds__(256) void sim_wprep_kernel(const float *__restrict__ Wm, const int32_t *__restrict__ ent_len, int Na,
-                                                        int Ne, int D, unsigned char *__restrict__ wprep, int *__restrict__ hdr) {
-  __shared__ int prefix[NA_MAX + 1];
-  __shared__ int qmap[TILE_COLS];
-  build_prefix(ent_len, Na, Ne, prefix);
-  __syncthreads();
-  const int Ql = prefix[Na];
-  const int ci = blockIdx.x, cg = blockIdx.y, nchunks = gridDim.x;
-  if (ci == 0 && cg == 0 && threadIdx.x == 0) hdr[0] = Ql;
-  if (threadIdx.x < TILE_COLS) {
-    const int c = cg * TILE_COLS + threadIdx.x;
-    int q = -1;
-    if (c < Ql) {
-      const int a = find_seg(prefix, Na, c);
-      q = a * Ne + (c - prefix[a]);
-    }
-    qmap[threadIdx.x] = q;
-  }
-  __syncthreads();
-  unsigned char *dst = wprep + ((size_t)cg * nchunks + ci) * WCHUNK_BYTES;
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int idx = threadIdx.x + 256 * u;        // 128 columns x 8 float4 of this chunk
-    const int cl = idx >> 3, k4 = idx & 7;
-    const int q = qmap[cl];
-    f32x4 w = {0.f, 0.f, 0.f, 0.f};
-    if (q >= 0) w = *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + ci * 32 + k4 * 4);
-    bf16x4 whi, wlo;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const __bf16 t = (__bf16)w[e];
-      whi[e] = t;
-      wlo[e] = (__bf16)(w[e] - (float)t);
-    }
-    const int k = k4 * 4;                         // 0..28 inside the chunk: k-step t = k >> 4, half = (k >> 3) & 1
-    const int off = ((((k >> 3) * 2) * TILE_COLS) + cl) * 16 + (k & 4) * 2;
-    *reinterpret_cast<bf16x4 *>(dst + off) = whi;
-    *reinterpret_cast<bf16x4 *>(dst + off + TILE_COLS * 16) = wlo;
-  }
-}
-
-// grid: ceil(NRG / 8) * 8 * G128 workgroups of NWT waves; NRG = row groups of NWT row blocks (32 * NWT proposals).
-// LDS: NB x (16 KB of W + NWT x 4 KB of V).  NWT = 8 (two waves per SIMD): with one wave per SIMD nothing hides the latency of
-// the 20 fragment reads per chunk (ablation: the loop took the same 60 us with the MFMAs and the DMAs removed).
-template <int NB, int NWT>
-__global__ __launch_bounds__(64 * NWT) void sim_tile_kernel(const float *__restrict__ V, const unsigned char *__restrict__ wprep,
-                                                       const int *__restrict__ hdr, int F, int Nb, int D, int nrb, int G,
-                                                       int Qpad, f32x4 *__restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 31, h = lane >> 5;
-  constexpr int WP = 16 / NWT;           // 1 KB pieces of a W chunk per wave
-  constexpr int PP = 4 + WP;             // staging instructions per chunk and wave
-  const int TRB = F * nrb, NRG = (TRB + NWT - 1) / NWT;
-  const int blk8 = blockIdx.x >> 3;
-  const int rho = (blk8 / G) * 8 + (blockIdx.x & 7);
-  const int g = blk8 % G;
-  if (rho >= NRG) return;
-  const int Ql = hdr[0];
-  if (g * TILE_COLS >= Ql) return;
-  const int nchunks = D >> 5;
-  unsigned char *wring = smem;                                        // [NB][16 KB]
-  unsigned char *vring = smem + (size_t)NB * WCHUNK_BYTES + (size_t)wave * NB * CHUNK_BYTES;
-
-  const int rb = rho * NWT + wave;
-  const bool active = rb < TRB;
-  const int rbc = active ? rb : TRB - 1;
-  const int f = rbc / nrb, b0 = (rbc - f * nrb) * 32;
-  const float *vsrc[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int rl = 8 * j + (lane >> 3);
-    int row = b0 + rl;
-    row = row < Nb ? row : Nb - 1;
-    vsrc[j] = V + ((size_t)f * Nb + row) * D + ((lane & 7) ^ ((rl >> 1) & 7)) * 4;
-  }
-  const unsigned char *wsrc = wprep + (size_t)g * nchunks * WCHUNK_BYTES + (size_t)wave * (WP * 1024) + lane * 16;
-  // piece p of chunk ci: p = 0..3 this wave's V rows (8 rows x 128 B each), p = 4.. this wave's share of the W chunk
-  auto dma_piece = [&](int ci, int p) {
-    const int slot = ci % NB;
-    if (p < 4)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vsrc[p] + (size_t)ci * 32),
-                                       (__attribute__((address_space(3))) void *)(vring + (size_t)slot * CHUNK_BYTES + p * 1024), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)ci * WCHUNK_BYTES + (p - 4) * 1024),
-                                       (__attribute__((address_space(3))) void *)(wring + (size_t)slot * WCHUNK_BYTES + wave * (WP * 1024) + (p - 4) * 1024),
-                                       16, 0, 0);
-  };
-  for (int ci = 0; ci < NB - 1 && ci < nchunks; ci++) {
-#pragma unroll
-    for (int p = 0; p < PP; p++) dma_piece(ci, p);
-  }
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int cb = 0; cb < 4; cb++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
-  const int aswz = (lr >> 1) & 7;
-  // One chunk.  MORE / the wait count are compile-time (two copies of the body: steady state and tail), and there is no
-  // branch between the fragment reads and the MFMAs: with runtime conditions in here hipcc cut the unrolled body into one
-  // basic block per column block, each "2 ds_read_b128 -> lgkmcnt(0) -> 3 MFMAs" serialised on the LDS latency (measured:
-  // 2 600 cycles per chunk, the same with the MFMAs removed).  All 8 B fragments of a k-step are requested before its MFMAs.
-  auto chunk = [&](int ci, auto more_tag, auto wait_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
-    wait_vm<decltype(wait_tag)::value>();
-    __builtin_amdgcn_s_barrier();        // everyone's share of W(ci) has landed; everyone is done reading slot (ci - 1) % NB
-    const unsigned char *ap = vring + (size_t)(ci % NB) * CHUNK_BYTES + lr * 128;
-    const unsigned char *wp = wring + (size_t)(ci % NB) * WCHUNK_BYTES + (size_t)(h * 2 * TILE_COLS + lr) * 16;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const int s0 = 4 * t + 2 * h;
-      const f32x4 x0 = *reinterpret_cast<const f32x4 *>(ap + ((s0 ^ aswz) << 4));
-      const f32x4 x1 = *reinterpret_cast<const f32x4 *>(ap + (((s0 + 1) ^ aswz) << 4));
-      const unsigned char *bp = wp + (size_t)t * (4 * TILE_COLS * 16);
-      bf16x8 bhi[4], blo[4];
-#pragma unroll
-      for (int cb = 0; cb < 4; cb++) {
-        bhi[cb] = *reinterpret_cast<const bf16x8 *>(bp + cb * 512);
-        blo[cb] = *reinterpret_cast<const bf16x8 *>(bp + TILE_COLS * 16 + cb * 512);
-      }
-      bf16x8 ahi, alo;
-      split8(x0, x1, ahi, alo);
-#pragma unroll
-      for (int cb = 0; cb < 4; cb++) {
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[cb], acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[cb], acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[cb], acc[cb], 0, 0, 0);
-        // the staging instructions of chunk ci + NB - 1 go out one per MFMA group (each costs 60-185 issue cycles)
-        if (MORE && t * 4 + cb < PP) dma_piece(ci + NB - 1, t * 4 + cb);
-      }
-    }
-  };
-  using T = std::true_type;
-  using Fl = std::false_type;
-  // issued before iteration ci: chunks 0 .. ci + NB - 2, so (NB - 2) chunks are younger than ci while they all exist
-  const int nmain = nchunks - (NB - 1) > 0 ? nchunks - (NB - 1) : 0;
-  int ci = 0;
-  for (; ci < nmain; ci++) chunk(ci, T{}, std::integral_constant<int, PP * (NB - 2)>{});
-  for (; ci < nchunks; ci++) chunk(ci, Fl{}, std::integral_constant<int, 0>{});
-  if (!active) return;
-#pragma unroll
-  for (int cb = 0; cb < 4; cb++) {
-    float m1 = -INFINITY, m2 = -INFINITY;
-    int i1 = 0, i2 = 0;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float v = acc[cb][r];
-      if (row < Nb) {
-        if (v > m1) {
-          m2 = m1; i2 = i1; m1 = v; i1 = row;
-        } else if (v > m2) {
-          m2 = v; i2 = row;
-        }
-      }
-    }
-    const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
-    const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
-    float n1, n2;
-    int k1, k2;
-    if (better(o1, j1, m1, i1)) {
-      n1 = o1; k1 = j1;
-      if (better(m1, i1, o2, j2)) { n2 = m1; k2 = i1; } else { n2 = o2; k2 = j2; }
-    } else {
-      n1 = m1; k1 = i1;
-      if (better(m2, i2, o1, j1)) { n2 = m2; k2 = i2; } else { n2 = o1; k2 = j1; }
-    }
-    const int c = g * TILE_COLS + cb * 32 + lr;
-    if (h == 0 && c < Ql) part[(size_t)rb * Qpad + c] = pack_part(n1, k1, n2, k2);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------- finish kernel
-// One WAVE per (frame, live column): merge the frame's row blocks, then evaluate with exact fp32 FMA dot products the winner
-// and every listed runner-up within the margin, and take the best of those (ties -> smaller index).  S_max is therefore always
-// an fp32 dot product of the winning pair (the loss tail divides by max - min over frames and is sensitive to ~1e-6 relative
-// errors), and D_ind is decided in fp32 wherever bf16x3 could not separate the candidates.  The workgroups also zero-fill the
-// masked query slots.  grid: ceil(F * Qh / 4) workgroups of 256 threads (Qh = the host's upper bound on live columns).
-__global__ __launch_bounds__(256) void sim_finish_kernel(const f32x4 *__restrict__ part, const float *__restrict__ V,
-                                                         const float *__restrict__ Wm, const int32_t *__restrict__ ent_len,
-                                                         int F, int Nb, int Na, int Ne, int D, int nrb, int Qpad, int Qh,
-                                                         float *__restrict__ S_max, int64_t *__restrict__ D_ind) {
-  __shared__ int prefix[NA_MAX + 1];
-  build_prefix(ent_len, Na, Ne, prefix);
-  __syncthreads();
-  const int Q = Na * Ne;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {  // masked slots: the whole S_ column is 0 (model.py:551) -> (0, 0)
-    const long total = (long)F * Q;
-    const long per = (total + gridDim.x - 1) / gridDim.x;
-    const long lo = (long)blockIdx.x * per;
-    long hi = lo + per;
-    hi = hi < total ? hi : total;
-    for (long idx = lo + threadIdx.x; idx < hi; idx += 256) {
-      const int q = (int)(idx % Q);
-      const int a = q / Ne, e = q - a * Ne;
-      if (e >= ent_len[a]) {
-        S_max[idx] = 0.f;
-        D_ind[idx] = 0;
-      }
-    }
-  }
-  const long item = (long)blockIdx.x * 4 + wave;
-  const int f = (int)(item / Qh), c = (int)(item - (long)f * Qh);
-  if (f >= F || c >= prefix[Na]) return;
-  const int a = find_seg(prefix, Na, c);
-  const int q = a * Ne + (c - prefix[a]);
-
-  f32x4 e = {-INFINITY, -INFINITY, 0.f, 0.f};
-  if (lane < nrb) e = part[((size_t)f * nrb + lane) * Qpad + c];
-  // this lane's slice of the query row (D <= 1024: at most 4 pieces of 4 floats); requested beside the partials
-  const float *wrow = Wm + (size_t)q * D;
-  f32x4 wf[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    const int d = lane * 4 + 256 * t;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    wf[t] = d < D ? *reinterpret_cast<const f32x4 *>(wrow + d) : z;
-  }
-  const int i1 = __float_as_int(e[2]), i2 = __float_as_int(e[3]);
-  float bm = e[0];
-  int bidx = i1;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float om = __shfl_xor(bm, o);
-    const int oi = __shfl_xor(bidx, o);
-    if (better(om, oi, bm, bidx)) {
-      bm = om;
-      bidx = oi;
-    }
-  }
-  const float margin = 3.0517578125e-05f * (float)D + 4.8828125e-04f * fabsf(bm);   // 2^-15 * D + 2^-11 * |score|
-  unsigned long long c1 = __ballot(lane < nrb && bm - e[0] < margin);   // includes the winner (0 < margin)
-  unsigned long long c2 = __ballot(lane < nrb && bm - e[1] < margin);
-  float eb = -INFINITY;
-  int ei = 0x7fffffff;
-  auto eval = [&](int i) {
-    const float *vrow = V + ((size_t)f * Nb + i) * D;
-    float acc = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int d = lane * 4 + 256 * t;
-      if (d < D) {
-        const f32x4 x = *reinterpret_cast<const f32x4 *>(vrow + d);
-        acc = fmaf(x[0], wf[t][0], acc);
-        acc = fmaf(x[1], wf[t][1], acc);
-        acc = fmaf(x[2], wf[t][2], acc);
-        acc = fmaf(x[3], wf[t][3], acc);
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (better(acc, i, eb, ei)) {
-      eb = acc;
-      ei = i;
-    }
-  };
-  while (c1) {
-    const int src = __ffsll((long long)c1) - 1;
-    c1 &= c1 - 1;
-    eval(__shfl(i1, src));
-  }
-  while (c2) {
-    const int src = __ffsll((long long)c2) - 1;
-    c2 &= c2 - 1;
-    eval(__shfl(i2, src));
-  }
-  if (ei == 0x7fffffff) {
-    // nothing was re-evaluated: the frame's scores are NaN or infinite (margin / bm - e compare false everywhere).  torch.max
-    // propagates the NaN with a valid index; an out-of-range D_ind would reach the box gathers of postprocess / record_det
-    eb = (bm == bm && fabsf(bm) != INFINITY) ? bm : NAN;
-    ei = (bidx >= 0 && bidx < Nb) ? bidx : 0;
-  }
-  if (lane == 0) {
-    S_max[(size_t)f * Q + q] = eb;
-    D_ind[(size_t)f * Q + q] = (int64_t)ei;
-  }
-}
-
-struct Plan {
-  int ok, dense, NCB, NC, G, KS, RBW, RPW, NW, NB, scratch, nrb, TRB, NRG, NSG, Qpad, Qh;
-  int64_t wprep_off;     // dense path: byte offset of the converted-W area (after the partials); header int right before it
-  size_t lds;
-  int64_t ws_bytes;
-};
-
-inline Plan make_plan(int F, int Nb, int Na, int Ne, int D, int max_live) {
-  Plan p{};
-  const int Q = Na * Ne;
-  int Qh = (max_live < 0 || max_live > Q) ? Q : max_live;
-  if (Qh < 1) Qh = 1;
-  p.Qh = Qh;
-  p.ok = (D % 32 == 0) && D <= 512 && Na <= NA_MAX && F >= 1 && Nb >= 1 && Nb <= 2048;   // (Nb: <= 64 row blocks per frame)
-  if (!p.ok) return p;
-  p.nrb = (Nb + 31) / 32;
-  p.TRB = F * p.nrb;
-  const int nchunks = D / 32;
-  if (Qh > 64) {          // dense path: 128-column tiles, W pre-converted (sim_wprep_kernel + sim_tile_kernel)
-    p.dense = 1;
-    p.G = (Qh + TILE_COLS - 1) / TILE_COLS;
-    p.Qpad = p.G * TILE_COLS;
-    p.NW = 4;
-    p.NRG = (p.TRB + p.NW - 1) / p.NW;
-    p.NB = 2;
-    p.lds = (size_t)p.NB * (WCHUNK_BYTES + p.NW * CHUNK_BYTES);
-    const int64_t parts = (int64_t)p.TRB * p.Qpad * 16;
-    p.wprep_off = ((parts + 255) / 256) * 256 + 256;
-    p.ws_bytes = p.wprep_off + (int64_t)p.G * nchunks * WCHUNK_BYTES;
-    return p;
-  }
-  p.NCB = 1;
-  p.NC = 32;
-  p.G = (Qh + p.NC - 1) / p.NC;
-  // One workgroup fits per CU (W planes + rings ~ 156 KB of LDS).  K is split over the waves of a workgroup only while
-  // 4-wave workgroups of whole row blocks would leave CUs without any workgroup (fewer than 1024 row blocks x column
-  // groups); workgroups have 8 waves (two per SIMD, 2-chunk rings) once every CU gets at least 8 waves of work anyway,
-  // else 4 (5-chunk rings: 80 KB of V in flight per CU, what it takes to pull ~25 GB/s per CU out of HBM).
-  int KS = 1;
-  while (KS < 4 && (long)p.TRB * p.G * KS * 2 <= 1024 && nchunks % (KS * 2) == 0 && nchunks / (KS * 2) >= 2) KS *= 2;
-  p.KS = KS;
-  p.NW = (KS == 1 && (long)p.TRB * p.G >= 8L * 256) ? 8 : 4;
-  p.RBW = p.NW / KS;
-  p.NB = p.NW == 8 ? 2 : 5;
-  const size_t scratch_ks = (size_t)(p.NW - p.RBW) * 16 * 64 * 4;
-  const size_t scratch_px = (((size_t)(Na + 1) * 4) + 15) & ~(size_t)15;
-  p.scratch = (int)(scratch_ks > scratch_px ? scratch_ks : scratch_px);
-  p.lds = (size_t)D * p.NC * 4 + p.NC * 4 + p.scratch + (size_t)p.NW * p.NB * CHUNK_BYTES;
-  if (p.lds > 160 * 1024) {
-    p.ok = 0;
-    return p;
-  }
-  p.NRG = (p.TRB + p.RBW - 1) / p.RBW;
-  // row groups per workgroup: one round of workgroups over the chip (W is converted once per workgroup)
-  const long units = (long)p.NRG * p.G;
-  long RPW = (units + 255) / 256;
-  if (RPW < 1) RPW = 1;
-  if (RPW > 16) RPW = 16;
-  p.RPW = (int)RPW;
-  p.NSG = (p.NRG + p.RPW - 1) / p.RPW;
-  p.Qpad = p.G * p.NC;
-  p.ws_bytes = (int64_t)p.TRB * p.Qpad * 16;
-  return p;
-}
-
-}  // namespace
-
 namespace nafae_sim {          // simfused.hip
-int64_t few_workspace_bytes(int F, int Nb);
+int64_t few_workspace_bytes(int F, int Nb, int Q);
 int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
                int64_t *D_ind, void *workspace, hipStream_t st);
 int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
@@ -704,27 +30,25 @@ int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F,
 }  // namespace nafae_sim
 
 namespace {
-// Which generation takes a call.  3 (simfused.hip): D % 32 == 0, D <= 512 and either at most 32 live columns (exact-fp32 stream
-// kernel) or more than 32 with more than 64 proposals per frame (frame kernel).  NAFAE_SIM_GEN=2 (experiments build only) keeps
-// the second-generation kernels of this file for A/B timing.
+// Live columns up to which the fp32-MFMA kernel is taken when the frame kernel applies as well: every 32-column block of it is one
+// more pass over V (out of L2) and 4-6 us of fp32 MFMA issue at C5, the frame kernel starts at ~30 us.  Measured (graph time per
+// call, live / frame kernel): 33-64 columns C5 28-29 / 34 us, C4 23-24 / 27-28, C2 15 / 19-20; 96 columns C5 41 / 44, C4 32 / 28;
+// 128 columns C5 49 / 44, C4 42 / 28, C2 23 / 20 (scripts/sim_sweep_live.py).
+constexpr int LIVE_MAX_DEFAULT = 64;
+
+// 0: the exact-fp32 fallback (simloss.hip), 1: sim_live_kernel + merge, 2: sim_frame_kernel
 inline int fused_route(int F, int Nb, int Na, int Ne, int D, int Qh) {
-  const char *e = nafae::experiment_env("NAFAE_SIM_GEN");
-  if (e && e[0] == '2') return 0;
   if (D % 32 != 0 || D > 512 || Na > NA_MAX || F < 1 || Nb < 1) return 0;
   if ((long)Nb * D >= (1L << 30) || (long)Na * Ne * D >= (1L << 30)) return 0;      // 32-bit element offsets inside the kernels
-  if (Qh <= 32) return 1;
-  if (Nb > 64 && D % 64 == 0) return 2;      // (the frame kernel's staging loop takes the 32-k chunks two at a time)
-  return 0;
+  int live_max = LIVE_MAX_DEFAULT;
+  if (const char *e = nafae::experiment_env("NAFAE_SIM_LIVE_MAX")) live_max = atoi(e);
+  const bool frame_ok = Nb > 64 && D % 64 == 0;      // (the frame kernel's staging loop takes the 32-k chunks two at a time)
+  if (Qh <= live_max || !frame_ok) return (Qh + 31) / 32 <= 65535 ? 1 : 0;
+  return 2;
 }
 }  // namespace
 
 extern "C" {
-
-#ifdef NAFAE_EXPERIMENTS
-int nafae_sim_debug_stamps(unsigned long long *out_host, int n) {
-  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(nafae_sim_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -3;
-}
-#endif
 
 // exact-fp32 first-generation kernel (simloss.hip): the fallback for shapes this file does not take
 int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
@@ -732,13 +56,7 @@ int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_
 
 int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D) {
   if (F <= 0 || Nb <= 0 || Na <= 0 || Ne <= 0 || D <= 0) return NAFAE_EINVAL;
-  const Plan p = make_plan(F, Nb, Na, Ne, D, -1);
-  const int64_t few = nafae_sim::few_workspace_bytes(F, Nb);
-  if (!p.ok) return few;                 // (the exact-fp32 fallback kernel needs none)
-  // the all-live plan is the largest: partials for Q rounded up to a 128-column tile + the converted W + header
-  const int64_t q128 = ((int64_t)Na * Ne + 127) / 128 * 128;
-  const int64_t gen2 = (int64_t)p.TRB * q128 * 16 + 1024 + q128 * D * 4;
-  return gen2 > few ? gen2 : few;
+  return nafae_sim::few_workspace_bytes(F, Nb, Na * Ne);        // (the other routes need none)
 }
 
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
@@ -747,60 +65,16 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
   if (!V || !W || !ent_len || !S_max || !D_ind) return NAFAE_EINVAL;
   if (Na <= 0 || F <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
   if ((long)F * Na * Ne > (1L << 31) - 256) return NAFAE_ELIMIT;
-  {
-    const int Q = Na * Ne;
-    int Qh = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
-    if (Qh < 1) Qh = 1;
-    const int route = fused_route(F, Nb, Na, Ne, D, Qh);
-    if (route == 1) {
-      if (!workspace || workspace_bytes < nafae_sim::few_workspace_bytes(F, Nb)) return NAFAE_EINVAL;
-      return nafae_sim::launch_few(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, workspace, as_stream(stream));
-    }
-    if (route == 2) return nafae_sim::launch_frames(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, as_stream(stream));
+  const int Q = Na * Ne;
+  int Qh = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
+  if (Qh < 1) Qh = 1;
+  const int route = fused_route(F, Nb, Na, Ne, D, Qh);
+  if (route == 1) {
+    if (!workspace || workspace_bytes < nafae_sim::few_workspace_bytes(F, Nb, Qh)) return NAFAE_EINVAL;
+    return nafae_sim::launch_few(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, workspace, as_stream(stream));
   }
-  const Plan p = make_plan(F, Nb, Na, Ne, D, max_live_cols);
-  if (!p.ok) return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
-  if (!workspace || workspace_bytes < p.ws_bytes) return NAFAE_EINVAL;
-  if ((long)F * Na * Ne > (1L << 31) - 256) return NAFAE_ELIMIT;
-  if (p.dense) {
-    unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
-    int *hdr = reinterpret_cast<int *>(wsb + p.wprep_off - 256);
-    unsigned char *wprep = wsb + p.wprep_off;
-    f32x4 *part = reinterpret_cast<f32x4 *>(workspace);
-    hipStream_t st = as_stream(stream);
-    const int nchunks = D / 32;
-    hipLaunchKernelGGL(sim_wprep_kernel, dim3(nchunks, p.G), dim3(256), 0, st, W, ent_len, Na, Ne, D, wprep, hdr);
-    const void *tk = reinterpret_cast<const void *>(sim_tile_kernel<2, 4>);
-    if (p.lds > 64 * 1024) {
-      const int rc = allow_dynamic_lds(tk, 160 * 1024);
-      if (rc != NAFAE_OK) return rc;
-    }
-    const int grid = ((p.NRG + 7) / 8) * 8 * p.G;
-    hipLaunchKernelGGL((sim_tile_kernel<2, 4>), dim3(grid), dim3(256), p.lds, st, V, wprep, hdr, F, Nb, D, p.nrb, p.G, p.Qpad, part);
-    const long items = (long)F * p.Qh;
-    hipLaunchKernelGGL(sim_finish_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, part, V, W, ent_len, F, Nb, Na, Ne, D,
-                       p.nrb, p.Qpad, p.Qh, S_max, D_ind);
-    return launch_status();
-  }
-  const void *kern = p.NB == 2 ? reinterpret_cast<const void *>(sim_part_kernel<2>)
-                               : reinterpret_cast<const void *>(sim_part_kernel<5>);
-  if (p.lds > 64 * 1024) {
-    const int rc = allow_dynamic_lds(kern, 160 * 1024);
-    if (rc != NAFAE_OK) return rc;
-  }
-  const int grid = ((p.NSG + 7) / 8) * 8 * p.G;
-  f32x4 *part = reinterpret_cast<f32x4 *>(workspace);
-  hipStream_t st = as_stream(stream);
-  if (p.NB == 2)
-    hipLaunchKernelGGL(sim_part_kernel<2>, dim3(grid), dim3(64 * p.NW), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
-                       p.RPW, p.Qpad, p.scratch, part);
-  else
-    hipLaunchKernelGGL(sim_part_kernel<5>, dim3(grid), dim3(64 * p.NW), p.lds, st, V, W, ent_len, F, Nb, Na, Ne, D, p.nrb, p.G, p.KS,
-                       p.RPW, p.Qpad, p.scratch, part);
-  const long items = (long)F * p.Qh;
-  hipLaunchKernelGGL(sim_finish_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, part, V, W, ent_len, F, Nb, Na, Ne, D,
-                     p.nrb, p.Qpad, p.Qh, S_max, D_ind);
-  return launch_status();
+  if (route == 2) return nafae_sim::launch_frames(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, as_stream(stream));
+  return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
 }
 
 }  // extern "C"

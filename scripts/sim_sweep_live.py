@@ -10,7 +10,7 @@ Na, Ns, Nb, Ne = W[name]
 V, Wt = syn.embeddings(Na * Ns * Nb, Na * Ne, 512, seed=1)
 V, Wt = V.cuda(), Wt.cuda()
 st = torch.cuda.Stream()
-for L in (8, 17, 24, 32, 33, 40, 48, 64, 96, 128, 192, 256, Na * Ne):
+for L in (17, 32, 33, 48, 64, 96, 128, 192, 256, Na * Ne):
     if L > Na * Ne: continue
     lens = [L // Na + (1 if a < L % Na else 0) for a in range(Na)]
     if max(lens) > Ne: continue

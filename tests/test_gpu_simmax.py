@@ -1,5 +1,5 @@
-"""The second-generation similarity kernel (nafae_sim_max_fwd_ws: live columns only, bf16x3 MFMA, top-2 per row block,
-fp32 re-evaluation of near-ties) against an fp64 evaluation of model.py:548-551,580-583,610-612 and against the
+"""The similarity entry point nafae_sim_max_fwd_ws (live columns only; fp32-MFMA live-column kernel, bf16x3-filter frame kernel
+with exact fp32 finish, exact-fp32 fallback) against an fp64 evaluation of model.py:548-551,580-583,610-612 and against the
 first-generation exact-fp32 kernel, over ragged / degenerate / adversarial shapes."""
 import numpy as np
 import pytest
@@ -230,8 +230,8 @@ def test_sim_max_unsquashed_embeddings_with_planted_near_ties(Ne, lens):
         assert (S[masked] == 0).all() and (Di[masked] == 0).all()
 
 
-@pytest.mark.parametrize("Ne,lens,hint", [(8, [8, 5], 9), (8, [8, 8], 4), (40, [40, 33], 40), (64, [64, 64], 64)],
-                         ids=["few9of13", "few4of16", "dense40of73", "dense64of128"])
+@pytest.mark.parametrize("Ne,lens,hint", [(8, [8, 5], 9), (8, [8, 8], 4), (40, [40, 33], 40), (64, [64, 64], 64), (100, [100, 100], 70)],
+                         ids=["few9of13", "few4of16", "live40of73", "live64of128", "frames70of200"])
 def test_sim_max_too_small_live_hint_is_loud(Ne, lens, hint):
     """max_live_cols is an UPPER BOUND the host promises.  If it is too small the live columns beyond it cannot be computed:
     they must come back as NaN (like the loss kernel's NaN for the same mistake), never as silently wrong numbers; the columns
@@ -260,7 +260,8 @@ def test_sim_max_too_small_live_hint_is_loud(Ne, lens, hint):
             live_index[a * Ne + e] = n
             n += 1
     assert n > hint
-    computed = (live_index >= 0) & (live_index < (hint if hint <= 32 else ((hint + 63) // 64) * 64))
+    # (the live-column route, hint <= 64, computes exactly `hint` columns; the frame kernel whole groups of 64)
+    computed = (live_index >= 0) & (live_index < (hint if hint <= 64 else ((hint + 63) // 64) * 64))
     lost = (live_index >= 0) & ~computed
     assert lost.any() and torch.isnan(S[:, lost]).all() and (Di[:, lost] == 0).all()
     scale = float(m.abs().max())
