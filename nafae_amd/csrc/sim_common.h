@@ -1,5 +1,5 @@
-// sim_common.h -- pieces shared by the similarity kernels (simmax.hip, simfused.hip): live-column bookkeeping, the
-// arg-max ordering, the fp32 -> bf16 hi/lo split.
+// sim_common.h -- pieces of the similarity kernels (simfused.hip; limits used by the routing in simmax.hip): live-column
+// bookkeeping, the arg-max ordering, the fp32 -> bf16 hi/lo split, wave reductions.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,17 +56,6 @@ __device__ __forceinline__ int find_seg(const int *prefix, int Na, int c) {
     if (prefix[mid] <= c) lo = mid; else hi = mid;
   }
   return lo;
-}
-
-__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8 &hi, bf16x8 &lo) {
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
-    hi[e] = h0;
-    hi[4 + e] = h1;
-    lo[e] = (__bf16)(x0[e] - (float)h0);
-    lo[4 + e] = (__bf16)(x1[e] - (float)h1);
-  }
 }
 
 // hi = bf16(x), lo = bf16(x - hi), two elements per instruction: v_cvt_pk_bf16_f32 packs a pair, the pair's two halves widened
