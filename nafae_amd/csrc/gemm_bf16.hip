@@ -399,6 +399,168 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
   epilogue<E, SPLIT && !PAIR>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);   // PAIR: plain bf16 / fp32 output
 }
 
+// ------------------------------------------------------------------------------------------------ 4-wave GEMM
+// The 256x256 interleaved-operand GEMM on ONE wave per SIMD: 4 waves = 2 x 2, a wave holds a 128x128 register tile -- sixteen
+// 32x32 accumulator tiles = 256 registers, which hipcc places in AGPRs when the kernel may use the whole 512-register file
+// (amdgpu_waves_per_eu(1,1)).  A k-step then reads 8 activation + 8 weight fragments for 48 MFMAs (bf16x3; 32 for the plain PAIR
+// form): 0.33 (0.5) ds_read_b128 per MFMA against 0.5 (0.75) with 128x64 wave tiles -- the LDS fragment reads are what the power
+// budget of the 8-wave kernel is spent on (DESIGN.md, bf16 tile engine log).  Same LDS image, staging (LDS-DMA, source-side
+// swizzle, 2-stage ring, one barrier per k-tile) and epilogue as bf16_dma_kernel.  With no partner wave on the SIMD the loop is
+// written as a software pipeline: the fragments of the NEXT k-step are read while the MFMAs of the current one issue, and the
+// k-tile's barrier sits between its two k-steps -- by then every wave holds the tile's last fragments in registers, so the stage
+// may be overwritten by the DMAs of tile + 2, which are handed out between the MFMA groups of the second k-step.
+// Full tiles only: M % 256 == 0, N % 256 == 0, K % 32 == 0 (the dispatcher checks).
+template <bool PAIR>
+struct EngineW4 {
+  static constexpr int BXT = 256, BWT = 256, NI = 4, NJ = 4, NG = 4, MS = 32;
+  f32x16 acc[NI][NJ];
+  int lane, wx, ww;
+  __device__ __forceinline__ void init() {
+    lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    wx = wave >> 1;
+    ww = wave & 1;
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  }
+  __device__ __forceinline__ int pm(int j) const { return wx * 128 + j * 32 + (lane & 31); }
+  __device__ __forceinline__ int pn(int i, int g) const { return ww * 128 + i * 32 + 8 * g + 4 * (lane >> 5); }
+};
+
+template <bool PAIR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                       __bf16 *__restrict__ Clo, int ldc, const float *__restrict__ bias, int M, int N, int K, float alpha, int act,
+                       int tiles_m, int tiles_n) {
+  using E = EngineW4<PAIR>;
+  constexpr int STAGE_B = 512 * 128;           // bytes per LDS stage: (256 + 256) rows x 128 B (hi 32 | lo 32, or 64 plain k)
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  char *smem = reinterpret_cast<char *>(smem16);
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = K / BKH;                      // k-tiles: 32 (hi, lo) k, or 64 plain k
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- staging.  Chunk i of this thread = 16 B at LDS byte (tid + 256 i) * 16 of the stage: row (tid >> 3) + 32 i, physical slot
+  // tid & 7; the logical slot it must fetch undoes the read swizzle and is the same for all 16 chunks (32 i is 0 mod 16).
+  const int r0 = tid >> 3;
+  const int lsl = (tid & 7) ^ ((r0 >> 1) & 7); // plane * 4 + k-slot
+  const unsigned xoff0 = (unsigned)((((size_t)(m0 + r0) * (2 * ldx)) + lsl * 8) * sizeof(__bf16));
+  const unsigned woff0 = (unsigned)((((size_t)(n0 + r0) * (2 * ldw)) + lsl * 8) * sizeof(__bf16));
+  const unsigned xstep = (unsigned)(32u * 2 * ldx * sizeof(__bf16)), wstep = (unsigned)(32u * 2 * ldw * sizeof(__bf16));
+  auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index 0 .. 15 (0-7 activation side, 8-15 weight side)
+    char *dst = smem + stage * STAGE_B + (256 * i + wave * 64) * 16;
+    const unsigned koff = (unsigned)kt * (2 * BKH * sizeof(__bf16));
+    if (i < 8)
+      lds_dma16(Xil, xoff0 + (unsigned)i * xstep + koff, dst);
+    else
+      lds_dma16(Wil, woff0 + (unsigned)(i - 8) * wstep + koff, dst);
+  };
+  // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads 16 B at logical slot plane * 4 + 2 s + h of its row
+  const int fr = lane & 31, h = lane >> 5, sw = (fr >> 1) & 7;
+  const int xrow = (e.wx * 128 + fr) * 128, wrow = (256 + e.ww * 128 + fr) * 128;   // byte offsets inside a stage
+  int fo[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; p++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) fo[p][s] = (((p << 2) | (2 * s + h)) ^ sw) << 4;
+  bf16x8 fx[2][4][2], fw[2][4][2];             // [register set][tile][plane]
+  auto read_frags = [&](const char *st, int s, auto set_tag, int q) {   // quarter q of the 16 fragments of k-step s
+    constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      fx[SET][q][p] = *reinterpret_cast<const bf16x8 *>(st + xrow + q * 4096 + fo[p][s]);
+      fw[SET][q][p] = *reinterpret_cast<const bf16x8 *>(st + wrow + q * 4096 + fo[p][s]);
+    }
+  };
+  auto mma_row = [&](auto set_tag, int i) {    // accumulator tiles (i, 0 .. 3): weight fragment i against the four activation ones
+    constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (PAIR) {
+        e.acc[i][j] = mfma_bf16(fw[SET][i][0], fx[SET][j][0], e.acc[i][j]);
+        e.acc[i][j] = mfma_bf16(fw[SET][i][1], fx[SET][j][1], e.acc[i][j]);
+      } else {
+        e.acc[i][j] = mfma_bf16(fw[SET][i][1], fx[SET][j][0], e.acc[i][j]);
+        e.acc[i][j] = mfma_bf16(fw[SET][i][0], fx[SET][j][1], e.acc[i][j]);
+        e.acc[i][j] = mfma_bf16(fw[SET][i][0], fx[SET][j][0], e.acc[i][j]);
+      }
+    }
+  };
+  auto fence = [] {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // ---- prologue: tile 0 -> stage 0, tile 1 -> stage 1, fragments of (tile 0, step 0)
+#pragma unroll
+  for (int i = 0; i < 16; i++) dma(i, 0, 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) dma(i, 1, 1);
+    wait_vmcnt<16>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 4; q++) read_frags(smem, 0, S0{}, q);
+  fence();
+  // one k-tile; MORE1: a next tile exists (its first fragments are prefetched), MORE2: a tile after that (its DMAs are issued).
+  // Compile-time variants: a runtime `if` around a read or a DMA is a branch that cuts the step into scheduling regions.
+  auto tile = [&](int kt, auto more1_tag, auto more2_tag) {
+    constexpr bool MORE1 = decltype(more1_tag)::value, MORE2 = decltype(more2_tag)::value;
+    const char *cur = smem + (kt & 1) * STAGE_B, *nxt = smem + ((kt + 1) & 1) * STAGE_B;
+    // step 0: its MFMAs, the fragments of step 1 read underneath
+    // (reads BEHIND the MFMA row they follow: ahead of the first row they would be waited for together with the loop-carried
+    // fragments that row needs -- the wait counter is in order)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      mma_row(S0{}, i);
+      fence();
+      if (i < 2) read_frags(cur, 1, S1{}, i);
+      if (i == 2) {
+        read_frags(cur, 1, S1{}, 2);
+        read_frags(cur, 1, S1{}, 3);
+      }
+      fence();
+    }
+    // everyone holds the tile's last fragments: tile kt + 1 (requested a tile ago) must have landed, the stage of tile kt is free
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // step 1: its MFMAs; underneath, the fragments of (tile kt + 1, step 0) and the DMAs of tile kt + 2 into the freed stage
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (MORE1) read_frags(nxt, 0, S0{}, i);
+      if (MORE2) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) dma(4 * i + u, kt + 2, kt & 1);
+      }
+      fence();
+      mma_row(S1{}, i);
+      fence();
+    }
+  };
+  int kt = 0;
+  for (; kt + 2 < nk; kt++) tile(kt, std::true_type{}, std::true_type{});
+  if (kt + 1 < nk) {
+    tile(kt, std::true_type{}, std::false_type{});
+    kt++;
+  }
+  tile(kt, std::false_type{}, std::false_type{});
+  epilogue<E, !PAIR>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
+}
+
 // ------------------------------------------------------------------------------------------------ run-reuse conv
 // 3x3 conv whose activation side is staged ONCE PER ROW OFFSET instead of once per tap.  A tile is 256 consecutive
 // pixels p0.. in raster order; for a fixed dy the three taps dx = -1, 0, +1 read the pixel run
@@ -1425,6 +1587,37 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   return launched();
 }
 
+// NAFAE_GEMM4 (experiments build): 0 = 8-wave kernels everywhere, 1 = the 4-wave kernel for the plain (PAIR) form too.  Default: the
+// 4-wave kernel for the split (bf16x3) form only -- same box, arms interleaved, fc6 / fc7 shapes (8192 x 4096, K = 25088 / 4096):
+// bf16x3 3.77-3.79 -> 3.66-3.67 ms and 0.71 -> 0.63-0.64 ms; plain bf16 1.49-1.50 -> 1.46-1.49 and 0.25 -> 0.26 ms (results
+// bit-identical in both forms; scripts/gemm4_ab.py).  What the one-wave-per-SIMD form does NOT deliver is the step hoped for from
+// 0.33 instead of 0.5 fragment reads per MFMA.  Timing experiments on it (temporary switches, since removed): operands L2-resident
+// -5 %; no DMA inside the loop -19 % (3.0 ms = 1.68 PFLOP/s of MFMA issue); no barrier: no change -- the sixteen LDS-DMA
+// instructions per k-tile stall the only wave of the SIMD while they issue, the barrier does not.  Staging through registers
+// instead (global_load_dwordx4 -> ds_write_b128, a full k-tile of latency slack per load) was slower still (3.94 against 3.84 ms on
+// that box) and was removed.
+inline int use_gemm4() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = nafae::experiment_env("NAFAE_GEMM4");
+    v = e ? atoi(e) : -1;
+    if (v < 0) v = 2;                          // default: split form only
+  }
+  return v;
+}
+
+template <bool PAIR>
+int launch_gemm4(const void *Xil, int ldx, const void *Wil, int ldw, float *Cf, void *Chi, void *Clo, int ldc, const float *bias, int M,
+                 int N, int K, float alpha, int act, hipStream_t st) {
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  const size_t lds = 2 * 512 * 128;
+  auto kern = bf16_gemm4_kernel<PAIR>;
+  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, (const __bf16 *)Xil, ldx, (const __bf16 *)Wil, ldw, Cf,
+                     (__bf16 *)Chi, (__bf16 *)Clo, ldc, bias, M, N, K, alpha, act, tiles_m, tiles_n);
+  return launched();
+}
+
 template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL = false, int BX = 256, bool PAIR = false>
 int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                     void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
@@ -1585,6 +1778,8 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     // workgroups (VisEbd's 8192 x 512 output would be 64 of them: the 256x128 tile below makes 128)
     const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (split && big && M >= 256 && N >= 256 && 2 * big_tiles >= num_cus()) {
+      if (il && use_gemm4() != 0 && M % 256 == 0 && N % 256 == 0 && act >= 0)
+        return launch_gemm4<false>(X_hi, ldx, W_hi, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha, act, S(stream));
       if (il)
         return launch_dma<256, 256, 2, 4, true, false, 2, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N,
                                                                 K, alpha, act, 0, 0, 0, S(stream));
@@ -1607,6 +1802,8 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     }
     if (pair && !split && (K % 64) == 0 && (ldx % 64) == 0 && (ldw % 64) == 0 && M >= 256 && N >= 128) {
       const void *xl = static_cast<const char *>(X_hi) + 64, *wl = static_cast<const char *>(W_hi) + 64;
+      if (big && N >= 256 && 2 * big_tiles >= num_cus() && use_gemm4() == 1 && M % 256 == 0 && N % 256 == 0 && act >= 0)
+        return launch_gemm4<true>(X_hi, ldx / 2, W_hi, ldw / 2, C_f32, C_hi, nullptr, ldc, bias, M, N, K / 2, alpha, act, S(stream));
       if (big && N >= 256 && 2 * big_tiles >= num_cus())
         return launch_dma<256, 256, 2, 4, true, false, 2, true, true>(X_hi, xl, ldx / 2, W_hi, wl, ldw / 2, C_f32, C_hi, nullptr, ldc,
                                                                       bias, M, N, K / 2, alpha, act, 0, 0, 0, S(stream));

@@ -1,16 +1,13 @@
-# round 3, job G: sim / loss chain after the few-kernel window, merge trim, dV frame kernel with 16 waves
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3g
 mkdir -p $O
 cd $R
-(timeout 2400 python -m pytest tests/test_gpu_simmax.py tests/test_gpu_configs.py tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_widened.py -q -m gpu --maxfail=30 > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log)
-grep -E "passed|failed|^FAILED|^ERROR|rc=" $O/tests.log | tail -30
-cd /tmp; export TMPDIR=/tmp
-for c in "c5 hist" "c5 dense" "c2 hist"; do set -- $c
-  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/simloss_$1_$2 -o t -- python3 $R/scripts/simloss_only.py $1 $2 20 > $O/simloss_$1_$2.log 2>&1
-done
-export NAFAE_LIB=$R/nafae_amd/csrc/libnafae_hip_exp.so
-for dbg in 16; do
-  NAFAE_SIM_DBG=$dbg timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dense_dbg$dbg -o t -- python3 $R/scripts/sim_only.py c5 dense 20 > $O/dense_dbg$dbg.log 2>&1
+(timeout 2400 python -m pytest tests -q -m gpu --maxfail=30 > $O/gpu_all.log 2>&1; echo rc=$? >> $O/gpu_all.log)
+grep -E "passed|failed|^FAILED|^ERROR|rc=" $O/gpu_all.log | tail -20
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+for i in 1 2; do
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --precision bf16x3 --no-other-precisions 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16x3', d['value'], d['ms_per_step'], d['stage_ms'])"
+NAFAE_LIB=$R/nafae_amd/csrc/libnafae_hip_exp.so NAFAE_GEMM4=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --precision bf16x3 --no-other-precisions 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16x3 8-wave gemm (exp build)', d['value'], d['ms_per_step'], d['stage_ms'])"
+NAFAE_LIB=$R/nafae_amd/csrc/libnafae_hip_exp.so python bench.py --steps 20 --warmup 3 --no-cpu-baseline --precision bf16x3 --no-other-precisions 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16x3 4-wave gemm (exp build)', d['value'], d['ms_per_step'], d['stage_ms'])"
 done
