@@ -2,7 +2,7 @@
 # kernel traces and PMC passes (one counter group per pass; never combined with other trace domains)
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3y
+O=$R/gpurun_out/r3f
 mkdir -p $O
 cd $R
 (timeout 2400 python -m pytest tests -q -m gpu --maxfail=30 --durations=10 > $O/gpu_all.log 2>&1; echo rc=$? >> $O/gpu_all.log)
