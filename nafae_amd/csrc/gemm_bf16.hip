@@ -407,8 +407,9 @@ __global__ __launch_bounds__(NT16) void bf16_dma_kernel(const __bf16 *Xhi, const
 // budget of the 8-wave kernel is spent on (DESIGN.md, bf16 tile engine log).  Same LDS image, staging (LDS-DMA, source-side
 // swizzle, 2-stage ring, one barrier per k-tile) and epilogue as bf16_dma_kernel.  With no partner wave on the SIMD the loop is
 // written as a software pipeline: the fragments of the NEXT k-step are read while the MFMAs of the current one issue, and the
-// k-tile's barrier sits between its two k-steps -- by then every wave holds the tile's last fragments in registers, so the stage
-// may be overwritten by the DMAs of tile + 2, which are handed out between the MFMA groups of the second k-step.
+// k-tile's barrier sits behind the third of its eight MFMA rows -- by then every wave holds the tile's last fragments in registers,
+// so the stage may be overwritten by the DMAs of tile + 2, which are handed out one at a time between the product groups of the
+// five rows that follow (a DMA issues while an MFMA executes; four back to back left the matrix pipe dry).
 // Full tiles only: M % 256 == 0, N % 256 == 0, K % 32 == 0 (the dispatcher checks).
 template <bool PAIR>
 struct EngineW4 {
@@ -451,16 +452,19 @@ void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, f
   // tid & 7; the logical slot it must fetch undoes the read swizzle and is the same for all 16 chunks (32 i is 0 mod 16).
   const int r0 = tid >> 3;
   const int lsl = (tid & 7) ^ ((r0 >> 1) & 7); // plane * 4 + k-slot
-  const unsigned xoff0 = (unsigned)((((size_t)(m0 + r0) * (2 * ldx)) + lsl * 8) * sizeof(__bf16));
-  const unsigned woff0 = (unsigned)((((size_t)(n0 + r0) * (2 * ldw)) + lsl * 8) * sizeof(__bf16));
-  const unsigned xstep = (unsigned)(32u * 2 * ldx * sizeof(__bf16)), wstep = (unsigned)(32u * 2 * ldw * sizeof(__bf16));
+  // Everything that differs between the DMAs of a thread is UNIFORM (tile origin, chunk row step, k-tile, stage), so it travels in
+  // scalar registers: the per-lane offset is one constant VGPR per side, the source base and the LDS destination (M0) are scalar
+  // adds -- no vector instruction, no v_readfirstlane per DMA beside the only wave that feeds this SIMD's matrix pipe.
+  const unsigned xv = (unsigned)((((size_t)r0 * (2 * ldx)) + lsl * 8) * sizeof(__bf16));
+  const unsigned wv = (unsigned)((((size_t)r0 * (2 * ldw)) + lsl * 8) * sizeof(__bf16));
+  const char *xbase = reinterpret_cast<const char *>(Xil) + (size_t)m0 * (2 * ldx) * sizeof(__bf16);
+  const char *wbase = reinterpret_cast<const char *>(Wil) + (size_t)n0 * (2 * ldw) * sizeof(__bf16);
+  const size_t xstep = (size_t)32 * 2 * ldx * sizeof(__bf16), wstep = (size_t)32 * 2 * ldw * sizeof(__bf16);
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
   auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index 0 .. 15 (0-7 activation side, 8-15 weight side)
-    char *dst = smem + stage * STAGE_B + (256 * i + wave * 64) * 16;
-    const unsigned koff = (unsigned)kt * (2 * BKH * sizeof(__bf16));
-    if (i < 8)
-      lds_dma16(Xil, xoff0 + (unsigned)i * xstep + koff, dst);
-    else
-      lds_dma16(Wil, woff0 + (unsigned)(i - 8) * wstep + koff, dst);
+    const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
+    const char *b = (i < 8 ? xbase + (size_t)i * xstep : wbase + (size_t)(i - 8) * wstep) + (size_t)kt * (2 * BKH * sizeof(__bf16));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? xv : wv), "s"(b) : "memory");
   };
   // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads 16 B at logical slot plane * 4 + 2 s + h of its row
   const int fr = lane & 31, h = lane >> 5, sw = (fr >> 1) & 7;
@@ -479,18 +483,18 @@ void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, f
       fw[SET][q][p] = *reinterpret_cast<const bf16x8 *>(st + wrow + q * 4096 + fo[p][s]);
     }
   };
-  auto mma_row = [&](auto set_tag, int i) {    // accumulator tiles (i, 0 .. 3): weight fragment i against the four activation ones
+  // accumulator tiles (i, 0 .. 3): weight fragment i against the four activation ones, PRODUCT-major (the four chains interleave, so
+  // no MFMA waits for its predecessor); `hook(p)` runs after the four MFMAs of product p -- one staging instruction goes there, so
+  // that it issues while an MFMA is executing instead of four of them back to back ahead of the row
+  constexpr int NP = PAIR ? 2 : 3;
+  auto mma_row = [&](auto set_tag, int i, auto hook) {
     constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (PAIR) {
-        e.acc[i][j] = mfma_bf16(fw[SET][i][0], fx[SET][j][0], e.acc[i][j]);
-        e.acc[i][j] = mfma_bf16(fw[SET][i][1], fx[SET][j][1], e.acc[i][j]);
-      } else {
-        e.acc[i][j] = mfma_bf16(fw[SET][i][1], fx[SET][j][0], e.acc[i][j]);
-        e.acc[i][j] = mfma_bf16(fw[SET][i][0], fx[SET][j][1], e.acc[i][j]);
-        e.acc[i][j] = mfma_bf16(fw[SET][i][0], fx[SET][j][0], e.acc[i][j]);
-      }
+    for (int p = 0; p < NP; p++) {
+      const int pw = PAIR ? p : (p == 0 ? 1 : 0), px = PAIR ? p : (p == 1 ? 1 : 0);    // (lo*hi, hi*lo, hi*hi: small terms first)
+#pragma unroll
+      for (int j = 0; j < 4; j++) e.acc[i][j] = mfma_bf16(fw[SET][i][pw], fx[SET][j][px], e.acc[i][j]);
+      hook(p);
     }
   };
   auto fence = [] {
@@ -519,12 +523,32 @@ void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, f
   auto tile = [&](int kt, auto more1_tag, auto more2_tag) {
     constexpr bool MORE1 = decltype(more1_tag)::value, MORE2 = decltype(more2_tag)::value;
     const char *cur = smem + (kt & 1) * STAGE_B, *nxt = smem + ((kt + 1) & 1) * STAGE_B;
-    // step 0: its MFMAs, the fragments of step 1 read underneath
-    // (reads BEHIND the MFMA row they follow: ahead of the first row they would be waited for together with the loop-carried
-    // fragments that row needs -- the wait counter is in order)
+    // The 16 DMAs of tile kt + 2 go behind the barrier, spread over the five MFMA rows that follow it (4, 3, 3, 3, 3): NP of a row's
+    // share in the hooks between its product groups, the rest ahead of it.  (Measured against the 8-wave kernel on one box each,
+    // fc6 bf16x3 / plain: barrier between the two k-steps, four rows: -6 % / -5 %; this form: -9 % / -8 %; all sixteen fragment
+    // reads behind row 0 and the barrier behind row 1, six rows: -7.5 % / -6.5 %.)
+    constexpr int CNT0 = 4, CNTR = 3;           // 4 + 4 * 3 = 16
+    auto row_dmas = [&](int r, int first, auto body) {     // r: 0 = last row of step 0, 1 .. 4 = rows of step 1
+      const int cnt = r == 0 ? CNT0 : CNTR, pre = cnt - NP;
+      if (MORE2) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      mma_row(S0{}, i);
+        for (int u = 0; u < pre; u++) dma(first + u, kt + 2, kt & 1);
+      }
+      fence();
+      body([&](int p) {
+        if (MORE2) {
+          fence();
+          dma(first + pre + p, kt + 2, kt & 1);
+          fence();
+        }
+      });
+      fence();
+    };
+    // step 0, rows 0 .. 2: their MFMAs, the fragments of step 1 read underneath (reads BEHIND the MFMA row they follow: ahead of
+    // the first row they would be waited for together with the loop-carried fragments that row needs -- the wait counter is in order)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      mma_row(S0{}, i, [](int) {});
       fence();
       if (i < 2) read_frags(cur, 1, S1{}, i);
       if (i == 2) {
@@ -533,22 +557,17 @@ void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, f
       }
       fence();
     }
-    // everyone holds the tile's last fragments: tile kt + 1 (requested a tile ago) must have landed, the stage of tile kt is free
+    // everyone holds the tile's last fragments (the stage of tile kt is free), and tile kt + 1, requested a tile ago, has landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // step 1: its MFMAs; underneath, the fragments of (tile kt + 1, step 0) and the DMAs of tile kt + 2 into the freed stage
+    row_dmas(0, 0, [&](auto hook) { mma_row(S0{}, 3, hook); });
+    // step 1: its MFMAs; underneath, the fragments of (tile kt + 1, step 0) and the rest of the DMAs
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (MORE1) read_frags(nxt, 0, S0{}, i);
-      if (MORE2) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) dma(4 * i + u, kt + 2, kt & 1);
-      }
-      fence();
-      mma_row(S1{}, i);
-      fence();
+      row_dmas(1 + i, CNT0 + CNTR * i, [&](auto hook) { mma_row(S1{}, i, hook); });
     }
   };
   int kt = 0;
@@ -1587,23 +1606,25 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   return launched();
 }
 
-// NAFAE_GEMM4 (experiments build): 0 = 8-wave kernels everywhere, 1 = the 4-wave kernel for the plain (PAIR) form too.  Default: the
-// 4-wave kernel for the split (bf16x3) form only -- same box, arms interleaved, fc6 / fc7 shapes (8192 x 4096, K = 25088 / 4096):
-// bf16x3 3.77-3.79 -> 3.66-3.67 ms and 0.71 -> 0.63-0.64 ms; plain bf16 1.49-1.50 -> 1.46-1.49 and 0.25 -> 0.26 ms (results
-// bit-identical in both forms; scripts/gemm4_ab.py).  What the one-wave-per-SIMD form does NOT deliver is the step hoped for from
-// 0.33 instead of 0.5 fragment reads per MFMA.  Timing experiments on it (temporary switches, since removed): operands L2-resident
-// -5 %; no DMA inside the loop -19 % (3.0 ms = 1.68 PFLOP/s of MFMA issue); no barrier: no change -- the sixteen LDS-DMA
-// instructions per k-tile stall the only wave of the SIMD while they issue, the barrier does not.  Staging through registers
-// instead (global_load_dwordx4 -> ds_write_b128, a full k-tile of latency slack per load) was slower still (3.94 against 3.84 ms on
-// that box) and was removed.
-inline int use_gemm4() {
+// The 4-wave kernel is the default for full 256x256 tiles in both forms; NAFAE_GEMM4=0 (experiments build) keeps the 8-wave kernels
+// for A/B timing.  Same box, arms interleaved, fc6 / fc7 shapes (8192 x 4096, K = 25088 / 4096; scripts/gemm4_ab.py), results
+// bit-identical: bf16x3 3.73-3.74 -> 3.40-3.41 ms and 0.70 -> 0.58-0.59 ms; plain bf16 1.48-1.49 -> 1.37-1.38 and 0.244-0.256 ->
+// 0.243 ms.  How it got there: as first written (per-DMA v_readfirstlane for M0 and a vector add for the address, like the 8-wave
+// kernel; barrier between the two k-steps; the four DMAs of a row ahead of it) it gained 3 % / 10 % in the split form and nothing
+// in the plain one, and timing experiments (temporary switches, since removed) showed why 0.33 instead of 0.5 fragment reads per
+// MFMA is not the step the power table promised: operands L2-resident -5 %, NO DMA inside the loop -19 % (3.0 ms = 1.68 PFLOP/s of
+// MFMA issue), no barrier: no change -- the sixteen LDS-DMA issue sequences per k-tile stall the only wave that feeds the SIMD's
+// matrix pipe.  So: (1) everything per-DMA into scalar registers (source base, M0): s_add / s_addc / s_mov m0 / s_nop / DMA, another
+// 3-6 %; (2) one DMA between product groups instead of four ahead of a row, and the barrier two rows earlier (five rows to spread
+// them over, a quarter tile more for them to land): another 3 %.  Staging through registers instead (global_load_dwordx4 ->
+// ds_write_b128, a full k-tile of latency slack per load) was slower (3.94 against 3.84 ms) and was removed.
+inline bool use_gemm4() {
   static int v = -1;
   if (v < 0) {
     const char *e = nafae::experiment_env("NAFAE_GEMM4");
-    v = e ? atoi(e) : -1;
-    if (v < 0) v = 2;                          // default: split form only
+    v = (e && e[0] == '0') ? 0 : 1;
   }
-  return v;
+  return v == 1;
 }
 
 template <bool PAIR>
@@ -1778,7 +1799,7 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     // workgroups (VisEbd's 8192 x 512 output would be 64 of them: the 256x128 tile below makes 128)
     const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (split && big && M >= 256 && N >= 256 && 2 * big_tiles >= num_cus()) {
-      if (il && use_gemm4() != 0 && M % 256 == 0 && N % 256 == 0 && act >= 0)
+      if (il && use_gemm4() && M % 256 == 0 && N % 256 == 0 && act >= 0)
         return launch_gemm4<false>(X_hi, ldx, W_hi, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha, act, S(stream));
       if (il)
         return launch_dma<256, 256, 2, 4, true, false, 2, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N,
@@ -1802,7 +1823,7 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     }
     if (pair && !split && (K % 64) == 0 && (ldx % 64) == 0 && (ldw % 64) == 0 && M >= 256 && N >= 128) {
       const void *xl = static_cast<const char *>(X_hi) + 64, *wl = static_cast<const char *>(W_hi) + 64;
-      if (big && N >= 256 && 2 * big_tiles >= num_cus() && use_gemm4() == 1 && M % 256 == 0 && N % 256 == 0 && act >= 0)
+      if (big && N >= 256 && 2 * big_tiles >= num_cus() && use_gemm4() && M % 256 == 0 && N % 256 == 0 && act >= 0)
         return launch_gemm4<true>(X_hi, ldx / 2, W_hi, ldw / 2, C_f32, C_hi, nullptr, ldc, bias, M, N, K / 2, alpha, act, S(stream));
       if (big && N >= 256 && 2 * big_tiles >= num_cus())
         return launch_dma<256, 256, 2, 4, true, false, 2, true, true>(X_hi, xl, ldx / 2, W_hi, wl, ldw / 2, C_f32, C_hi, nullptr, ldc,
