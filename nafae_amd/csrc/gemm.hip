@@ -752,6 +752,179 @@ inline bool f32_single_buffer() {
   return e ? e[0] == '1' : F32_SB_DEFAULT;
 }
 
+// ------------------------------------------------------------------------------------------------ 4-wave fp32 GEMM
+// C = act(alpha * A B^T + bias) for full 256x256 tiles on ONE wave per SIMD (the fp32 sibling of bf16_gemm4_kernel, gemm_bf16.hip):
+// 4 waves = 2 x 2, a wave holds a 128x128 register tile = sixteen 32x32 accumulator tiles = 256 registers in AGPRs
+// (amdgpu_waves_per_eu(1,1)).  Operands go global -> LDS by LDS-DMA (fp32 needs no conversion), 16 B per lane, lane-linear LDS
+// destinations with the XOR swizzle on the source address; LDS image [2 stages][256 + 256 rows][128 B = 32 k], the layout of
+// mfma_tile.h, so the fragments, the k order inside an 8-wide group and therefore every accumulator's summation order are those of
+// gemm_nt_kernel: the results are bit-identical to it.  A k-tile is four 8-k steps of 64 MFMAs per wave (64 cycles each: 16 384
+// cycles per k-tile), so the 16 DMAs, 32 fragment reads and one barrier per k-tile are ~2 % of the issue slots -- against 8 loads +
+// 8 ds_write + 16 reads + 2 barriers per 4 096 cycles and wave in the 128x128 kernel, whose three workgroups per CU hide but do not
+// remove them.  Pipeline as in the bf16 kernel: the next step's fragments are read behind the first MFMA row of the current
+// step; the k-tile's barrier sits behind row 1 of step 2 (every wave then holds the tile's last fragments, the stage is free) and
+// the DMAs of tile + 2 are handed out one per product group over the six rows that follow.
+// The weight side is the MFMA "A" operand (as in the bf16 engine): a lane's 4 consecutive accumulator registers are 4 consecutive
+// output columns of one row -> 16-byte stores.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                      int M, int N, int K, float alpha, int act, int tiles_m, int tiles_n) {
+  constexpr int STAGE_B = 512 * 128;
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  char *smem = reinterpret_cast<char *>(smem_f);
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = K / BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wx = wave >> 1, ww = wave & 1;
+  // ---- staging: chunk i of this thread = 16 B at LDS byte (tid + 256 i) * 16 of the stage = row (tid >> 3) + 32 i, physical slot
+  // tid & 7; the logical slot (4 floats of the k-tile) undoes the read swizzle.  Everything that differs between a thread's DMAs is
+  // uniform and lives in scalar registers (source base, M0); the per-lane offset is one constant VGPR per side.
+  const int r0 = tid >> 3;
+  const int lsl = (tid & 7) ^ ((r0 >> 1) & 7);
+  const unsigned av = (unsigned)(((size_t)r0 * lda + lsl * 4) * sizeof(float));
+  const unsigned bv = (unsigned)(((size_t)r0 * ldb + lsl * 4) * sizeof(float));
+  const char *abase = reinterpret_cast<const char *>(A) + (size_t)m0 * lda * sizeof(float);
+  const char *bbase = reinterpret_cast<const char *>(B) + (size_t)n0 * ldb * sizeof(float);
+  const size_t astep = (size_t)32 * lda * sizeof(float), bstep = (size_t)32 * ldb * sizeof(float);
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
+  auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index (0-7: A rows, 8-15: B rows)
+    const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
+    const char *b = (i < 8 ? abase + (size_t)i * astep : bbase + (size_t)(i - 8) * bstep) + (size_t)kt * (BK * sizeof(float));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? av : bv), "s"(b) : "memory");
+  };
+  // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads the 16 B at logical slot 2 jj + h of its row: element e of step jj
+  // is k = 8 jj + 4 h + e on both sides
+  const int fr = lane & 31, h = lane >> 5, sw = (fr >> 1) & 7;
+  const int arow = (wx * 128 + fr) * 128, brow = (256 + ww * 128 + fr) * 128;
+  int fo[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) fo[jj] = ((2 * jj + h) ^ sw) << 4;
+  f32x4 fa[2][4], fb[2][4];                    // [register set][tile]
+  auto read_frags = [&](const char *st, int jj, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      fa[SET][q] = *reinterpret_cast<const f32x4 *>(st + arow + q * 4096 + fo[jj]);
+      fb[SET][q] = *reinterpret_cast<const f32x4 *>(st + brow + q * 4096 + fo[jj]);
+    }
+  };
+  // accumulator tiles (i, 0 .. 3), k-element major (four independent chains interleave); hook(e) after the four MFMAs of element e
+  auto mma_row = [&](auto set_tag, int i, auto hook) {
+    constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[SET][i][e], fa[SET][j][e], acc[i][j], 0, 0, 0);
+      hook(e);
+    }
+  };
+  auto fence = [] {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto nohook = [](int) {};
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // ---- prologue: tile 0 -> stage 0, tile 1 -> stage 1, fragments of (tile 0, step 0)
+#pragma unroll
+  for (int i = 0; i < 16; i++) dma(i, 0, 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) dma(i, 1, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(smem, 0, S0{});
+  fence();
+  auto tile = [&](int kt, auto more1_tag, auto more2_tag) {
+    constexpr bool MORE1 = decltype(more1_tag)::value, MORE2 = decltype(more2_tag)::value;
+    const char *cur = smem + (kt & 1) * STAGE_B, *nxt = smem + ((kt + 1) & 1) * STAGE_B;
+    // a step whose next step's fragments come from the same stage: read them behind row 0
+    auto step = [&](auto set_tag, auto next_tag, int jj_next) {
+      mma_row(set_tag, 0, nohook);
+      fence();
+      read_frags(cur, jj_next, next_tag);
+      fence();
+#pragma unroll
+      for (int i = 1; i < 4; i++) {
+        mma_row(set_tag, i, nohook);
+        fence();
+      }
+    };
+    step(S0{}, S1{}, 1);                        // step 0
+    step(S1{}, S0{}, 2);                        // step 1
+    // step 2: the tile's last fragments (step 3) are read behind row 0; behind row 1 every wave holds them
+    mma_row(S0{}, 0, nohook);
+    fence();
+    read_frags(cur, 3, S1{});
+    fence();
+    mma_row(S0{}, 1, nohook);
+    fence();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt + 1, requested a tile ago
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the 16 DMAs of tile kt + 2 into the freed stage: rows 2, 3 of step 2 and the rows of step 3 take 3, 3, 3, 3, 2, 2 of them,
+    // one per k-element group
+    auto row_dmas = [&](int r, auto body) {
+      const int cnt = r < 4 ? 3 : 2, first = r < 4 ? 3 * r : 12 + 2 * (r - 4);
+      body([&](int e) {
+        if (MORE2 && e < cnt) {
+          fence();
+          dma(first + e, kt + 2, kt & 1);
+          fence();
+        }
+      });
+      fence();
+    };
+    row_dmas(0, [&](auto hook) { mma_row(S0{}, 2, hook); });
+    row_dmas(1, [&](auto hook) { mma_row(S0{}, 3, hook); });
+    // step 3; behind its row 0 the fragments of (tile kt + 1, step 0)
+    row_dmas(2, [&](auto hook) { mma_row(S1{}, 0, hook); });
+    if (MORE1) read_frags(nxt, 0, S0{});
+    fence();
+    row_dmas(3, [&](auto hook) { mma_row(S1{}, 1, hook); });
+    row_dmas(4, [&](auto hook) { mma_row(S1{}, 2, hook); });
+    row_dmas(5, [&](auto hook) { mma_row(S1{}, 3, hook); });
+  };
+  int kt = 0;
+  for (; kt + 2 < nk; kt++) tile(kt, std::true_type{}, std::true_type{});
+  if (kt + 1 < nk) {
+    tile(kt, std::true_type{}, std::false_type{});
+    kt++;
+  }
+  tile(kt, std::false_type{}, std::false_type{});
+  // ---- epilogue: acc[i][j][4 g + q] = C[m0 + wx*128 + j*32 + (lane & 31)][n0 + ww*128 + i*32 + 8 g + 4 (lane >> 5) + q]
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int n = n0 + ww * 128 + i * 32 + 8 * g + 4 * h;
+      f32x4 bvv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) bvv = *reinterpret_cast<const f32x4 *>(bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int m = m0 + wx * 128 + j * 32 + fr;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = apply_act(alpha * acc[i][j][4 * g + q] + bvv[q], act);
+        *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
+      }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M,
                     int N, int K, float alpha, int act, hipStream_t st) {
@@ -867,6 +1040,21 @@ int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, in
   // 128 x 64 tiles also when 128 x 128 would leave fewer than two workgroups per CU (VisEbd: 8192 x 512 = 256 tiles, one per CU,
   // whose barrier / staging bubbles nobody fills)
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  // full 256x256 tiles, at least one per CU: the 4-wave kernel (one wave per SIMD, 128x128 register tiles); NAFAE_F32_GEMM4=0
+  // (experiments build) keeps the 128x128 kernel for A/B timing
+  {
+    const char *e4 = nafae::experiment_env("NAFAE_F32_GEMM4");
+    const bool on = !(e4 && e4[0] == '0');
+    if (on && M % 256 == 0 && N % 256 == 0 && K % BK == 0 && (long)(M / 256) * (N / 256) >= sk_num_cus() && (ldc & 3) == 0 &&
+        aligned16(C) && (!bias || aligned16(bias)) && (size_t)256 * lda * sizeof(float) < (1ull << 31) &&
+        (size_t)256 * ldb * sizeof(float) < (1ull << 31)) {
+      const void *k4 = reinterpret_cast<const void *>(f32_gemm4_kernel);
+      if (nafae::allow_dynamic_lds(k4, 2 * 512 * 128) != NAFAE_OK) return NAFAE_ELAUNCH;
+      hipLaunchKernelGGL(f32_gemm4_kernel, dim3((M / 256) * (N / 256)), dim3(256), 2 * 512 * 128, S(stream), A, lda, B, ldb, C, ldc,
+                         bias, M, N, K, alpha, act, M / 256, N / 256);
+      return launched();
+    }
+  }
   if (N <= 64 || t128 < 2L * sk_num_cus())
     launch_gemm_nt<128, 64, 4, 1>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
   else
