@@ -49,11 +49,13 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense (the 5 PF headline includes 2:1 spars
 HBM_PEAK_GBS = 8000.0
 MODE_INFO = {
     # precision: (MFMAs issued per algorithmic product, dense peak of the pipe, fc6 kernel, bytes per operand element)
-    "f32": (1, FP32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel<128,128,2,2> (fc6, exact fp32 MFMA)", 4.0, "gemm_nt_fc6"),
-    "bf16x3": (3, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,split,gemm,2> (fc6, 3 bf16 MFMAs per product)", 4.0,
-               "gemm_bf16x3_fc6_256x256_il"),
-    "bf16": (1, BF16_MFMA_PEAK_TFLOPS, "bf16_dma_kernel<256,256,2,4,plain,gemm,3> (fc6, bf16 MFMA)", 2.0,
-             "gemm_bf16_plain_fc6_256x256"),
+    # (fc6 runs the 4-wave kernels -- one wave per SIMD, 128x128 register tiles -- in every mode: M = 64 * Nb and N = 4096 are
+    # multiples of 256 in all BASELINE configurations)
+    "f32": (1, FP32_MFMA_PEAK_TFLOPS, "f32_gemm4_kernel (fc6, exact fp32 MFMA, 256x256 tiles on one wave per SIMD)", 4.0, "gemm4_f32_fc6"),
+    "bf16x3": (3, BF16_MFMA_PEAK_TFLOPS, "bf16_gemm4_kernel<split> (fc6, 3 bf16 MFMAs per product, 256x256 tiles on one wave per SIMD)", 4.0,
+               "gemm4_bf16x3_fc6"),
+    "bf16": (1, BF16_MFMA_PEAK_TFLOPS, "bf16_gemm4_kernel<pair> (fc6, bf16 MFMA, 256x256 tiles on one wave per SIMD)", 2.0,
+             "gemm4_bf16_plain_fc6"),
 }
 
 
@@ -415,10 +417,9 @@ def run_rank(a):
                                "traffic": traffic,
                                "traffic_source": ("static: %s (separate --pmc passes on scripts/kernels*_only.py at this shape, "
                                                   "FETCH_SIZE x2; not read in this run)" % src) if traffic else None,
-                               "traffic_note": ("L2-miss bytes (Infinity-Cache hits included), not HBM bytes: each 128x128 tile streams "
-                                                "its two K panels and the workgroups that share a panel drift apart along K, so "
-                                                "L2 re-serves little (36 % hits).  The kernel is MFMA-bound (PMC MFMA-busy 0.87 of "
-                                                "active cycles), so the re-reads cost power, not time: DESIGN.md section 8") if (traffic and prec == "f32") else None}
+                               "traffic_note": ("L2-miss bytes (Infinity-Cache hits included), not HBM bytes: the workgroups that share "
+                                                "a K panel drift apart along K, so L2 re-serves only part of it.  The kernel is "
+                                                "MFMA-bound, so the re-reads cost power, not time: DESIGN.md section 8") if (traffic and prec == "f32") else None}
         res["stage_ms"] = {k: round(v["avg_ms"], 4) for k, v in sorted(prof.items())}
         det_ms = sum(v["avg_ms"] for k, v in prof.items() if k in ("base", "rpn", "roi_align", "fc6", "fc7"))
         if det_ms > 0:
