@@ -3,7 +3,7 @@
 parent put into the environment, and saves the merged fp32 outputs.  One process per arm: the library caches some switches
 in function-local statics, so an arm cannot be changed inside a process.
 
-    python tests/exp_arm_worker.py <kind: patch|pair> <out.pt>
+    python tests/exp_arm_worker.py <kind: patch|pair|gemm4> <out.pt>
 """
 import os
 import sys
@@ -17,6 +17,10 @@ PATCH_CASES = [(8, 64, 128, 64, 64), (3, 112, 112, 64, 64), (5, 48, 160, 64, 64)
                (9, 32, 32, 256, 64)]
 PAIR_CASES = [(8, 64, 128, 64, 64), (3, 112, 112, 64, 128), (4, 64, 64, 128, 128), (40, 56, 56, 128, 256), (64, 28, 28, 256, 512),
               (6, 14, 14, 512, 512), (2, 20, 36, 64, 64)]
+
+
+# (M, N, K): full 256x256 tiles, at least one per CU -- the shapes the one-wave-per-SIMD GEMMs take
+GEMM4_CASES = [(4096, 4096, 512), (8192, 4096, 1056), (5120, 4096, 96)]
 
 
 def inputs(case, seed_of):
@@ -39,6 +43,18 @@ def main():
             xp, wp = ops.split_bf16(x, True, True), ops.split_bf16(w, True, True)
             _, p = ops.conv3x3_bf16(xp, wp, b, relu=True)
             out[c] = ops.merge_bf16(p).cpu()
+    elif kind == "gemm4":
+        for (M, N, K) in GEMM4_CASES:
+            g = torch.Generator(device="cuda").manual_seed(M + N + K)
+            A = torch.relu(torch.randn(M, K, device="cuda", generator=g))
+            B = torch.randn(N, K, device="cuda", generator=g) * 0.05
+            bias = torch.randn(N, device="cuda", generator=g)
+            f32 = ops.gemm_nt(A, B, bias, act=1)
+            x3 = ops.gemm_nt_bf16(ops.split_bf16(A, True, True), ops.split_bf16(B, True, True), bias, act=1, want_f32=True, want_planes=False)[0]
+            pl = ops.gemm_nt_bf16(ops.split_bf16(A, False), ops.split_bf16(B, False), bias, act=0, want_f32=True, want_planes=False)[0] if K % 64 == 0 else None
+            ref = torch.relu(A.double() @ B.double().T + bias.double())
+            out[(M, N, K)] = (f32.cpu(), x3.cpu(), None if pl is None else pl.cpu(), float((f32.double() - ref).abs().max() / ref.abs().max()),
+                              float((x3.double() - ref).abs().max() / ref.abs().max()))
     else:
         for c in PAIR_CASES:
             x, w, b = inputs(c, lambda c: c[0] + c[1] + c[3])

@@ -375,3 +375,19 @@ def test_conv_fused_maxpool(F, H, W, Cin, Cout, split):
     full = torch.relu(torch.nn.functional.conv2d(ops.merge_bf16(xp).permute(0, 3, 1, 2), ops.merge_bf16(wp).permute(0, 3, 1, 2), b, padding=1))
     pooled = torch.nn.functional.max_pool2d(full, 2, 2).permute(0, 2, 3, 1)
     assert float((out - pooled).abs().max()) <= (5e-5 if split else 8e-3) * float(pooled.abs().max())
+
+
+def test_one_wave_per_simd_gemms_equal_the_kernels_they_replace(tmp_path):
+    """f32_gemm4_kernel / bf16_gemm4_kernel (256x256 tiles, one wave per SIMD, accumulators in AGPRs) keep the fragment mapping and the
+    k order of the kernels they replace for full tiles: the outputs must be BIT-identical across the arms (NAFAE_F32_GEMM4 /
+    NAFAE_GEMM4 = 0 selects the old kernels in the experiments build), and right against fp64."""
+    from exp_arm_worker import GEMM4_CASES
+    old = _exp_arm("gemm4", {"NAFAE_F32_GEMM4": "0", "NAFAE_GEMM4": "0"}, tmp_path, "old")
+    new = _exp_arm("gemm4", {"NAFAE_F32_GEMM4": "1", "NAFAE_GEMM4": "1"}, tmp_path, "new")
+    for c in GEMM4_CASES:
+        fo, xo, po, e_f32, e_x3 = old[c]
+        fn, xn, pn, e_f32n, e_x3n = new[c]
+        assert torch.equal(fo, fn), ("fp32", c)
+        assert torch.equal(xo, xn), ("bf16x3", c)
+        assert (po is None) == (pn is None) and (po is None or torch.equal(po, pn)), ("bf16", c)
+        assert e_f32n < 2e-6 and e_x3n < 3e-5, (c, e_f32n, e_x3n)
