@@ -20,7 +20,7 @@ PAIR_CASES = [(8, 64, 128, 64, 64), (3, 112, 112, 64, 128), (4, 64, 64, 128, 128
 
 
 # (M, N, K): full 256x256 tiles, at least one per CU -- the shapes the one-wave-per-SIMD GEMMs take
-GEMM4_CASES = [(4096, 4096, 512), (8192, 4096, 1056), (5120, 4096, 96)]
+GEMM4_CASES = [(4096, 4096, 512), (8192, 4096, 1056), (5120, 4096, 96), (4096, 4096, 32), (4096, 4096, 64)]   # (1, 2, 3 k-tiles too)
 
 
 def inputs(case, seed_of):
