@@ -317,13 +317,18 @@ def run_rank(a):
         raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    distributed = world > 1
+    distributed = world > 1 or a.force_dist            # --force-dist: a world-size-1 RCCL group, so that the collective path runs
     backend = "gloo" if a.test_shared_gpu else "nccl"       # nccl = RCCL on ROCm; gloo only for the shared-GPU launcher test
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:         # (--force-dist outside a launcher)
+            os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     from nafae_amd import ops
+    from nafae_amd import parallel as _par
+    if a.force_dist:
+        _par.FORCE_COLLECTIVES = True              # a world-size-1 group still issues every collective of the N > 1 step
     from nafae_amd.config import cfg, cfg_from_file, reset_cfg
     from nafae_amd.model import default_args
     from nafae_amd.train import PipelinedTrainer, make_batch, setup_training, shard_frames, train_step, train_step_exact
@@ -360,7 +365,8 @@ def run_rank(a):
     def time_mode(prec, steps, warmup):
         """warmup untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks."""
         model.fasterRCNN.precision = prec
-        pipe = None if (a.no_pipeline or exact) else PipelinedTrainer(model, opt, crit, args, reducer)
+        pipe = None if (a.no_pipeline or exact) else PipelinedTrainer(model, opt, crit, args, reducer,
+                                                                      tail_priority=not a.no_tail_priority)
 
         def run_steps(n):
             if feeder is not None:                 # --stream-input: a different pinned-host uint8 batch every step
@@ -402,7 +408,8 @@ def run_rank(a):
         res = {"dtype": prec, "value": round(world * F * steps / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(1e3 * dt / steps, 3),
                "pairs_per_s": round(world * R * Q * (world if exact else 1) * steps / dt, 1),
-               "step_pipeline": "detector(k+1) overlaps tail(k) on a second stream" if pipe else "sequential",
+               "step_pipeline": ("detector(k+1) overlaps tail(k) on a second stream" + ("" if a.no_tail_priority else
+                                 "; tail on a high-priority stream")) if pipe else "sequential",
                "loss": round(float(loss), 5)}
         nprod, peak, kname, opb, pmc_key = MODE_INFO[prec]
         fc6 = prof.get("fc6")
@@ -503,6 +510,8 @@ def main():
                     help="run detector and tail of a step back to back on one stream (default: the frozen detector of step "
                          "k+1 overlaps the embedding/loss/backward/optimiser tail of step k on a second HIP stream)")
     ap.add_argument("--no-other-precisions", action="store_true", help="time the headline arithmetic mode only")
+    ap.add_argument("--no-tail-priority", action="store_true",
+                    help="A/B: run the pipelined tail on the caller's stream instead of a high-priority HIP stream")
     ap.add_argument("--dp-mode", default="replica", choices=["replica", "exact"],
                     help="N > 1: 'replica' = per-GPU minibatch of whole segments, local loss, averaged gradients (default, "
                          "BASELINE.json's DP); 'exact' = ONE global batch of N x the segments, frames sharded over the GPUs, "
@@ -514,6 +523,9 @@ def main():
                     help="TEST ONLY: let the N ranks share the visible GPU(s) (LOCAL_RANK modulo device count) with gloo collectives "
                          "staged through host memory, so that the launcher and the data-parallel step can be exercised end to "
                          "end on a one-GPU box; the numbers it prints are meaningless as throughput")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (backend nccl = RCCL) even with one rank: the gradient all-reduce, barrier "
+                         "and max-over-ranks timing of the N > 1 path then execute on a one-GPU box (world size 1)")
     ap.add_argument("--stream-input", action="store_true",
                     help="feed every step a different batch of raw uint8 frames from pinned host memory through a copy stream "
                          "(PCIe-inclusive figure; the default keeps one fp32 batch resident in HBM, as the contract's `value` requires)")
@@ -523,6 +535,9 @@ def main():
     a = ap.parse_args()
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if a.stream_input and a.dp_mode == "exact":
+        ap.error("--stream-input feeds whole per-rank minibatches; --dp-mode exact shards ONE global batch by frames -- "
+                 "the combination is not implemented (its numbers would be mislabelled)")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     run_rank(a)

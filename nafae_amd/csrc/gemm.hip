@@ -797,11 +797,11 @@ void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *_
   const size_t astep = (size_t)32 * lda * sizeof(float), bstep = (size_t)32 * ldb * sizeof(float);
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
   auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index (0-7: A rows, 8-15: B rows)
-    // (M0, the LDS-DMA destination, is written and read inside ONE asm statement; an "m0" clobber is ignored by hipcc -- the
-    // generated kernel contains no other use of M0: checked in the ISA)
+    // (M0, the LDS-DMA destination, is written and read inside ONE asm statement and declared clobbered; tests/test_build_isa.py
+    // disassembles the built object and asserts that this kernel touches M0 nowhere else)
     const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
     const char *b = (i < 8 ? abase + (size_t)i * astep : bbase + (size_t)(i - 8) * bstep) + (size_t)kt * (BK * sizeof(float));
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? av : bv), "s"(b) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? av : bv), "s"(b) : "memory", "m0");
   };
   // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads the 16 B at logical slot 2 jj + h of its row: element e of step jj
   // is k = 8 jj + 4 h + e on both sides

@@ -462,11 +462,11 @@ void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, f
   const size_t xstep = (size_t)32 * 2 * ldx * sizeof(__bf16), wstep = (size_t)32 * 2 * ldw * sizeof(__bf16);
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
   auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index 0 .. 15 (0-7 activation side, 8-15 weight side)
-    // (M0, the LDS-DMA destination, is written and read inside ONE asm statement; an "m0" clobber is ignored by hipcc -- the
-    // generated kernel contains no other use of M0: checked in the ISA)
+    // (M0, the LDS-DMA destination, is written and read inside ONE asm statement and declared clobbered; tests/test_build_isa.py
+    // disassembles the built object and asserts that this kernel touches M0 nowhere else)
     const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
     const char *b = (i < 8 ? xbase + (size_t)i * xstep : wbase + (size_t)(i - 8) * wstep) + (size_t)kt * (2 * BKH * sizeof(__bf16));
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? xv : wv), "s"(b) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? xv : wv), "s"(b) : "memory", "m0");
   };
   // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads 16 B at logical slot plane * 4 + 2 s + h of its row
   const int fr = lane & 31, h = lane >> 5, sw = (fr >> 1) & 7;

@@ -688,9 +688,10 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
   Top *ctop = reinterpret_cast<Top *>(smem);                       // [4 contributors][GC]
   int *cnan = reinterpret_cast<int *>(smem + 4 * GC * sizeof(Top));   // [4][GC]
   float *red = reinterpret_cast<float *>(smem + 4 * GC * sizeof(Top) + 4 * GC * 4);   // [2][4 staging waves]
-  int *nslow = reinterpret_cast<int *>(red + 8);                   // [1] number of columns on the slow path
+  float2 *sbest = reinterpret_cast<float2 *>(red + 8);             // [8 waves] per-wave result of a slow column (8-B aligned:
+  static_assert((4 * GC * sizeof(Top) + 4 * GC * 4 + 32) % 8 == 0, "sbest must be 8-byte aligned");   // ds_read/write_b64)
+  int *nslow = reinterpret_cast<int *>(sbest + 8);                 // [1] number of columns on the slow path
   int *slowc = nslow + 1;                                           // [GC] their column indices
-  float2 *sbest = reinterpret_cast<float2 *>(slowc + GC);          // [8 waves] per-wave result of a slow column
   if (tid == 0) nslow[0] = 0;
   if (wave < 4) {
 #pragma unroll
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(512) void sim_frame_kernel(const float *__restrict_
 
   // ---- one thread per column: winner, the other LISTED candidates within the margin of the best filter value, and whether an
   // UNLISTED row could lie within it (a contributor's third-best value too close) or a NaN was seen (-> slow list)
-  int *rec = reinterpret_cast<int *>(sbest + 8);                   // [GC][10]: i1, ncand, cand[0..7]
+  int *rec = slowc + GC;                                           // [GC][10]: i1, ncand, cand[0..7]
   if (tid < GC) {
     const int c = tid;
     Top t[4];

@@ -11,6 +11,19 @@ import torch
 import torch.distributed as dist
 
 
+# A world-size-1 process group normally skips every collective (nothing to exchange).  FORCE_COLLECTIVES makes them execute
+# anyway, so that the RCCL code path -- init, all_reduce, all_to_all_single, all_gather_into_tensor, all_gather, broadcast,
+# barrier -- can run end to end on a one-GPU box (`bench.py --gpus 1 --force-dist`, tests/test_gpu_rccl_world1.py).
+FORCE_COLLECTIVES = False
+
+
+def _exchange(group=None):
+    """True when collectives have to run: an initialised process group with more than one rank (or FORCE_COLLECTIVES)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
+
+
 def trainable_parameters(model):
     """The parameters the reference's optimiser can actually move (model.py:1077-1082 builds Adam over
     DVSA + word_ebd + vis_ebd, but DVSA's parameters never get a gradient)."""
@@ -77,12 +90,12 @@ class GradAllReducer:
         with per-rank minibatches).  average=False is the frame-sharded exact mode, where every rank holds a PARTIAL
         gradient of one global loss."""
         self.bind()
-        if self.world > 1:
+        if self.world > 1 or _exchange(self.group):
             if self.mode == "direct":
                 _direct_reduce(self._buf, self.world, self.group)
             else:
                 _all_reduce_sum(self.flat, self.group)
-            if average:
+            if average and self.world > 1:
                 self.flat.div_(self.world)
         return self.flat
 
@@ -134,7 +147,7 @@ def _direct_reduce(buf, world, group=None):
 def all_gather_rows(t, group=None):
     """[n, ...] on every rank (same n) -> [world*n, ...] in rank order."""
     world = _world(group)
-    if world == 1:
+    if not _exchange(group):
         return t
     src = t.cpu() if _host_staged(t, group) else t.contiguous()
     parts = [torch.empty_like(src) for _ in range(world)]
@@ -143,7 +156,7 @@ def all_gather_rows(t, group=None):
 
 
 def broadcast_rows(t, src=0, group=None):
-    if _world(group) == 1:
+    if not _exchange(group):
         return t
     if _host_staged(t, group):
         h = t.cpu()
@@ -220,7 +233,7 @@ def dvsa_frame_sharded(dvsa, vis_feats_local, word_feats, entities_length, group
 
 def broadcast_parameters(model, src=0, group=None):
     """Make every rank start from rank `src`'s weights and BatchNorm statistics."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchange(group):
         return
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):

@@ -30,6 +30,17 @@ def get_word(glove, word):
     return glove.vectors[glove.stoi[word]]
 
 
+def resize_target(args, H, W):
+    """(height, width) a decoded H x W frame leaves the loader with (youcook2.py:215-217).  A frame that already is
+    img_h x img_w passes; any other is resized by `cv2.resize(img, (img_h, img_w))` -- and cv2's dsize is (WIDTH, HEIGHT), so
+    the reference's output has height img_w and width img_h.  Bug-compatible: identical for the square 224 x 224 default,
+    transposed target for any other pair (loader.load_segment passes the same tuple to its cv2-style callable)."""
+    ih, iw = getattr(args, 'img_h', H), getattr(args, 'img_w', W)
+    if H == ih and W == iw:
+        return H, W
+    return iw, ih
+
+
 def prepare_batch(loader_batch, glove, args, device='cuda', raw_frames=False):
     """The host-side preparation train() does on every loader tuple (model.py:684-747), returning a Batch, or None
     when the reference skips the iteration (`max(entities_length) == 0`, model.py:685-686).
@@ -52,7 +63,7 @@ def prepare_batch(loader_batch, glove, args, device='cuda', raw_frames=False):
         if im_blobs.dtype != np.uint8:
             raise TypeError("raw_frames=True expects the decoded uint8 frames, got %s" % im_blobs.dtype)
         im_data = torch.from_numpy(np.ascontiguousarray(im_blobs)).to(device)     # uint8 HWC: the first conv layer reads it as is
-        th, tw = getattr(args, 'img_h', H), getattr(args, 'img_w', W)
+        th, tw = resize_target(args, H, W)
         if (H, W) != (th, tw):        # youcook2.py:215-217: frames of another size are resized (bilinear) -- here on the GPU
             im_data = ops.frames_resize_bilinear(im_data, th, tw)
             H, W = th, tw
@@ -109,9 +120,28 @@ def detector_forward(model, batch):
     det.materialize_pooled = False
     try:
         with torch.no_grad():
-            return det(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+            _frames_ready(batch)
+            out = det(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+            _frames_consumed(batch)
+            return out
     finally:
         det.materialize_pooled = keep
+
+
+def _frames_ready(batch):
+    """A streamed batch (FrameStreamer) carries the event of its H2D copy: the stream the detector is about to run on waits for
+    it.  Every detector call of this module goes through here (train_step, train_step_exact, PipelinedTrainer, eval_step)."""
+    ready = getattr(batch, "ready_event", None)
+    if ready is not None:
+        torch.cuda.current_stream().wait_event(ready)
+
+
+def _frames_consumed(batch):
+    """... and leaves the event after which the device frame buffer may be overwritten."""
+    if getattr(batch, "ready_event", None) is not None:
+        ev = torch.cuda.Event()
+        ev.record()
+        batch.consumed_event = ev
 
 
 def criterion_backward(criterion, margin_loss):
@@ -133,7 +163,8 @@ class FrameStreamer:
     step k: 64 x 224 x 224 x 3 bytes = 9.6 MB per step instead of the 38.5 MB of fp32 frames, and the first conv layer reads
     the bytes as they are.  `host_batches`: list of pinned uint8 tensors [F,H,W,3]; `template`: a Batch whose other fields
     (im_info, GloVe rows, lengths) are reused.  next() returns a Batch carrying `ready_event` (recorded on the copy stream);
-    the consumer sets `consumed_event` when its detector has read the frames (PipelinedTrainer.submit / train_step do)."""
+    `detector_forward` / `eval_step` -- every detector call of this module -- wait for it and set `consumed_event` once the
+    detector has read the frames; a buffer whose batch never got one is protected by a wait on the caller's stream."""
 
     def __init__(self, host_batches, template, device):
         self.host, self.template, self.k = host_batches, template, 0
@@ -147,8 +178,13 @@ class FrameStreamer:
         self.k += 1
         prev = self.last[b]
         with torch.cuda.stream(self.copy):
-            if prev is not None and getattr(prev, "consumed_event", None) is not None:
-                self.copy.wait_event(prev.consumed_event)
+            if prev is not None:
+                if getattr(prev, "consumed_event", None) is not None:
+                    self.copy.wait_event(prev.consumed_event)
+                else:
+                    # the batch that holds this buffer was never handed to a detector call of this module (or next() ran more
+                    # than twice ahead): whatever reads it was enqueued on the caller's stream -- wait for that, never overwrite
+                    self.copy.wait_stream(torch.cuda.current_stream(self.dbuf[b].device))
             self.dbuf[b].copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy)
@@ -162,13 +198,7 @@ class FrameStreamer:
 
 def train_step(model, optimizer, criterion, batch, args, reducer=None):
     """One iteration of model.py:684-775.  Returns the (device) loss; no host synchronisation inside."""
-    ready = getattr(batch, "ready_event", None)
-    if ready is not None:
-        torch.cuda.current_stream().wait_event(ready)
-    rois, roi_scores, roi_feats, fc_feats = detector_forward(model, batch)
-    if ready is not None:
-        batch.consumed_event = torch.cuda.Event()
-        batch.consumed_event.record()
+    rois, roi_scores, roi_feats, fc_feats = detector_forward(model, batch)     # (waits for / releases streamed frames)
     vis_feats = model.vis_ebd(fc_feats)
     word_feats = model.word_ebd(batch.glove_feats)
     if reducer is not None:
@@ -193,8 +223,11 @@ def shard_frames(batch, rank, world):
     if F % world:
         raise ValueError("%d frames do not split over %d ranks" % (F, world))
     k = F // world
-    return Batch(batch.im_data[rank * k:(rank + 1) * k], batch.im_info[rank * k:(rank + 1) * k], batch.glove_feats,
-                 batch.entities_length)
+    out = Batch(batch.im_data[rank * k:(rank + 1) * k], batch.im_info[rank * k:(rank + 1) * k], batch.glove_feats,
+                batch.entities_length)
+    if getattr(batch, "ready_event", None) is not None:       # a streamed global batch: the shard waits for the same copy
+        out.ready_event = batch.ready_event
+    return out
 
 
 def shared_word_dropout_generator(model, args):
@@ -248,24 +281,25 @@ class PipelinedTrainer:
     step fill them.  This is the overlap SURVEY.md section 8(e) asks for ("overlap with the detector forward of the next
     step"), applied to the whole tail.  Every step still does exactly one detector forward and one tail."""
 
-    def __init__(self, model, optimizer, criterion, args, reducer):
+    def __init__(self, model, optimizer, criterion, args, reducer, tail_priority=True):
         self.model, self.optimizer, self.criterion, self.args, self.reducer = model, optimizer, criterion, args, reducer
         self.det_stream = torch.cuda.Stream()
+        # The tail is ~20 short, latency-bound launches that compete with the detector's chip-filling kernels for CU slots: on a
+        # stream of equal priority each of them queues behind whole waves of conv workgroups (stage_ms `sim_max` 1.39 ms in-step
+        # against 0.012 ms alone).  It therefore runs on a HIGH-priority HIP stream (torch offers default and higher, not lower:
+        # the detector stream cannot be demoted), fenced against the caller's stream on both sides, so callers still see
+        # main-stream semantics.  tail_priority=False runs the tail on the caller's stream as before (A/B: bench.py).
+        self.tail_stream = torch.cuda.Stream(priority=-1) if tail_priority else None
         self.pending = None
 
     def submit(self, batch):
         """Enqueue the detector forward for `batch` on the detector stream (returns immediately)."""
         main = torch.cuda.current_stream()
         self.det_stream.wait_stream(main)          # inputs (and any weight re-packing) issued so far are visible
-        ready = getattr(batch, "ready_event", None)
-        if ready is not None:                      # frames still in flight on a copy stream (FrameStreamer)
-            self.det_stream.wait_event(ready)
-        with torch.cuda.stream(self.det_stream):
+        with torch.cuda.stream(self.det_stream):   # (frames still in flight on a copy stream: detector_forward waits for them)
             rois, roi_scores, roi_feats, fc_feats = detector_forward(self.model, batch)
             ev = torch.cuda.Event()
             ev.record(self.det_stream)
-            if ready is not None:
-                batch.consumed_event = ev          # the device frame buffer may be overwritten once this has passed
         self.pending = (batch, rois, fc_feats, ev)
 
     def step(self, next_batch=None):
@@ -276,26 +310,35 @@ class PipelinedTrainer:
         if next_batch is not None:
             self.submit(next_batch)
         main = torch.cuda.current_stream()
-        main.wait_event(ev)
+        tail = self.tail_stream if self.tail_stream is not None else main
+        if tail is not main:
+            tail.wait_stream(main)                 # everything the caller enqueued so far (inputs, the previous step's results)
+        tail.wait_event(ev)
         for t in (rois, fc_feats):                 # produced on the detector stream, consumed here
+            t.record_stream(tail)
             t.record_stream(main)
         planes = getattr(fc_feats, "_nafae_planes", None)   # fc7's split-bf16 planes travel with it (VisEbd reads them)
         if planes is not None:
             for t in (planes.hi, planes.lo):
                 if t is not None:
-                    t.record_stream(main)
+                    t.record_stream(tail)
         model, args = self.model, self.args
-        vis_feats = model.vis_ebd(fc_feats)
-        word_feats = model.word_ebd(batch.glove_feats)
-        self.reducer.zero_grad()
-        D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
-        loss = criterion_backward(self.criterion, margin_loss)
-        self.reducer.allreduce()
-        if isinstance(self.optimizer, FusedClipAdam):
-            self.optimizer.step()
-        else:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
-            self.optimizer.step()
+        with torch.cuda.stream(tail):
+            vis_feats = model.vis_ebd(fc_feats)
+            word_feats = model.word_ebd(batch.glove_feats)
+            self.reducer.zero_grad()
+            D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
+            loss = criterion_backward(self.criterion, margin_loss)
+            self.reducer.allreduce()
+            if isinstance(self.optimizer, FusedClipAdam):
+                self.optimizer.step()
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip)
+                self.optimizer.step()
+        if tail is not main:
+            main.wait_stream(tail)                 # the caller's stream sees the finished step
+            for t in (loss, D, D_sim):             # allocated on the tail stream, handed to the caller's stream
+                t.record_stream(main)
         return loss, D, D_sim, rois
 
 
@@ -338,8 +381,10 @@ def train_epoch(train_loader, model, glove, criterion, optimizer, reducer, args,
 def eval_step(model, batch):
     """Forward of validate() (model.py:875-947) for one segment batch."""
     with torch.no_grad():
+        _frames_ready(batch)
         rois, roi_scores, roi_feats, fc_feats = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes,
                                                                  batch.num_boxes)
+        _frames_consumed(batch)
         vis_feats = model.vis_ebd(fc_feats)
         word_feats = model.word_ebd(batch.glove_feats)
         D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)

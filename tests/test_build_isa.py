@@ -1,0 +1,56 @@
+"""Build-time ISA checks on the in-tree objects (no GPU needed: hipcc cross-compiles).
+
+The one-wave-per-SIMD GEMMs issue their LDS-DMAs through inline asm that writes M0 (the DMA's LDS destination) and reads it in the
+same statement.  hipcc does not model M0 inside inline asm beyond the declared clobber, so the kernels are only correct while
+NOTHING else in them uses M0: disassemble the gfx950 code objects and assert that, per kernel, every instruction that
+mentions m0 is either the `s_mov_b32 m0, ...` of a DMA sequence or the `global_load_lds_dwordx4` that consumes it."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _disassemble(obj):
+    with tempfile.TemporaryDirectory() as d:
+        o = os.path.join(d, os.path.basename(obj))
+        shutil.copy(obj, o)
+        subprocess.check_call([OBJDUMP, "--offloading", o], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
+        co = [f for f in os.listdir(d) if "gfx950" in f]
+        assert co, os.listdir(d)
+        return subprocess.check_output([OBJDUMP, "-d", os.path.join(d, co[0])], text=True)
+
+
+def _functions(asm):
+    name, body, out = None, [], {}
+    for line in asm.splitlines():
+        if line.endswith(">:") and "<" in line:
+            if name:
+                out[name] = body
+            name, body = line[line.index("<") + 1:-2], []
+        elif name and line.strip():
+            body.append(line.strip())
+    if name:
+        out[name] = body
+    return out
+
+
+@pytest.mark.parametrize("obj,needle", [("gemm.o", "f32_gemm4_kernel"), ("gemm_bf16.o", "bf16_gemm4_kernel")])
+def test_m0_only_in_dma_sequences(obj, needle):
+    path = os.path.join(ROOT, "nafae_amd", "csrc", obj)
+    if not os.path.exists(path) or not os.path.exists(OBJDUMP):
+        pytest.skip("object or llvm-objdump missing (run __graft_entry__.build() first)")
+    fns = {k: v for k, v in _functions(_disassemble(path)).items() if needle in k}
+    assert fns, "no %s in %s" % (needle, obj)
+    for name, body in fns.items():
+        uses = [(i, l) for i, l in enumerate(body) if "m0" in l.split("//")[0]]
+        assert uses, name + ": expected LDS-DMA sequences"
+        for i, l in uses:
+            ins = l.split("//")[0]
+            assert ins.startswith("s_mov_b32 m0,") or ins.startswith("global_load_lds_dwordx4"), (name, l)
+            if ins.startswith("global_load_lds_dwordx4"):       # its destination was set by the s_mov two instructions above
+                assert any(body[j].startswith("s_mov_b32 m0,") for j in range(max(0, i - 3), i)), (name, i, l)
