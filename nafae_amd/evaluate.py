@@ -62,7 +62,7 @@ def _summary(match, count):
     return float(np.mean(cls_acc)), float(np.sum(match) / np.sum(count))
 
 
-def phrase_accuracy(recs, dets, class_list, verbose=False):
+def phrase_accuracy(recs, dets, class_list, verbose=False, both=False):
     """Per (frame, query class): counted once if the class has a gt box in the frame; matched if any of its gt boxes
     overlaps the grounded box with IoU >= that box's threshold.  Returns the macro (class-mean) accuracy.
 
@@ -96,10 +96,10 @@ def phrase_accuracy(recs, dets, class_list, verbose=False):
     if verbose:
         print('macro query accuracy: {:0.2%}'.format(macro))
         print('micro query accuracy: {:0.2%}'.format(micro))
-    return macro
+    return (macro, micro) if both else macro        # (the reference returns the macro figure; `both` adds the printed micro one)
 
 
-def box_accuracy(recs, dets, class_list, verbose=False):
+def box_accuracy(recs, dets, class_list, verbose=False, both=False):
     """Per gt box: counted always; matched if some detection of the same class in that frame has IoU >= its threshold."""
     cells, num_imgs = _group_by_frame(dets)
     match = np.zeros(len(class_list), dtype=int)
@@ -119,7 +119,7 @@ def box_accuracy(recs, dets, class_list, verbose=False):
     if verbose:
         print('macro box accuracy: {:0.2%}'.format(macro))
         print('micro box accuracy: {:0.2%}'.format(micro))
-    return macro
+    return (macro, micro) if both else macro
 
 
 def evaluate_box(recs, dets, class_list, verbose=False):

@@ -197,6 +197,93 @@ def test_full_size_detector_and_grounding(name, precision, capsys):
         assert abs(float(gw.double().norm()) - float(g["g_ve_w_norm"])) < bars["grad"] * float(g["g_ve_w_norm"])
 
 
+def synthetic_ground_truth(Na, Ns, lens, seed, H=224, W=224, vocab=("bowl", "egg", "pan", "oil", "salt", "water", "knife", "rice")):
+    """Seeded ground truth that depends on NEITHER detection path: per segment the entity labels (a small vocabulary, repeats
+    allowed -- youcook_eval's per-frame label bookkeeping sees them), per (frame, entity) one gt box drawn uniformly with sides of
+    60..200 px and an individual IoU threshold from {0.1, 0.3, 0.5} (youcook_eval.py's `thr` field), so that the accuracy is a
+    mid-range number on which a changed grounded box can show.  -> (vid_entities, recs, class_list) in the formats of
+    model.py:906-909 and youcook_eval.parse_gt."""
+    rs = np.random.RandomState(seed)
+    vid_entities = [[vocab[i] for i in rs.randint(0, len(vocab), l)] for l in lens]
+    recs = []
+    for a in range(Na):
+        for s_ in range(Ns):
+            labels, boxes, thrs = [], [], []
+            for ent in vid_entities[a]:
+                w, h = rs.randint(60, 201), rs.randint(60, 201)
+                x1, y1 = rs.randint(0, W - w + 1), rs.randint(0, H - h + 1)
+                labels.append(ent); boxes.append([float(x1), float(y1), float(x1 + w - 1), float(y1 + h - 1)])
+                thrs.append(float(rs.choice([0.1, 0.3, 0.5])))
+            recs.append({"label": labels, "bbox": boxes, "thr": thrs, "img_ids": [a * Ns + s_] * len(labels)})
+    return vid_entities, recs, list(vocab)
+
+
+def accuracies(rois, D_ind, D_sim, dims, vid_entities, recs, class_list):
+    """Detections of one path through the reference's own chain: postprocess (model.py:457-474) -> record_det (:477-487) ->
+    box_accuracy / phrase_accuracy (youcook_eval.py:241-336, :135-237).  -> (macro box, micro box, macro phrase, micro phrase)."""
+    from nafae_amd import evaluate as E
+    from nafae_amd.model import postprocess
+    Na, Ns, Nb, Ne = dims
+    Dp, Sp = postprocess(np.asarray(D_ind), np.asarray(D_sim), Na, Ns, Nb, Ne)
+    dets = [[], [], [], []]
+    E.record_det(dets[0], dets[1], dets[2], dets[3], Nb, vid_entities, Dp, Sp, list(range(Na * Ns)),
+                 np.asarray(rois)[:, :, 1:5].reshape(-1, 4))
+    out = []
+    for fn in (E.box_accuracy, E.phrase_accuracy):
+        out += list(fn(recs, dets, class_list, both=True))
+    return out, dets
+
+
+ACC_CASES = [("c2", "f32"), ("c2", "bf16x3"), ("c4", "f32"), ("c4", "bf16x3"), ("c5", "f32"), ("c5", "bf16x3")]
+
+
+@pytest.mark.parametrize("name,precision", ACC_CASES, ids=["%s-%s" % c for c in ACC_CASES])
+def test_grounding_accuracy_delta_vs_oracle(name, precision, capsys):
+    """north_star: "grounding accuracy within +-0.1 % of the reference on identical inputs".  The HIP detections of the config's
+    seeded 64-frame batch and the ORACLE's detections of the same batch (rebuilt from the fixture's rois / D_ind / D_sim) go
+    through postprocess -> record_det -> box_accuracy and phrase_accuracy (model.py:457-487, youcook_eval.py:135-336) against one
+    synthetic ground truth that is independent of both; |delta| <= 0.001 on all four figures.  eval-mode DVSA, like validate()."""
+    c = load_config(name)
+    g, model, batch = c["g"], c["model"], c["batch"]
+    Na, Ns, Nb, Ne = c["dims"]
+    c["cfg"].TEST.RPN_POST_NMS_TOP_N = Nb
+    fr = model.fasterRCNN
+    fr.precision = precision
+    model.eval(); model.DVSA.init_eval(); model.DVSA.Na = Na
+    try:
+        with torch.no_grad():
+            rois, roi_scores, pooled, fc7 = fr(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+            V = model.vis_ebd(fc7)
+            W = model.word_ebd(batch.glove_feats)
+            D_ind, D_sim, L = model.DVSA(V, W, batch.entities_length)
+    finally:
+        model.train(); model.DVSA.init_train(); fr.eval()
+    # validate() records the own-segment pairs only (Ns x sum(lens) = 152 detections here): one changed match would be 0.66 % of
+    # one ground truth, so the comparison is pooled over N_GT independent ground truths (mean of each figure), which resolves 0.08 %
+    N_GT = 8
+    hip_all, ora_all, moved, n_det = [], [], 0, 0
+    r_h, d_h, s_h = rois.cpu().numpy(), D_ind.cpu().numpy(), D_sim.cpu().numpy()
+    for k in range(N_GT):
+        vid_entities, recs, class_list = synthetic_ground_truth(Na, Ns, batch.entities_length, seed=4242 + 17 * k + Nb)
+        hip, dets_h = accuracies(r_h, d_h, s_h, c["dims"], vid_entities, recs, class_list)
+        ora, dets_o = accuracies(g["rois"], g["D_ind"], g["D_sim"], c["dims"], vid_entities, recs, class_list)
+        hip_all.append(hip); ora_all.append(ora)
+        n_det = len(dets_h[0])
+        assert n_det == len(dets_o[0]) == Ns * sum(batch.entities_length)
+        moved = int(sum(1 for bh, bo in zip(dets_h[2], dets_o[2]) if np.abs(np.asarray(bh) - np.asarray(bo)).max() >= 0.02))
+    hip_all, ora_all = np.array(hip_all), np.array(ora_all)
+    hip, ora = hip_all.mean(0), ora_all.mean(0)
+    worst_single = float(np.abs(hip_all - ora_all).max())
+    with capsys.disabled():
+        print("\n[%s %-6s accuracy, mean over %d ground truths] box macro %.4f vs oracle %.4f | box micro %.4f vs %.4f | phrase macro "
+              "%.4f vs %.4f | phrase micro %.4f vs %.4f | %d detections, %d grounded boxes differ by >= 0.02 px | max |delta| of the "
+              "means %.5f (worst single ground truth %.5f)"
+              % (name.upper(), precision, N_GT, hip[0], ora[0], hip[1], ora[1], hip[2], ora[2], hip[3], ora[3], n_det, moved,
+                 float(np.abs(hip - ora).max()), worst_single))
+    assert 0.02 < ora[1] < 0.98, "the synthetic ground truth must give a mid-range accuracy"
+    assert float(np.abs(hip - ora).max()) <= 0.001, (hip, ora)
+
+
 @pytest.mark.parametrize("name", ["c4", "c5"])
 def test_full_step_at_size_properties(name, capsys):
     """C4's per-GPU share and C5 as FULL TRAINING STEPS on one GPU (what `bench.py --gpus 8` runs per rank): two pipelined
