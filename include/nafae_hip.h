@@ -259,7 +259,7 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
  *   - routing (simmax.hip fused_route / make_plan), Qh = the live-column count the launch is sized for
  *     (max_live_cols if >= 0, else Na*Ne):
  *       D % 32 == 0, D <= 512, and Qh <= 64 or a shape the next route does not take:
- *                                                fp32 live-column kernel + merge (simfused.hip sim_live_kernel), ceil(Qh / 32)
+ *                                                fp32 live-column kernel (simfused.hip sim_live_kernel, ONE launch), ceil(Qh / 32)
  *                                                column blocks: every score is an fp32 dot product on the fp32 matrix cores,
  *                                                no filter, no margin;
  *       Qh > 64, Nb > 64, D % 64 == 0, D <= 512  one launch, one workgroup per (frame, 64 / 128 live columns)
@@ -276,12 +276,48 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
  *   - max_live_cols: an UPPER BOUND on the number of live slots, sum_a min(max(ent_len[a],0),Ne), if the host knows it
  *     (it sizes the launch), or -1 = unknown (sized for all Na*Ne).  A bound that is too small is a caller error that is
  *     made visible: the live columns beyond it come back as (NaN, 0), never as a plausible wrong maximum;
- *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes (the per-row-block records of the live-column route at
- *     Qh = Na*Ne: F * ceil(Nb/32) * ceil(Q/32) * 256 bytes + the column map), no initialisation needed.  */
+ *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes: 1 MiB of arrival counters, then the per-row-block records of
+ *     the live-column route at Qh = Na*Ne (F * ceil(Nb/32) * ceil(Q/32) * 256 bytes).  Round 4: the live-column route finishes
+ *     inside its one launch -- the last of a frame's row-block workgroups to arrive merges their records -- so the first 1 MiB
+ *     (the counters) must be ZERO when the FIRST call on a workspace starts (hipMemsetAsync once, at allocation); every completed
+ *     call leaves it zero, whatever its shape, so one workspace serves calls of different shapes on one stream.  (After an aborted
+ *     launch zero it again.)  Calls that share a workspace must be stream-ordered.  */
 int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D);
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
                          int max_live_cols, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
                          void *stream);
+
+/* ---- similarity operand planes (round 4; simplanes.hip) -------------------------------------------------------------------
+ * The many-live-column route of the call above converted its fp32 operands into matrix-core planes inside the kernel, once per
+ * (frame, column group) workgroup, beside the MFMA waves (round 3: 33 us of a 60 us kernel at C5).  With planes the operands are
+ * split ONCE by their producer -- the dropout + tanh epilogue of VisEbd / WordEbd (model.py:627-628, 641-642) -- and the
+ * similarity kernel stages them by LDS-DMA.
+ *   kind NAFAE_SIMPLANES_BF16X3: per row and 32 k one 128-byte line [hi k 0..31 | lo k 0..31], hi = bf16(x), lo = bf16(x - hi);
+ *        rows * D * 4 bytes; D % 32 == 0.  Filter = hi*hi + hi*lo + lo*hi (three bf16 MFMAs).
+ *   kind NAFAE_SIMPLANES_F16:    per row D fp16 values (round to nearest even); rows * D * 2 bytes; D % 64 == 0.  Filter = one
+ *        fp16 MFMA per product (a third of the matrix work, half the staged bytes, a wider margin).
+ *   stats: f32 [rows][2] = (max |x|, sqrt(sum x^2)) of every row, written with the planes; the filter margin is built from them.
+ * The planes only FILTER: every row within the margin of its column's best filter value is re-evaluated as an exact fp32 dot
+ * product from V and W themselves, so S_max / D_ind keep the contract of nafae_sim_max_fwd_ws (fp32 dot products, torch.max's
+ * tie / NaN rules) whatever the plane kind.  Planes and stats MUST come from the calls below on the same V / W values.  */
+#define NAFAE_SIMPLANES_BF16X3 0
+#define NAFAE_SIMPLANES_F16 1
+int64_t nafae_sim_planes_bytes(int rows, int D, int kind);
+/* planes + stats of an fp32 matrix X [rows, D] (the stand-alone form).  */
+int nafae_sim_planes(const float *X, int rows, int D, int kind, void *planes, float *stats, void *stream);
+/* nafae_dropout_tanh / nafae_dropout_tanh_seeded (below) over x [rows, D] that ALSO write the planes and stats of their result y
+ * in the same pass; y is bit-identical to what those calls write.  */
+int nafae_dropout_tanh_planes(const float *x, const uint8_t *mask, float scale, float *y, int rows, int D, int kind,
+                              void *planes, float *stats, void *stream);
+int nafae_dropout_tanh_seeded_planes(const float *x, uint64_t seed, float p, float *y, int rows, int D, int kind, void *planes,
+                                     float *stats, void *stream);
+/* nafae_sim_max_fwd_ws with operand planes.  Where the many-live-column route applies (Qh > 64, Nb > 64, D <= 512, D a multiple
+ * of the plane kind's line) the planes kernel runs (sim_planes_kernel); every other shape takes nafae_sim_max_fwd_ws's routes on
+ * V and W and ignores the planes.  V_planes / V_stats cover the F * Nb rows of V, W_planes / W_stats the Na * Ne rows of W.  */
+int nafae_sim_max_fwd_planes(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
+                             int max_live_cols, int kind, const void *V_planes, const float *V_stats, const void *W_planes,
+                             const float *W_stats, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
+                             void *stream);
 
 /* Bytes of workspace nafae_loss_fwd_bwd needs.  */
 int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D);

@@ -24,6 +24,7 @@ SOURCES = [
     ("simloss.hip", []),
     ("simmax.hip", []),
     ("simfused.hip", []),
+    ("simplanes.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "--offload-arch=" + ARCH, "-fhip-fp32-correctly-rounded-divide-sqrt", "-std=c++17",
           "-Wall", "-Wno-unused-function"]

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -12,6 +14,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 namespace nafae_sim {
 
 constexpr int NA_MAX = 2048;   // segments per batch the live-column prefix table holds (LDS)
+constexpr int FEW_NCNT = 1 << 18;   // arrival counters at the start of the similarity workspace (sim_live_kernel): F * ceil(L / 32) of them are used
 
 // (value desc, index asc): the order torch.max(dim) resolves ties in (first maximal index)
 __device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -112,6 +115,57 @@ __device__ __forceinline__ float wave_dot(const float *__restrict__ vrow, const 
     }
   }
   return wave_sum(acc);
+}
+
+
+// ---- pieces shared by the frame kernels (simfused.hip, simplanes.hip) ----------------------------------------------------------
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, typename Fn>
+__device__ __forceinline__ void unroll_blocks(Fn &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    unroll_blocks<N, I + 1>(f);
+  }
+}
+
+// max(m, |x0|, |x1|, |x2|, |x3|) in two v_max3_f32 (the |.| are source modifiers)
+__device__ __forceinline__ float absmax4(float m, const f32x4 x) {
+  asm("v_max3_f32 %0, |%1|, |%2|, %0\n\tv_max3_f32 %0, |%3|, |%4|, %0" : "+v"(m) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+  return m;
+}
+
+// workgroup barrier without the vmcnt(0) of __syncthreads(): waves keep global loads / LDS-DMAs in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// 16-B slot swizzle of a 128-B stage row.  u = (row >> 1) & 7 enumerates the 8 slots over 16 consecutive rows (8 even + 8 odd
+// rows: the 16 lanes of a ds_read_b128 group hit all 64 banks once); its bits are ROTATED (u0 -> bit 2) so that the rows r and
+// r + 2 a staging wave writes in one ds_write_b64 put their 64-B plane halves into different halves of the row -- with the
+// plain value the four even rows of a write shared 16 banks (4 cycles per write instead of 2); the row's parity flips bit 2.
+__device__ __forceinline__ int frame_swz(int row) {
+  const int u = (row >> 1) & 7;
+  return (((u & 1) << 2) | (u >> 1)) ^ ((row & 1) << 2);
+}
+
+// Seeded dropout: the keep decision of element i is a pure function of (seed, i) -- a counter-based generator with a 2 x 32-bit
+// multiply-xorshift mix (not bit-compatible with torch's Philox stream, which nothing downstream depends on: the reference draws
+// its masks from the device generator, model.py:627,641).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t i, uint32_t thresh) {
+  const uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
+  uint32_t h = mix32(lo ^ (uint32_t)seed);
+  h = mix32(h + hi * 0x9e3779b9U + (uint32_t)(seed >> 32));
+  return h >= thresh;                 // P(drop) = thresh / 2^32
 }
 
 }  // namespace nafae_sim

@@ -2,13 +2,13 @@
 // 580-583, 610-612), third generation, gfx950.  Two kernels that replace simmax.hip's part / tile + finish pairs where they apply
 // (simmax.hip's make_plan routes; its kernels stay as the fallback for the shapes these do not take):
 //
-//   sim_live_kernel (+ sim_few_merge_kernel)   L <= 32 live query slots -- every BASELINE configuration with entity lengths from
+//   sim_live_kernel   L <= 32 live query slots per column block -- every BASELINE configuration with entity lengths from
 //       the data set's histogram (C2: 19 of 128 slots live, C5: 17 of 512).  The problem is then a pure stream of V (C5: 39 MB
 //       against 0.7 GFLOP), so there is no filter and no second pass over V at all: every (proposal, live query) score is an
 //       fp32 dot product on the fp32 matrix cores while the rows stream through (a wave = 32 rows x a quarter of K, see the
 //       kernel).  A workgroup owns 32 consecutive rows of ONE frame and leaves its per-column (max, arg-max) in the workspace;
-//       the merge kernel takes the best of a frame's workgroups (ties -> smaller index, NaN -> first NaN: torch.max's rules) and
-//       the masked slots are zero-filled.  All of V is requested within the first two microseconds.  (Its first form, fp32 FMA
+//       the LAST of a frame's workgroups to arrive takes the best of them (ties -> smaller index, NaN -> first NaN: torch.max's
+//       rules; round 3 did that in a second launch) and the masked slots are zero-filled.  All of V is requested within the first two microseconds.  (Its first form, fp32 FMA
 //       chains on the vector ALU with W as an LDS image, was VALU-bound at 17 us for C5 and is gone.)
 //
 //   sim_frame_kernel<RW, CW>   L > 32 (C5 with every slot live: 512 columns).  One workgroup = (frame, group of 64*CW live
@@ -51,43 +51,11 @@ __device__ unsigned long long nafae_simfused_stamps[8 * 8192];
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------------- few live columns: merge
 constexpr int FEW_MAXL = 32;    // live columns the kernel takes (one 32-column MFMA tile)
 constexpr int FEW_ROWS = 32;    // rows per workgroup (one 32-row MFMA tile; its 4 waves split K)
 
-// one thread per (frame, live column): the best of the frame's S row-block workgroups (ties -> smaller row, NaN first: torch.max's
-// rules).  parts[((f * S + s) * CB + cb) * 32 + c] = (value, row) of column cb * 32 + c over the rows of block s.
-__global__ __launch_bounds__(256) void sim_few_merge_kernel(const float2 *__restrict__ parts, const int *__restrict__ qlist, int F, int Nb,
-                                                            int Q, int S, int CB, float *__restrict__ S_max,
-                                                            int64_t *__restrict__ D_ind) {
-  const int LC = CB * FEW_MAXL;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int f = t / LC, j = t - f * LC;
-  if (f >= F) return;
-  // (the records of the columns j >= L are inside the workspace, unwritten: every load below is issued before the first
-  // result is looked at -- one memory latency instead of three dependent ones)
-  const int L = qlist[0];
-  const int q = qlist[1 + j];
-  const size_t cbo = (size_t)(j >> 5) * FEW_MAXL + (j & 31), stride = (size_t)CB * FEW_MAXL;
-  float2 b = parts[((size_t)f * S) * stride + cbo];
-  constexpr int SB = 16;
-  for (int s0 = 1; s0 < S; s0 += SB) {
-    float2 o[SB];
-#pragma unroll
-    for (int u = 0; u < SB; u++) o[u] = parts[((size_t)f * S + (s0 + u < S ? s0 + u : S - 1)) * stride + cbo];
-#pragma unroll
-    for (int u = 0; u < SB; u++)
-      if (s0 + u < S && better_nan(o[u].x, __float_as_int(o[u].y), b.x, __float_as_int(b.y))) b = o[u];
-  }
-  if (j >= L) return;
-  int bi = __float_as_int(b.y);
-  bi = bi < 0 ? 0 : (bi >= Nb ? Nb - 1 : bi);
-  S_max[(size_t)f * Q + q] = b.x;
-  D_ind[(size_t)f * Q + q] = (int64_t)bi;
-}
-
 // ---------------------------------------------------------------------------------------------------- few live columns, fp32 MFMA
-// Workgroup (f, s) = rows [s*32, s*32+32) of frame f against the L <= 32 live columns; `parts` records for sim_few_merge_kernel.
+// Workgroup (f, s) = rows [s*32, s*32+32) of frame f against the L <= 32 live columns; `parts` = the records of the in-launch merge.
 // v_mfma_f32_32x32x2_f32 multiplies and accumulates in fp32, so every score is an fp32 dot product (no filter, no margin, no
 // second pass) -- the 19 200 x 512 x 32 products of C5 cost 4 us of MFMA issue spread over the chip (as vector FMAs: 17 us).
 // Wave q of the workgroup owns a quarter of K -- whole 128-B lines, [q*NL/4, (q+1)*NL/4) of a row's NL = D/32 -- of the 32 rows,
@@ -119,8 +87,9 @@ __host__ __device__ inline LiveLds live_lds(int Na) {
 
 __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
                                                           const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne,
-                                                          int D, int S, int Lh, float2 *__restrict__ parts, int *__restrict__ qlist,
-                                                          float *__restrict__ S_max, int64_t *__restrict__ D_ind, int dbg) {
+                                                          int D, int S, int Lh, unsigned long long *__restrict__ parts,
+                                                          int *__restrict__ arrived, float *__restrict__ S_max,
+                                                          int64_t *__restrict__ D_ind, int dbg) {
   (void)dbg;   // timing experiment (experiments build): 1 = no MFMA (loads, transposition and the epilogue only)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const LiveLds lo = live_lds(Na);
@@ -188,10 +157,6 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
     const int c = cb * FEW_MAXL + (r31 < Lc ? r31 : Lc - 1);
     const int a = find_seg(prefix, Na, c);
     cq = a * Ne + (c - prefix[a]);
-  }
-  if (blockIdx.x == 0 && tid < FEW_MAXL) {      // the merge kernel's column -> query map (the frame-0 workgroups write it)
-    qlist[1 + cb * FEW_MAXL + tid] = tid < Lc ? cq : -1;
-    if (cb == 0 && tid == 0) qlist[0] = L;
   }
   if (Lc == 0 && !(s == 0 && cb == 0)) return;  // an over-provisioned column block (block (s = 0, cb = 0) still zero-fills)
   FSTAMP(1);
@@ -281,7 +246,60 @@ __global__ __launch_bounds__(256, 3) void sim_live_kernel(const float *__restric
       bv = ov;
       bi = oi;
     }
-    if (lane < Lc) parts[(((size_t)f * S + s) * CB + cb) * FEW_MAXL + lane] = make_float2(bv, __int_as_float(bi));
+    // ---- hand-off inside the launch (round 4; round 3 ran sim_few_merge_kernel as a second launch: 4 us of 18 at C5).  The S
+    // row-block workgroups of (frame, column block) leave their (max, arg-max) records in the workspace and count themselves on
+    // arrived[f][cb]; the one whose add returns S - 1 has seen every other arrive, reads the S records and writes the frame's
+    // result, then puts the counter back to 0 for the next call (the workspace is zeroed ONCE, when it is created).  Visibility
+    // across CUs / XCDs without fences (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores, the storing wave's
+    // vmcnt(0), one agent-scope add by a lane of that wave, sc1 loads by the wave whose add came last): records are written and
+    // read as 8-byte agent-scope relaxed atomics (global_store / global_load ... sc1), all by wave 0.
+    if (Lc > 0) {
+      unsigned long long *rec0 = parts + (((size_t)f * S) * CB + cb) * FEW_MAXL + r31;
+      const size_t rstride = (size_t)CB * FEW_MAXL;
+      if (lane < Lc)
+        __hip_atomic_store(rec0 + (size_t)s * rstride, ((unsigned long long)(unsigned)bi << 32) | (unsigned long long)__float_as_uint(bv),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(&arrived[f * CB + cb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old == S - 1) {                      // every record of (f, cb) is in memory: lane (column r31, half hi) takes s = hi, hi + 2, ...
+        asm volatile("" ::: "memory");
+        float mv = -INFINITY;
+        int mi = 0x7fffffff;
+        constexpr int SB = 8;
+        for (int s0 = hi; s0 < S; s0 += 2 * SB) {
+          unsigned long long o[SB];
+#pragma unroll
+          for (int u = 0; u < SB; u++) {
+            const int sx = s0 + 2 * u < S ? s0 + 2 * u : s0;
+            o[u] = __hip_atomic_load(rec0 + (size_t)sx * rstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int u = 0; u < SB; u++) {
+            const float v = __uint_as_float((unsigned)o[u]);
+            const int ix = (int)(o[u] >> 32);
+            if (s0 + 2 * u < S && better_nan(v, ix, mv, mi)) {
+              mv = v;
+              mi = ix;
+            }
+          }
+        }
+        const float pv = __shfl_xor(mv, 32);
+        const int pi = __shfl_xor(mi, 32);
+        if (better_nan(pv, pi, mv, mi)) {
+          mv = pv;
+          mi = pi;
+        }
+        if (lane < Lc) {
+          mi = mi < 0 ? 0 : (mi >= Nb ? Nb - 1 : mi);
+          const size_t o = (size_t)f * (Na * Ne) + cq;
+          S_max[o] = mv;
+          D_ind[o] = (int64_t)mi;
+        }
+        if (lane == 0) __hip_atomic_store(&arrived[f * CB + cb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
   FSTAMP(4);
 }
@@ -335,37 +353,6 @@ __device__ __forceinline__ Top top_merge(Top a, Top b) {
 }
 
 constexpr int FR_MAXT = 2;      // D <= 512: float4 pieces per lane of an exact dot product
-
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
-template <int N, int I = 0, typename Fn>
-__device__ __forceinline__ void unroll_blocks(Fn &&f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    unroll_blocks<N, I + 1>(f);
-  }
-}
-
-// max(m, |x0|, |x1|, |x2|, |x3|) in two v_max3_f32 (the |.| are source modifiers)
-__device__ __forceinline__ float absmax4(float m, const f32x4 x) {
-  asm("v_max3_f32 %0, |%1|, |%2|, %0\n\tv_max3_f32 %0, |%3|, |%4|, %0" : "+v"(m) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
-  return m;
-}
-
-// workgroup barrier without the vmcnt(0) of __syncthreads(): the staging waves keep global loads in flight across it
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-// 16-B slot swizzle of a 128-B stage row.  u = (row >> 1) & 7 enumerates the 8 slots over 16 consecutive rows (8 even + 8 odd
-// rows: the 16 lanes of a ds_read_b128 group hit all 64 banks once); its bits are ROTATED (u0 -> bit 2) so that the rows r and
-// r + 2 a staging wave writes in one ds_write_b64 put their 64-B plane halves into different halves of the row -- with the
-// plain value the four even rows of a write shared 16 banks (4 cycles per write instead of 2); the row's parity flips bit 2.
-__device__ __forceinline__ int frame_swz(int row) {
-  const int u = (row >> 1) & 7;
-  return (((u & 1) << 2) | (u >> 1)) ^ ((row & 1) << 2);
-}
 
 // grid ceil(F/8)*8*G workgroups of 512 threads (one per CU: ~120 KB of LDS); workgroup = (frame f, column group g).
 // Waves 0-3 (one per SIMD) issue the MFMAs: wave = (row half rh, column half ch), RW x CW accumulator tiles.  Waves 4-7 (their
@@ -901,25 +888,26 @@ namespace nafae_sim {
 
 // Any number of live columns Lh (the caller's bound) in blocks of 32, D % 32 == 0, D <= 512.  A block re-reads V (from L2 when
 // the blocks of a row block run together), so beyond a few blocks launch_frames is the better route where it applies.
-// workspace: the (max, arg-max) records [F][S][CB][32] of 8 bytes, then the column -> query map.
+// workspace: FEW_NCNT arrival counters (int; one per (frame, column block)) at its START -- a fixed place and size, whatever the
+// shape of the call, so that one workspace can serve calls of different shapes -- then the (max, arg-max) records [F][S][CB][32] of
+// 8 bytes.  The counters must be ZERO when the first call on a workspace starts; every completed call leaves them zero.
 int64_t few_workspace_bytes(int F, int Nb, int Q) {
   const int64_t CB = (Q + FEW_MAXL - 1) / FEW_MAXL;
-  return (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * CB * FEW_MAXL * 8 + (CB * FEW_MAXL + 1) * 4 + 252;
+  return (int64_t)FEW_NCNT * 4 + (int64_t)F * ((Nb + FEW_ROWS - 1) / FEW_ROWS) * CB * FEW_MAXL * 8;
 }
 
 int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
                int64_t *D_ind, void *workspace, hipStream_t st) {
   const int S = (Nb + FEW_ROWS - 1) / FEW_ROWS;
   const int CB = (Lh + FEW_MAXL - 1) / FEW_MAXL;
-  float2 *parts = reinterpret_cast<float2 *>(workspace);
-  int *qlist = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)F * S * CB * FEW_MAXL * 8);
+  if ((long)F * CB > FEW_NCNT) return NAFAE_ELIMIT;
+  int *arrived = reinterpret_cast<int *>(workspace);
+  unsigned long long *parts = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)FEW_NCNT * 4);
   const LiveLds lo = live_lds(Na);
   int dbg = 0;
   if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
-  hipLaunchKernelGGL(sim_live_kernel, dim3(F * S, CB), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, qlist,
+  hipLaunchKernelGGL(sim_live_kernel, dim3(F * S, CB), dim3(256), lo.total, st, V, W, ent_len, F, Nb, Na, Ne, D, S, Lh, parts, arrived,
                      S_max, D_ind, dbg);
-  hipLaunchKernelGGL(sim_few_merge_kernel, dim3((unsigned)(((long)F * CB * FEW_MAXL + 255) / 256)), dim3(256), 0, st, parts, qlist, F,
-                     Nb, Na * Ne, S, CB, S_max, D_ind);
   return launch_status();
 }
 

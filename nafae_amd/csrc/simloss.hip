@@ -14,8 +14,10 @@
 #include "mfma_tile.h"
 #include "../../include/nafae_hip.h"
 #include "hip_util.h"
+#include "sim_common.h"
 
 using namespace nafae;
+using nafae_sim::keep_elem;
 
 namespace {
 
@@ -1117,25 +1119,7 @@ __global__ __launch_bounds__(256) void dropout_tanh_bwd_kernel(const float *__re
   }
 }
 
-// Seeded dropout: the keep decision of element i is a pure function of (seed, i) -- Philox-style counter-based generation with
-// a 2 x 32-bit multiply-xorshift mix (not bit-compatible with torch's Philox stream, which nothing downstream depends on: the
-// reference draws its masks from the device generator, model.py:627,641) -- so no mask tensor is written by the forward or
-// read by the backward, and no torch RNG kernels run (rand + compare + cast = 3 launches and 36 MB of traffic per VisEbd call).
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16;
-  x *= 0x7feb352dU;
-  x ^= x >> 15;
-  x *= 0x846ca68bU;
-  x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t i, uint32_t thresh) {
-  const uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
-  uint32_t h = mix32(lo ^ (uint32_t)seed);
-  h = mix32(h + hi * 0x9e3779b9U + (uint32_t)(seed >> 32));
-  return h >= thresh;                 // P(drop) = thresh / 2^32
-}
-
+// (the seeded keep rule, keep_elem(seed, i, thresh), lives in sim_common.h: the plane-emitting forms in simplanes.hip share it)
 __global__ __launch_bounds__(256) void dropout_tanh_seeded_kernel(const float *__restrict__ x, uint64_t seed, uint32_t thresh,
                                                                   float scale, float *__restrict__ y, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

@@ -27,6 +27,10 @@ int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, in
                int64_t *D_ind, void *workspace, hipStream_t st);
 int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
                   float *S_max, int64_t *D_ind, hipStream_t st);
+// simplanes.hip
+int launch_planes_frames(const float *V, const float *W, const void *Vp, const void *Wp, const float *vstat, const float *wstat,
+                         int kind, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh, float *S_max,
+                         int64_t *D_ind, hipStream_t st);
 }  // namespace nafae_sim
 
 namespace {
@@ -43,7 +47,7 @@ inline int fused_route(int F, int Nb, int Na, int Ne, int D, int Qh) {
   int live_max = LIVE_MAX_DEFAULT;
   if (const char *e = nafae::experiment_env("NAFAE_SIM_LIVE_MAX")) live_max = atoi(e);
   const bool frame_ok = Nb > 64 && D % 64 == 0;      // (the frame kernel's staging loop takes the 32-k chunks two at a time)
-  if (Qh <= live_max || !frame_ok) return (Qh + 31) / 32 <= 65535 ? 1 : 0;
+  if (Qh <= live_max || !frame_ok) return ((Qh + 31) / 32 <= 65535 && (long)F * ((Qh + 31) / 32) <= FEW_NCNT) ? 1 : 0;
   return 2;
 }
 }  // namespace
@@ -75,6 +79,24 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
   }
   if (route == 2) return nafae_sim::launch_frames(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, as_stream(stream));
   return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
+}
+
+int nafae_sim_max_fwd_planes(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
+                             int max_live_cols, int kind, const void *V_planes, const float *V_stats, const void *W_planes,
+                             const float *W_stats, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
+                             void *stream) {
+  if (!V || !W || !ent_len || !S_max || !D_ind) return NAFAE_EINVAL;
+  if (Na <= 0 || F <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return NAFAE_EINVAL;
+  if (kind != NAFAE_SIMPLANES_BF16X3 && kind != NAFAE_SIMPLANES_F16) return NAFAE_EINVAL;
+  if ((long)F * Na * Ne > (1L << 31) - 256) return NAFAE_ELIMIT;
+  const int Q = Na * Ne;
+  int Qh = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
+  if (Qh < 1) Qh = 1;
+  const bool have = V_planes && V_stats && W_planes && W_stats;
+  if (have && fused_route(F, Nb, Na, Ne, D, Qh) == 2 && D % (kind == NAFAE_SIMPLANES_F16 ? 64 : 32) == 0)
+    return nafae_sim::launch_planes_frames(V, W, V_planes, W_planes, V_stats, W_stats, kind, ent_len, F, Nb, Na, Ne, D, Qh, S_max,
+                                           D_ind, as_stream(stream));
+  return nafae_sim_max_fwd_ws(V, W, ent_len, F, Nb, Na, Ne, D, max_live_cols, S_max, D_ind, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -117,13 +117,15 @@ class DropSeed:
         self.p = float(p)
 
 
-def _tanh_drop(x, drop):
+def _tanh_drop(x, drop, planes=None):
+    """tanh(dropout(x)); `planes` = a sim-planes kind: the same launch also writes the result's matrix-core planes + row
+    statistics (ops.SimPlanes, attached to the returned tensor) for the many-live-column similarity kernel."""
     if isinstance(drop, DropSeed):
-        return ops.dropout_tanh_seeded(x, drop.seed, drop.p)
+        return ops.dropout_tanh_seeded(x, drop.seed, drop.p, planes=planes)
     if drop is None:
-        return ops.dropout_tanh(x, None, 1.0)
+        return ops.dropout_tanh(x, None, 1.0, planes=planes)
     mask, scale = drop                                   # explicit (uint8 mask, scale)
-    return ops.dropout_tanh(x, mask, scale)
+    return ops.dropout_tanh(x, mask, scale, planes=planes)
 
 
 def _tanh_drop_bwd(gy, y, drop):
@@ -139,7 +141,7 @@ class _VisEbdFn(torch.autograd.Function):
     """tanh(drop(fc1(x / 100)))  -- model.py:624-629."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, drop, planes=None):
+    def forward(ctx, feats, weight, bias, drop, planes=None, sim_planes=None):
         ctx.params = (weight, bias)
         with ops.timed("vis_ebd"):
             if planes is not None:
@@ -149,7 +151,7 @@ class _VisEbdFn(torch.autograd.Function):
                 pre, _ = ops.gemm_nt_bf16(planes, wp, bias, alpha=0.01, want_f32=True, want_planes=False)
             else:
                 pre = ops.gemm_nt(feats, weight, bias, alpha=0.01)  # (x/100) W^T + b  ==  0.01 (x W^T) + b
-            y = _tanh_drop(pre, drop)
+            y = _tanh_drop(pre, drop, sim_planes)
         ctx.save_for_backward(feats, y)
         ctx.drop = drop
         return y
@@ -165,19 +167,19 @@ class _VisEbdFn(torch.autograd.Function):
             sw, sb = _grad_slot(weight), _grad_slot(bias)
             gw = ops.gemm_tn_rows(gpre, feats, rows, count, alpha=0.01, out=sw, accumulate=True)   # [D, 4096]
             gb = ops.colsum(gpre, out=sb, accumulate=True, rows=rows, count=count)
-        return None, (None if sw is not None else gw), (None if sb is not None else gb), None, None
+        return None, (None if sw is not None else gw), (None if sb is not None else gb), None, None, None
 
 
 class _WordEbdFn(torch.autograd.Function):
     """tanh(drop(bn(fc1(x))))  -- model.py:640-642."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, bn_w, bn_b, run_mean, run_var, training, momentum, eps, drop):
+    def forward(ctx, feats, weight, bias, bn_w, bn_b, run_mean, run_var, training, momentum, eps, drop, sim_planes=None):
         ctx.params = (weight, bias, bn_w, bn_b)
         with ops.timed("word_ebd"):
             lin = ops.gemm_nt(feats, weight, bias)
             bn, save_mean, save_invstd = ops.batchnorm_fwd(lin, bn_w, bn_b, run_mean, run_var, training, momentum, eps)
-            y = _tanh_drop(bn, drop)
+            y = _tanh_drop(bn, drop, sim_planes)
         ctx.save_for_backward(feats, lin, bn_w, save_mean, save_invstd, y, run_var)
         ctx.drop, ctx.training, ctx.eps = drop, training, eps
         return y
@@ -196,7 +198,7 @@ class _WordEbdFn(torch.autograd.Function):
         gw = ops.gemm_tn(glin, feats, out=sw, accumulate=sw is not None)                # [D, glove_dim]
         gb = ops.colsum(glin, out=sb, accumulate=True)
         return (None, None if sw is not None else gw, None if sb is not None else gb, None if both else g_bn_w,
-                None if both else g_bn_b, None, None, None, None, None, None)
+                None if both else g_bn_b, None, None, None, None, None, None, None)
 
 
 class _DVSAFn(torch.autograd.Function):
@@ -204,9 +206,9 @@ class _DVSAFn(torch.autograd.Function):
     pass as the loss; backward only scatters it to dV / dW."""
 
     @staticmethod
-    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, lens=None):
+    def forward(ctx, V, W, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train, lens=None, planes=False):
         with ops.timed("sim_max"):
-            S_max, D_ind = ops.sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne, lens=lens)
+            S_max, D_ind = ops.sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne, lens=lens, planes=planes)
         need = V.requires_grad or W.requires_grad
         with ops.timed("loss_tail"):
             loss_out, dS, ws = ops.loss_fwd_bwd(S_max, D_ind, V, ent_len, Na, Ns, Nb, Ne, Delta, vis_lam, train,
@@ -225,7 +227,7 @@ class _DVSAFn(torch.autograd.Function):
         gs = g_loss.detach().reshape(1).float().contiguous()
         with ops.timed("sim_bwd"):
             dV, dW = ops.sim_bwd(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, train, ws, grad_scale=gs)
-        return dV, dW, None, None, None, None, None, None, None, None, None
+        return dV, dW, None, None, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------- modules
@@ -283,9 +285,13 @@ class DVSA(nn.Module):
         if len(entities_length) != Na:
             raise ValueError("entities_length has %d entries, Na = %d" % (len(entities_length), Na))
         ent_len = torch.tensor([int(x) for x in entities_length], dtype=torch.int32, device=vis_feats.device)
+        # matrix-core planes that VisEbd / WordEbd wrote next to their outputs travel ON the tensors (the signature is the
+        # reference's); they are used by the many-live-column similarity kernel only, and only while both tensors are unmodified
+        vp, wp = ops.attached_sim_planes(vis_feats), ops.attached_sim_planes(word_feats)
+        planes = (vp, wp) if (vp is not None and wp is not None and vp.kind == wp.kind) else False
         D_ind, D_sim, margin_loss = _DVSAFn.apply(vis_feats.contiguous(), word_feats.contiguous(), ent_len, Na, Ns, Nb,
                                                   Ne, float(self.args.Delta), float(self.args.vis_lam),
-                                                  self.phase == 'train', [int(x) for x in entities_length])
+                                                  self.phase == 'train', [int(x) for x in entities_length], planes)
         return D_ind, D_sim, margin_loss
 
 
@@ -294,16 +300,18 @@ class VisEbd(nn.Module):
         super().__init__()
         self.fc1 = nn.Linear(args.vis_fc_dim, args.word_ebd_dim)
         self.drop = nn.Dropout(p=args.dropout_rate)
+        self.sim_planes = "auto"        # emit the similarity kernel's operand planes in the tanh epilogue (None: do not)
 
     def forward(self, feats):
         p = self.drop.p
         drop = DropSeed(p) if (self.training and p > 0) else None
+        sp = ops.SIM_PLANES_DEFAULT if self.sim_planes == "auto" else self.sim_planes
         # the detector hands fc7 over together with its split-bf16 planes (an attribute on the very tensor it returned)
         planes = getattr(feats, "_nafae_planes", None)
         if planes is not None and (tuple(planes.shape) != tuple(feats.shape) or not feats.is_contiguous()
                                    or getattr(feats, "_nafae_planes_version", None) != feats._version):
             planes = None
-        return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, drop, planes)
+        return _VisEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, drop, planes, sp)
 
 
 class WordEbd(nn.Module):
@@ -313,15 +321,17 @@ class WordEbd(nn.Module):
         self.drop = nn.Dropout(p=args.dropout_rate)
         self.bn = nn.BatchNorm1d(args.word_ebd_dim)
         self.mask_generator = None      # set by train_step_exact: replicated WordEbd must draw the same mask on every rank
+        self.sim_planes = "auto"        # as VisEbd.sim_planes
 
     def forward(self, feats):
         p = self.drop.p
         drop = DropSeed(p, self.mask_generator) if (self.training and p > 0) else None
         if self.training:
             self.bn.num_batches_tracked += 1
+        sp = ops.SIM_PLANES_DEFAULT if self.sim_planes == "auto" else self.sim_planes
         return _WordEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, self.bn.weight, self.bn.bias,
                                 self.bn.running_mean, self.bn.running_var, self.training, self.bn.momentum,
-                                self.bn.eps, drop)
+                                self.bn.eps, drop, sp)
 
 
 class GroundModel(nn.Module):

@@ -499,11 +499,12 @@ _sim_ws = {}
 
 
 def _sim_workspace(nbytes, device):
-    """Scratch of the two-kernel similarity (top-2 partials per 32-row block), one buffer per (device, stream)."""
+    """Scratch of the live-column similarity (arrival counters + per-row-block records), one buffer per (device, stream)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _sim_ws.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+        # zero-filled ONCE: the live-column kernel keeps its arrival counters (the first 1 MB) at zero between calls
+        t = torch.zeros(max(int(nbytes), 16), device=device, dtype=torch.uint8)
         _sim_ws[key] = t
     return t
 
@@ -512,11 +513,65 @@ def _live_cols(lens, Ne):
     return None if lens is None else int(sum(min(max(int(l), 0), Ne) for l in lens))
 
 
-def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=None, exact_fp32=False):
+SIM_PLANES_KINDS = {"bf16x3": 0, "f16": 1}       # include/nafae_hip.h: NAFAE_SIMPLANES_BF16X3 / _F16
+# what the embedding modules emit next to their fp32 output (model.VisEbd / WordEbd) and what `planes=True` means below
+SIM_PLANES_DEFAULT = "f16"
+
+
+class SimPlanes:
+    """Matrix-core planes of an fp32 matrix [rows, D] for the many-live-column similarity kernel (simplanes.hip): `planes` in the
+    layout the kernel stages by LDS-DMA (kind 'bf16x3': [rows, D/32, 2, 32] bf16 = hi | lo per 32 k; 'f16': [rows, D] fp16) and
+    `stats` f32 [rows, 2] = (max |x|, l2 norm) per row.  They only FILTER; results stay exact fp32 dot products of the fp32 matrix."""
+    __slots__ = ("kind", "planes", "stats", "rows", "D", "version")
+
+    def __init__(self, kind, planes, stats, rows, D, version=None):
+        self.kind, self.planes, self.stats, self.rows, self.D, self.version = kind, planes, stats, rows, D, version
+
+
+def _alloc_sim_planes(rows, D, kind, device):
+    if kind not in SIM_PLANES_KINDS:
+        raise NafaeOpError("sim planes kind must be one of %s" % sorted(SIM_PLANES_KINDS))
+    if D % (64 if kind == "f16" else 32):
+        raise NafaeOpError("sim planes (%s) need D %% %d == 0" % (kind, 64 if kind == "f16" else 32))
+    planes = torch.empty(rows, D * (1 if kind == "f16" else 2), device=device,
+                         dtype=torch.float16 if kind == "f16" else torch.bfloat16)
+    stats = torch.empty(rows, 2, device=device, dtype=torch.float32)
+    return SimPlanes(kind, planes, stats, rows, D)
+
+
+def sim_planes(X, kind=None):
+    """Stand-alone pre-pass: the planes + row statistics of X [rows, D] (nafae_sim_planes)."""
+    _chk(X)
+    kind = kind or SIM_PLANES_DEFAULT
+    rows, D = X.shape
+    P = _alloc_sim_planes(rows, D, kind, X.device)
+    _rc(_lib.lib().nafae_sim_planes(_p(X), rows, D, SIM_PLANES_KINDS[kind], _p(P.planes), _p(P.stats), _stream()), "nafae_sim_planes")
+    P.version = X._version
+    return P
+
+
+def attach_sim_planes(X, P):
+    """Carry the planes on the tensor they describe (the B1 signature DVSA(vis_feats, word_feats, entities_length) does not change;
+    the planes are dropped as soon as the tensor is modified in place: its version counter no longer matches)."""
+    P.version = X._version
+    X._nafae_simplanes = P
+    return X
+
+
+def attached_sim_planes(X):
+    P = getattr(X, "_nafae_simplanes", None)
+    if P is None or P.version != X._version or (P.rows, P.D) != tuple(X.shape) or not X.is_contiguous():
+        return None
+    return P
+
+
+def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=None, exact_fp32=False, planes=None):
     """Sim + max for F whole frames (V [F*Nb, D]) of a batch with Na segments against all Q = Na*Ne query rows W
     -> S_max f32 [F, Q], D_ind int64 [F, Q].  On one GPU F = Na*Ns; in the frame-sharded multi-GPU mode F is this rank's share.
     `lens`: the host-side entity_length list (what DVSA.forward is called with), if available: it sizes the launch for the
-    live query slots without a device read-back.  exact_fp32=True selects the first-generation exact-fp32 MFMA kernel."""
+    live query slots without a device read-back.  exact_fp32=True selects the first-generation exact-fp32 MFMA kernel.
+    `planes`: None -> the planes attached to V and W by their producer (attach_sim_planes), if both carry the same kind;
+    (SimPlanes of V, SimPlanes of W); a kind name / True -> computed here by the stand-alone pre-pass; False -> never."""
     _chk(V); _chk(W); _chk(ent_len, torch.int32)
     D = V.shape[1]
     Q = Na * Ne
@@ -536,15 +591,29 @@ def sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=None, exact_fp32=False):
         raise NafaeOpError("nafae_sim_max_workspace_bytes failed")
     ws = _sim_workspace(nws, V.device)
     live = _live_cols(lens, Ne)
+    if planes is None:
+        vp, wp = attached_sim_planes(V), attached_sim_planes(W)
+        planes = (vp, wp) if (vp is not None and wp is not None and vp.kind == wp.kind) else False
+    elif planes is True or isinstance(planes, str):
+        kind = SIM_PLANES_DEFAULT if planes is True else planes
+        planes = (sim_planes(V, kind), sim_planes(W, kind)) if D % (64 if kind == "f16" else 32) == 0 else False
+    if planes:
+        vp, wp = planes
+        if vp.kind != wp.kind or (vp.rows, vp.D) != tuple(V.shape) or (wp.rows, wp.D) != tuple(W.shape):
+            raise NafaeOpError("sim_max_fwd_frames: planes do not describe V / W")
+        _rc(L.nafae_sim_max_fwd_planes(_p(V), _p(W), _p(ent_len), F, Nb, Na, Ne, D, -1 if live is None else live,
+                                       SIM_PLANES_KINDS[vp.kind], _p(vp.planes), _p(vp.stats), _p(wp.planes), _p(wp.stats),
+                                       _p(S_max), _p(D_ind), _p(ws), ws.numel(), _stream()), "nafae_sim_max_fwd_planes")
+        return S_max, D_ind
     _rc(L.nafae_sim_max_fwd_ws(_p(V), _p(W), _p(ent_len), F, Nb, Na, Ne, D, -1 if live is None else live, _p(S_max),
                                _p(D_ind), _p(ws), ws.numel(), _stream()), "nafae_sim_max_fwd_ws")
     return S_max, D_ind
 
 
-def sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne, lens=None, exact_fp32=False):
+def sim_max_fwd(V, W, ent_len, Na, Ns, Nb, Ne, lens=None, exact_fp32=False, planes=None):
     if V.shape[0] != Na * Ns * Nb:
         raise NafaeOpError("sim_max_fwd: shape mismatch V %s (Na,Ns,Nb,Ne)=(%d,%d,%d,%d)" % (tuple(V.shape), Na, Ns, Nb, Ne))
-    return sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=lens, exact_fp32=exact_fp32)
+    return sim_max_fwd_frames(V, W, ent_len, Nb, Na, Ne, lens=lens, exact_fp32=exact_fp32, planes=planes)
 
 
 def sim_bwd_frames(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, cluster_rows, workspace, pre_scale=None, grad_scale=None):
@@ -596,9 +665,17 @@ def sim_bwd(dS, D_ind, V, W, ent_len, Na, Ns, Nb, Ne, train, workspace, pre_scal
 
 
 # ------------------------------------------------------------------------------------------------ embedding tails
-def dropout_tanh(x, mask=None, scale=1.0):
+def dropout_tanh(x, mask=None, scale=1.0, planes=None):
+    """y = tanh(x * mask * scale).  planes = a sim-planes kind: ALSO emit y's matrix-core planes + row statistics in the same pass
+    (x [rows, D]) and attach them to y (attach_sim_planes); y itself is bit-identical either way."""
     _chk(x); _chk(mask, torch.uint8)
     y = torch.empty_like(x)
+    if planes and x.dim() == 2 and x.shape[1] % (64 if planes == "f16" else 32) == 0:
+        rows, D = x.shape
+        P = _alloc_sim_planes(rows, D, planes, x.device)
+        _rc(_lib.lib().nafae_dropout_tanh_planes(_p(x), _p(mask), float(scale), _p(y), rows, D, SIM_PLANES_KINDS[planes],
+                                                 _p(P.planes), _p(P.stats), _stream()), "nafae_dropout_tanh_planes")
+        return attach_sim_planes(y, P)
     _rc(_lib.lib().nafae_dropout_tanh(_p(x), _p(mask), float(scale), _p(y), x.numel(), _stream()), "nafae_dropout_tanh")
     return y
 
@@ -611,10 +688,18 @@ def dropout_tanh_bwd(g_out, y, mask=None, scale=1.0):
     return g_in
 
 
-def dropout_tanh_seeded(x, seed, p):
-    """tanh(dropout_p(x)) with the keep mask generated in the kernel from (seed, element index); no mask tensor."""
+def dropout_tanh_seeded(x, seed, p, planes=None):
+    """tanh(dropout_p(x)) with the keep mask generated in the kernel from (seed, element index); no mask tensor.
+    planes: as in dropout_tanh."""
     _chk(x)
     y = torch.empty_like(x)
+    if planes and x.dim() == 2 and x.shape[1] % (64 if planes == "f16" else 32) == 0:
+        rows, D = x.shape
+        P = _alloc_sim_planes(rows, D, planes, x.device)
+        _rc(_lib.lib().nafae_dropout_tanh_seeded_planes(_p(x), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), _p(y), rows, D,
+                                                        SIM_PLANES_KINDS[planes], _p(P.planes), _p(P.stats), _stream()),
+            "nafae_dropout_tanh_seeded_planes")
+        return attach_sim_planes(y, P)
     _rc(_lib.lib().nafae_dropout_tanh_seeded(_p(x), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), _p(y), x.numel(), _stream()),
         "nafae_dropout_tanh_seeded")
     return y

@@ -23,9 +23,24 @@ def _ref(V, W, lens, Na, Nb, Ne):
     return m, i, gap, masked.expand(m.shape[0], Q)
 
 
+PLANES = {"kind": False}
+
+
+@pytest.fixture(autouse=True, params=[False, "bf16x3", "f16"], ids=["fp32-operands", "planes-bf16x3", "planes-f16"])
+def plane_kind(request):
+    """Every test of this file runs three times: on the fp32 operands alone (round 3's routes), and with the operand planes of
+    round 4 (simplanes.hip: the many-live-column shapes then take sim_planes_kernel with a bf16x3 / a one-product fp16 filter; the
+    other shapes ignore the planes) -- the contract (fp32 dot products, torch.max's tie / NaN rules) is the same."""
+    PLANES["kind"] = request.param
+    yield request.param
+    PLANES["kind"] = False
+
+
 def _run(V, W, lens_dev, Na, Ns, Nb, Ne, **kw):
     from nafae_amd import ops
     lt = torch.tensor(lens_dev, dtype=torch.int32, device="cuda")
+    if "exact_fp32" not in kw:
+        kw.setdefault("planes", PLANES["kind"])
     return ops.sim_max_fwd(V.cuda(), W.cuda(), lt, Na, Ns, Nb, Ne, **kw)
 
 
@@ -167,9 +182,9 @@ def test_sim_max_v2_frames_equals_whole_batch():
     V = torch.tanh(syn.randn(3, "Vf", (Na * Ns * Nb, D))).cuda()
     W = torch.tanh(syn.randn(3, "Wf", (Na * Ne, D))).cuda()
     lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    S, Di = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)
+    S, Di = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens, planes=PLANES["kind"])
     for lo, hi in ((0, 4), (4, 16), (15, 16)):
-        Sl, Dl = ops.sim_max_fwd_frames(V[lo * Nb:hi * Nb].contiguous(), W, lt, Nb, Na, Ne, lens=lens)
+        Sl, Dl = ops.sim_max_fwd_frames(V[lo * Nb:hi * Nb].contiguous(), W, lt, Nb, Na, Ne, lens=lens, planes=PLANES["kind"])
         # (the launch plan -- how K is split over waves -- depends on the number of frames, so the fp32 sums may differ in
         # the last bit between the two calls; the indices may not)
         assert torch.allclose(Sl, S[lo:hi], rtol=0, atol=2e-6 * float(S.abs().max())) and torch.equal(Dl, Di[lo:hi])
@@ -183,20 +198,29 @@ def test_sim_max_v2_is_deterministic_and_graph_capturable():
     V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, D, seed=2)
     V, W = V.cuda(), W.cuda()
     lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    pk = PLANES["kind"]
+    if pk:        # the planes as the embedding modules hand them over: attached to the tensors, produced outside the graph
+        ops.attach_sim_planes(V, ops.sim_planes(V, pk))
+        ops.attach_sim_planes(W, ops.sim_planes(W, pk))
     a = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)
-    b = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne)               # no hint: sized for all Q columns, another K split
+    b = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne)               # no hint: sized for all Q columns, another K split / route
     assert torch.allclose(a[0], b[0], rtol=0, atol=2e-6 * float(a[0].abs().max())) and torch.equal(a[1], b[1])
     a2 = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)   # same plan: bit-identical run to run
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+    b2 = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne)              # (with planes this is sim_planes_kernel: LDS list order varies,
+    assert torch.equal(b[0], b2[0]) and torch.equal(b[1], b2[1])    # the decision must not)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)    # allocate the stream's workspace outside the capture
+        ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne)
         st.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
             c = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne, lens=lens)
+            d = ops.sim_max_fwd(V, W, lt, Na, Ns, Nb, Ne)
         g.replay()
         st.synchronize()
+    assert torch.equal(b[0], d[0]) and torch.equal(b[1], d[1])
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
 
 
@@ -247,9 +271,16 @@ def test_sim_max_too_small_live_hint_is_loud(Ne, lens, hint):
     Di = torch.empty(F, Q, device="cuda", dtype=torch.int64)
     L = _lib.lib()
     nws = int(L.nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D))
-    ws = torch.empty(max(nws, 16), device="cuda", dtype=torch.uint8)
-    rc = L.nafae_sim_max_fwd_ws(ops._p(V), ops._p(W), ops._p(lt), F, Nb, Na, Ne, D, hint, ops._p(S), ops._p(Di), ops._p(ws), ws.numel(),
-                                ops._stream())
+    ws = torch.zeros(max(nws, 16), device="cuda", dtype=torch.uint8)      # (zeroed once: the arrival counters of the one-launch merge)
+    pk = PLANES["kind"]
+    if pk:
+        vp, wp = ops.sim_planes(V, pk), ops.sim_planes(W, pk)
+        rc = L.nafae_sim_max_fwd_planes(ops._p(V), ops._p(W), ops._p(lt), F, Nb, Na, Ne, D, hint, ops.SIM_PLANES_KINDS[pk],
+                                        ops._p(vp.planes), ops._p(vp.stats), ops._p(wp.planes), ops._p(wp.stats), ops._p(S), ops._p(Di),
+                                        ops._p(ws), ws.numel(), ops._stream())
+    else:
+        rc = L.nafae_sim_max_fwd_ws(ops._p(V), ops._p(W), ops._p(lt), F, Nb, Na, Ne, D, hint, ops._p(S), ops._p(Di), ops._p(ws),
+                                    ws.numel(), ops._stream())
     assert rc == 0
     m, i, gap, masked = _ref(V.cpu(), W.cpu(), lens, Na, Nb, Ne)
     S, Di = S.cpu().double(), Di.cpu()
