@@ -93,7 +93,8 @@ int nafae_sim_max_fwd_planes(const float *V, const float *W, const int32_t *ent_
   int Qh = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
   if (Qh < 1) Qh = 1;
   const bool have = V_planes && V_stats && W_planes && W_stats;
-  if (have && fused_route(F, Nb, Na, Ne, D, Qh) == 2 && D % (kind == NAFAE_SIMPLANES_F16 ? 64 : 32) == 0)
+  // (the kernel takes the 128-byte lines of a row two at a time: D % 128 == 0 for fp16 planes, D % 64 == 0 for bf16x3 ones)
+  if (have && fused_route(F, Nb, Na, Ne, D, Qh) == 2 && D % (kind == NAFAE_SIMPLANES_F16 ? 128 : 64) == 0)
     return nafae_sim::launch_planes_frames(V, W, V_planes, W_planes, V_stats, W_stats, kind, ent_len, F, Nb, Na, Ne, D, Qh, S_max,
                                            D_ind, as_stream(stream));
   return nafae_sim_max_fwd_ws(V, W, ent_len, F, Nb, Na, Ne, D, max_live_cols, S_max, D_ind, workspace, workspace_bytes, stream);

@@ -123,7 +123,9 @@ constexpr int FR_MAXT = 2;      // D <= 512: float4 pieces per lane of an exact 
 constexpr int PL_BATCH = 8;     // exact dot products in flight per wave
 
 // one accumulator element against the column's threshold: cnt += hit, ids = hit ? (ids << 8 | ID) : ids.  Four vector
-// instructions, branch-free (as a ternary hipcc builds exec-masked branches around 160 of these).
+// instructions, branch-free (as a ternary hipcc builds exec-masked branches around 160 of these).  Measured and NOT adopted: a
+// scalar skip (v_cmp; s_cbranch_vccz over the other three -- four elements in five have no hit in any lane): the branch waits
+// for the compare's VCC every time, the scan took 5.8 us instead of 3.3 at C5.
 template <int ID>
 __device__ __forceinline__ void cand_push(float v, float thr, int &cnt, unsigned &ids) {
   unsigned tmp;
@@ -148,20 +150,27 @@ __device__ __forceinline__ void cand_push(float v, float thr, int &cnt, unsigned
   }
 }
 
+// v = OFF < lim ? v : ninf (a row beyond the frame), two vector instructions
+template <int OFF>
+__device__ __forceinline__ void mask_row(float &v, int lim, float ninf) {
+  asm volatile("v_cmp_gt_i32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %3, %0, vcc" : "+v"(v) : "v"(lim), "n"(OFF), "v"(ninf) : "vcc");
+}
+
 struct PlanesLds {
-  int qmap, wst, cmax, cflag, ccnt, clist, vst, prefix, total;
+  int qmap, wst, wam, cmax, cflag, ccnt, clist, vst, prefix, total;
 };
 template <int RT, int GC>
 __host__ __device__ inline PlanesLds planes_lds(int Na) {
   PlanesLds o;
   int p = 2 * (RT + GC) * 128;                 // [2 stages][(RT + GC) rows][128 B]; after the k-loops: the exact phase's lists
   o.qmap = p;   p += GC * 4;                   // live column -> query row (-1: beyond the live count)
-  o.wst = p;    p += GC * 4;                   // the column's W statistic
+  o.wst = p;    p += GC * 4;                   // the column's W statistic the margin uses
+  o.wam = p;    p += GC * 4;                   // the column's max |w| (fp16 planes: range check)
   o.cmax = p;   p += 2 * GC * 4;               // [row half][column] filter maximum of the current super-tile
   o.cflag = p;  p += GC * 4;                   // bit 0: NaN / Inf seen, bit 1: more than PL_LANEC hits in one lane
   o.ccnt = p;   p += GC * 4;                   // listed candidates
   o.clist = p;  p += GC * PL_MAXC * 4;         // their rows
-  o.vst = p;    p += 16;                       // the frame's V statistic (max over its rows)
+  o.vst = p;    p += 16;                       // the frame's V statistics (max over its rows): [0] the margin's, [1] max |v|
   o.prefix = p; p += ((Na + 1) * 4 + 15) & ~15;
   o.total = p;
   return o;
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
   const PlanesLds lo = planes_lds<RT, GC>(Na);
   int *qmap = reinterpret_cast<int *>(smem + lo.qmap);
   float *wst = reinterpret_cast<float *>(smem + lo.wst);
+  float *wam = reinterpret_cast<float *>(smem + lo.wam);
   float *cmax = reinterpret_cast<float *>(smem + lo.cmax);
   int *cflag = reinterpret_cast<int *>(smem + lo.cflag);
   int *ccnt = reinterpret_cast<int *>(smem + lo.ccnt);
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
     cflag[tid] = 0;
     ccnt[tid] = 0;
   }
-  if (tid == 0) vsti[0] = 0;
+  if (tid < 2) vsti[tid] = 0;
   __syncthreads();
   const int Ql = prefix[Na];
   if (g == 0) {      // masked slots of this frame: (0, 0) (model.py:551); live slots beyond the launch (bound too small): NaN
@@ -230,23 +240,31 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
     }
     qmap[tid] = q;
     wst[tid] = q >= 0 ? wstat[(size_t)q * 2 + ST] : 0.f;
+    wam[tid] = q >= 0 ? wstat[(size_t)q * 2] : 0.f;
   }
   {   // the frame's V statistic: statistics are >= 0 (or NaN, whose bit pattern compares above every number: the margin then is
       // NaN and every column takes the slow path), so an integer max over the bit patterns is the float max
-    int m = 0;
+    int m = 0, m2 = 0;
     for (int r = tid; r < Nb; r += 512) {
-      const int b = __float_as_int(vstat[((size_t)f * Nb + r) * 2 + ST]) & 0x7fffffff;
+      const float2 st2 = *reinterpret_cast<const float2 *>(vstat + ((size_t)f * Nb + r) * 2);
+      const int b = __float_as_int(ST ? st2.y : st2.x) & 0x7fffffff, b2 = __float_as_int(st2.x) & 0x7fffffff;
       m = b > m ? b : m;
+      m2 = b2 > m2 ? b2 : m2;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const int y = __shfl_xor(m, o);
+      const int y = __shfl_xor(m, o), y2 = __shfl_xor(m2, o);
       m = y > m ? y : m;
+      m2 = y2 > m2 ? y2 : m2;
     }
-    if (lane == 0) atomicMax(vsti, m);
+    if (lane == 0) {
+      atomicMax(vsti, m);
+      atomicMax(vsti + 1, m2);
+    }
   }
   __syncthreads();
-  const float vst = __int_as_float(vsti[0]);
+  const float vst = __int_as_float(vsti[0]), vam = __int_as_float(vsti[1]);
+  (void)vam;
   const float *Vf = V + (size_t)f * Nb * D;
   const unsigned char *Vpf = Vp + (size_t)f * Nb * rowbytes;
   const int nsuper = (Nb + RT - 1) / RT;
@@ -254,6 +272,10 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
 
   if (wave >= 4) {
     // ================================================================ staging waves: LDS-DMA only
+    // (Measured against register staging -- global_load_dwordx4 -> VGPRs -> ds_write_b128, two chunks of loads in flight, no
+    // conversion: the k-loop at C5 took 9.9 us instead of 8.5 (fp16) and 23.3 instead of 21.7 (bf16x3): the 57 KB of ds_write_b128
+    // per chunk compete with the MFMA waves' fragment reads for the LDS, and the loads' latency was not what bounded the DMA
+    // form.  With the MFMAs compiled out the DMA loop alone runs at 0.7 us per chunk = 82 GB/s into one CU.)
     const int sw = wave - 4;
     const int lr8 = lane >> 3, ls = lane & 7;
     constexpr int NV = 2 * RW, NW = 2 * CW;    // DMAs per wave and chunk: instruction n = j * 4 + sw covers stage rows [8n, 8n + 8)
@@ -264,14 +286,13 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
       const int q = qmap[sc];
       woff[j] = (unsigned)(q >= 0 ? q : 0) * (unsigned)rowbytes + (unsigned)((ls ^ frame_swz(sc)) << 4);
     }
-    int gt = 0;
     for (int rt = 0; rt < nsuper; rt++) {
       unsigned voff[NV];
 #pragma unroll
       for (int j = 0; j < NV; j++) {
         const int sr = (j * 4 + sw) * 8 + lr8;
         int row = rt * RT + sr;
-        row = row < Nb ? row : Nb - 1;         // (a row beyond the frame re-reads its last row; masked in the scan)
+        row = row < Nb ? row : Nb - 1;
         voff[j] = (unsigned)row * (unsigned)rowbytes + (unsigned)((ls ^ frame_swz(sr)) << 4);
       }
       auto issue = [&](int ci, int stage) {
@@ -282,16 +303,15 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < NW; j++) lds_dma16(wb, woff[j], st + RT * 128 + j * 4096);
       };
-      issue(0, gt & 1);
-      if (rt > 0) lds_barrier();               // (X1 of the previous super-tile: the MFMA waves exchange their column maxima)
+      issue(0, 0);
+      if (rt > 0) lds_barrier();               // (X1 of the previous super-tile)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();                           // chunk 0 has landed
       PSTAMP(1);
       for (int ci = 0; ci < nch; ci++) {
-        if (ci + 1 < nch) issue(ci + 1, (gt + 1) & 1);
+        if (ci + 1 < nch) issue(ci + 1, (ci + 1) & 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-        gt++;
       }
       PSTAMP(2);
     }
@@ -316,7 +336,6 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
     float bmr[CW];                             // running column maximum of the filter values over the super-tiles
 #pragma unroll
     for (int cb = 0; cb < CW; cb++) bmr[cb] = -INFINITY;
-    int gt = 0;
     for (int rt = 0; rt < nsuper; rt++) {
       f32x16 acc[RW][CW];
 #pragma unroll
@@ -328,11 +347,10 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
       lds_barrier();                           // chunk 0 is in its stage
       PSTAMP(1);
       for (int ci = 0; ci < nch; ci++) {
-        const unsigned char *st = smem + (gt & 1) * STAGE;
+        const unsigned char *st = smem + (ci & 1) * STAGE;      // (nch is even: every super-tile starts in stage 0)
 #ifdef NAFAE_EXPERIMENTS
         if (dbg & 2) {                         // timing experiment: no fragment reads, no MFMAs
           lds_barrier();
-          gt++;
           continue;
         }
 #endif
@@ -372,27 +390,50 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
           }
         }
         lds_barrier();
-        gt++;
       }
       PSTAMP(2);
       // ---- pass 1: this lane's column (cb) holds 16 rows per 32-row block, element (rb, r) = row wbase + 32 rb + (r & 3) +
-      // 8 (r >> 2) + 4 h.  Column maximum of the filter values; a NaN / Inf anywhere makes nanacc NaN (x * 0).  Rows beyond the
-      // frame are staged as copies of its last row: they cannot raise the maximum, and pass 2 drops them by their row number.
+      // 8 (r >> 2) + 4 h.  Rows beyond the frame were staged as copies of its last row: where a wave's blocks reach beyond the
+      // frame (uniform: the last super-tile's second row half) their elements become -inf first -- two instructions per element
+      // through inline asm (as C++ hipcc hoists the 160 row-validity compares into SGPR masks and spills them).  Left in, a last row
+      // that wins a column would be listed once per copy and overflow the lane's list: the slow path for a third of the workgroups
+      // (measured: +30 us).
       const int wbase = rt * RT + rh * RW * 32;
+      if (wbase + RW * 32 > Nb) {
+        const float ninf = -INFINITY;
+        unroll_blocks<RW>([&](auto rb_tag) {
+          constexpr int rb = decltype(rb_tag)::value;
+          const int lim = Nb - (wbase + rb * 32) - 4 * h;      // element r is a real row iff (r & 3) + 8 (r >> 2) < lim
+          unroll_blocks<16>([&](auto r_tag) {
+            constexpr int r = decltype(r_tag)::value;
+#pragma unroll
+            for (int cb = 0; cb < CW; cb++) {
+              float v = acc[rb][cb][r];
+              mask_row<(r & 3) + 8 * (r >> 2)>(v, lim, ninf);
+              acc[rb][cb][r] = v;
+            }
+          });
+        });
+      }
+      // Column maximum of the filter values, and their SUM: NaN as soon as one element is NaN (or +Inf meets a masked -inf), +Inf
+      // when one is +Inf -- the column then takes the exact slow path (so does a finite sum that overflows).  A -Inf filter value
+      // alone is not flagged here (the masked rows are -inf): among real rows it only arises from an fp16 plane that overflowed,
+      // which pass 2 catches from the operands' max |x| statistics.  (The order mask -> one loop matters to hipcc: with the NaN
+      // test taken before the masking, or the sum as v_pk_add_f32 pairs, it spilled 380 registers.)
 #pragma unroll
       for (int cb = 0; cb < CW; cb++) {
-        float m = -INFINITY, nanacc = 0.f;
+        float m = -INFINITY, sum = 0.f;
 #pragma unroll
         for (int rb = 0; rb < RW; rb++)
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const float v = acc[rb][cb][r];
-            nanacc = fmaf(v, 0.f, nanacc);
+            sum += v;
             m = fmaxf(m, v);
           }
         m = fmaxf(m, __shfl_xor(m, 32));
         const int c = (ch * CW + cb) * 32 + lr;
-        if (nanacc != nanacc) atomicOr(&cflag[c], 1);
+        if (sum != sum || sum == INFINITY) atomicOr(&cflag[c], 1);
         if (h == 0) cmax[rh * GC + c] = m;
       }
       lds_barrier();                           // X1: both row halves have written their maxima
@@ -406,6 +447,8 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
         if (KIND == KIND_F16) {
           const float nw = wst[c];
           margin = (2.0e-3f + 2.4e-7f * (float)D) * vst * nw + 1.2e-7f * sqrtf((float)D) * (vst + nw);
+          // an operand beyond the fp16 range is +-Inf in its plane: nothing the filter says about this column can be trusted
+          if (!(vam <= 65504.f) || !(wam[c] <= 65504.f)) margin = INFINITY;
         } else {
           margin = 6.103515625e-05f * (float)D * vst * wst[c] + 4.8828125e-04f * fabsf(bm);
         }
@@ -448,75 +491,59 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
     }
   }
 
-  // ---- exact fp32: flat work list of (column, row) items
+  // ---- exact fp32.  Work items (column, row): item c < GC is column c's FIRST listed row (a fixed place: no scan), the other
+  // listed rows (about one column in nine has a second one with the fp16 filter) are appended behind them.
   __syncthreads();                             // lists complete; the stages are free: reuse them as scratch
-  int *coff = reinterpret_cast<int *>(smem);                          // [GC + 1] first item of each column
-  int *itemc = coff + GC + 4;                                          // [GC * PL_MAXC]
-  int *itemr = itemc + GC * PL_MAXC;                                   // [GC * PL_MAXC]
-  float *res = reinterpret_cast<float *>(itemr + GC * PL_MAXC);        // [GC * PL_MAXC]
-  int *nslow = reinterpret_cast<int *>(res + GC * PL_MAXC);            // [1] (+ pad)
-  int *slowc = nslow + 2;                                              // [GC]
-  float2 *sbest = reinterpret_cast<float2 *>(slowc + GC);              // [8] (8-byte aligned: all counts above are even)
-  static_assert((GC + 4) % 2 == 0 && (GC * PL_MAXC) % 2 == 0, "sbest alignment");
-  if (tid == 0) nslow[0] = 0;
-  int my_n = 0;
-  bool my_slow = false;
-  if (tid < 64) {                              // wave 0: exclusive scan of the list lengths, GC / 64 columns per lane
-    constexpr int PER = GC / 64;
-    int n[PER], s = 0;
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-      const int c = lane * PER + u;
-      const int cn = ccnt[c];
-      const bool dead = qmap[c] < 0;
-      const bool slow = !dead && (cflag[c] != 0 || cn > PL_MAXC || cn == 0);
-      n[u] = (dead || slow) ? 0 : cn;
-      cflag[c] = slow ? 1 : 0;                 // (from here on: 1 = slow list)
-      s += n[u];
-    }
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(incl, o);
-      if (lane >= o) incl += y;
-    }
-    int off = incl - s;
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-      coff[lane * PER + u] = off;
-      off += n[u];
-    }
-    if (lane == 63) coff[GC] = incl;
+  int *itemc = reinterpret_cast<int *>(smem);                          // [GC + GC * PL_MAXC] column of an item (-1: none)
+  int *itemr = itemc + GC + GC * PL_MAXC;                              // ... its row
+  float *res = reinterpret_cast<float *>(itemr + GC + GC * PL_MAXC);   // ... its exact score
+  int *nextra = reinterpret_cast<int *>(res + GC + GC * PL_MAXC);      // [1] items behind the first GC
+  int *nslow = nextra + 1;                                             // [1]
+  int *slowc = nslow + 1;                                              // [GC]
+  float2 *sbest = reinterpret_cast<float2 *>(slowc + GC);              // [8] (8-byte aligned: the counts above sum to an even number)
+  static_assert((3 * (GC + GC * PL_MAXC) + 2 + GC) % 2 == 0, "sbest alignment");
+  if (tid == 0) {
+    nextra[0] = 0;
+    nslow[0] = 0;
   }
   __syncthreads();
+  int my_n = 0;
   if (tid < GC) {
     const int c = tid;
-    my_n = coff[c + 1] - coff[c];
-    my_slow = cflag[c] != 0;
-    for (int k = 0; k < my_n; k++) {
-      itemc[coff[c] + k] = c;
-      itemr[coff[c] + k] = clist[c * PL_MAXC + k];
+    const int cn = ccnt[c];
+    const bool dead = qmap[c] < 0;
+    const bool slow = !dead && (cflag[c] != 0 || cn > PL_MAXC || cn == 0);
+    my_n = (dead || slow) ? 0 : cn;
+    itemc[c] = my_n > 0 ? c : -1;
+    itemr[c] = my_n > 0 ? clist[c * PL_MAXC] : 0;
+    if (my_n > 1) {
+      const int o = GC + atomicAdd(nextra, my_n - 1);
+      for (int k = 1; k < my_n; k++) {
+        itemc[o + k - 1] = c;
+        itemr[o + k - 1] = clist[c * PL_MAXC + k];
+      }
     }
-    if (my_slow) slowc[atomicAdd(nslow, 1)] = c;
+    if (slow) slowc[atomicAdd(nslow, 1)] = c;
   }
   __syncthreads();
   PSTAMP(4);
   {
-    const int total = coff[GC];
-    const int per = (total + 7) >> 3;          // consecutive items per wave
-    const int i_end = (wave + 1) * per < total ? (wave + 1) * per : total;
-    for (int i0 = wave * per; i0 < i_end; i0 += PL_BATCH) {
+    const int total = GC + nextra[0];
+    // wave w: the first items of its GC / 8 columns, then every eighth batch of the appended ones
+    auto batch = [&](int i0, int i_end) {
       f32x4 wf[PL_BATCH][FR_MAXT], xf[PL_BATCH][FR_MAXT];
+      int ic[PL_BATCH];
 #pragma unroll
       for (int u = 0; u < PL_BATCH; u++) {
         const int i = i0 + u < i_end ? i0 + u : i_end - 1;
-        const int q = qmap[itemc[i]];
-        const int r = itemr[i];
+        ic[u] = i0 + u < i_end ? itemc[i] : -1;
+        const int q = qmap[ic[u] >= 0 ? ic[u] : 0];
+        const int r = ic[u] >= 0 ? itemr[i] : 0;
 #pragma unroll
         for (int k = 0; k < FR_MAXT; k++) {
           const int d = lane * 4 + 256 * k;
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          wf[u][k] = d < D ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)q * D + d) : z;
+          wf[u][k] = d < D ? *reinterpret_cast<const f32x4 *>(Wm + (size_t)(q >= 0 ? q : 0) * D + d) : z;
           xf[u][k] = d < D ? *reinterpret_cast<const f32x4 *>(Vf + (size_t)r * D + d) : z;
         }
       }
@@ -531,23 +558,30 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
           a = fmaf(xf[u][k][3], wf[u][k][3], a);
         }
         a = wave_sum(a);
-        if (lane == 0 && i0 + u < i_end) res[i0 + u] = a;
+        if (lane == 0 && ic[u] >= 0) res[i0 + u] = a;
       }
-    }
+    };
+    constexpr int CPW = GC / 8;
+    for (int i0 = wave * CPW; i0 < (wave + 1) * CPW; i0 += PL_BATCH) batch(i0, (wave + 1) * CPW);
+    for (int i0 = GC + wave * PL_BATCH; i0 < total; i0 += 8 * PL_BATCH) batch(i0, total);
   }
   __syncthreads();
   PSTAMP(5);
   if (tid < GC && my_n > 0) {
-    const int c = tid, o = coff[c];
-    float e1 = res[o];
-    int ei = itemr[o];
-    for (int k = 1; k < my_n; k++) {
-      const float e = res[o + k];
-      const int ix = itemr[o + k];
-      if (better_nan(e, ix, e1, ei)) {
-        e1 = e;
-        ei = ix;
-      }
+    const int c = tid;
+    float e1 = res[c];
+    int ei = itemr[c];
+    if (my_n > 1) {                            // this column's appended rows: a scan of the (short) appended list
+      const int total = GC + nextra[0];
+      for (int i = GC; i < total; i++)
+        if (itemc[i] == c) {
+          const float e = res[i];
+          const int ix = itemr[i];
+          if (better_nan(e, ix, e1, ei)) {
+            e1 = e;
+            ei = ix;
+          }
+        }
     }
     const int q = qmap[c];
     S_max[(size_t)f * Q + q] = e1;
@@ -621,7 +655,7 @@ int launch_planes(const float *V, const float *W, const unsigned char *Vp, const
                   int64_t *D_ind, hipStream_t st) {
   constexpr int RT = 2 * RW * 32, GC = 64 * CW;
   const size_t lds = (size_t)planes_lds<RT, GC>(Na).total;
-  static_assert((size_t)(GC + 4 + 3 * GC * PL_MAXC + 2 + GC + 16) * 4 <= (size_t)2 * (RT + GC) * 128, "exact-phase scratch fits the stages");
+  static_assert((size_t)(3 * (GC + GC * PL_MAXC) + 2 + GC + 16) * 4 <= (size_t)2 * (RT + GC) * 128, "exact-phase scratch fits the stages");
   const void *k = reinterpret_cast<const void *>(sim_planes_kernel<RW, CW, KIND>);
   if (lds > 64 * 1024) {
     const int rc = allow_dynamic_lds(k, 160 * 1024);

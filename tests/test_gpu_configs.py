@@ -242,22 +242,21 @@ def test_grounding_accuracy_delta_vs_oracle(name, precision, capsys):
     """north_star: "grounding accuracy within +-0.1 % of the reference on identical inputs".  The HIP detections of the config's
     seeded 64-frame batch and the ORACLE's detections of the same batch (rebuilt from the fixture's rois / D_ind / D_sim) go
     through postprocess -> record_det -> box_accuracy and phrase_accuracy (model.py:457-487, youcook_eval.py:135-336) against one
-    synthetic ground truth that is independent of both; |delta| <= 0.001 on all four figures.  eval-mode DVSA, like validate()."""
+    synthetic ground truth that is independent of both; |delta| <= 0.001 on all four figures."""
     c = load_config(name)
     g, model, batch = c["g"], c["model"], c["batch"]
     Na, Ns, Nb, Ne = c["dims"]
     c["cfg"].TEST.RPN_POST_NMS_TOP_N = Nb
     fr = model.fasterRCNN
     fr.precision = precision
-    model.eval(); model.DVSA.init_eval(); model.DVSA.Na = Na
-    try:
-        with torch.no_grad():
-            rois, roi_scores, pooled, fc7 = fr(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
-            V = model.vis_ebd(fc7)
-            W = model.word_ebd(batch.glove_feats)
-            D_ind, D_sim, L = model.DVSA(V, W, batch.entities_length)
-    finally:
-        model.train(); model.DVSA.init_train(); fr.eval()
+    # (the fixture's W comes from WordEbd in TRAIN mode -- BatchNorm on batch statistics, dropout_rate 0 -- like every other test
+    # on these fixtures; D_ind / D_sim do not depend on DVSA's phase, model.py:610-612)
+    model.train(); model.DVSA.init_train(); fr.eval()
+    with torch.no_grad():
+        rois, roi_scores, pooled, fc7 = fr(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
+        V = model.vis_ebd(fc7)
+        W = model.word_ebd(batch.glove_feats)
+        D_ind, D_sim, L = model.DVSA(V, W, batch.entities_length)
     # validate() records the own-segment pairs only (Ns x sum(lens) = 152 detections here): one changed match would be 0.66 % of
     # one ground truth, so the comparison is pooled over N_GT independent ground truths (mean of each figure), which resolves 0.08 %
     N_GT = 8
