@@ -262,22 +262,22 @@ int nafae_sim_max_fwd(const float *V, const float *W, const int32_t *ent_len, in
  *                                                fp32 live-column kernel (simfused.hip sim_live_kernel, ONE launch), ceil(Qh / 32)
  *                                                column blocks: every score is an fp32 dot product on the fp32 matrix cores,
  *                                                no filter, no margin;
- *       Qh > 64, Nb > 64, D % 64 == 0, D <= 512  one launch, one workgroup per (frame, 64 / 128 live columns)
- *                                                (sim_frame_kernel): bf16x3 products on the bf16 matrix cores (hi*hi + hi*lo +
- *                                                lo*hi, fp32 accumulate) as a FILTER that keeps the best three rows per
- *                                                contributor; the winner and every listed row within
- *                                                margin = 2^-14 * D * max|V_frame| * max|W_group| + 2^-11 * |score| of it are
- *                                                re-evaluated with exact fp32 dot products; a column whose unlisted rows could lie
- *                                                inside the margin, or that saw a NaN/Inf product, is evaluated exactly over all
- *                                                Nb rows.  The maxima are MEASURED while staging: no precondition on |V|, |W|;
+ *       Qh > 64, Nb > 64, D % 64 == 0, D <= 512  the planes kernel (simplanes.hip sim_planes_kernel; see nafae_sim_max_fwd_planes
+ *                                                below): V and W are first split into matrix-core planes by a pre-pass launch into
+ *                                                the workspace (fp16 planes when D % 128 == 0, else bf16 hi / lo), then one launch,
+ *                                                one workgroup per (frame, 64 / 128 live columns), filters with them and finishes
+ *                                                every listed row as an exact fp32 dot product; a column that saw a NaN / Inf, an
+ *                                                operand beyond the plane's range or more listed rows than the lists hold is
+ *                                                evaluated exactly over all Nb rows.  No precondition on |V|, |W|;
  *       anything else (D % 32 != 0, D > 512, Na > 2048): the exact-fp32 first-generation kernel of nafae_sim_max_fwd_frames
  *                                                (any D % 4 == 0; F <= 65535, else NAFAE_ELIMIT).
  *     In every route D_ind follows torch.max: the first maximal row, a NaN score is the maximum (first NaN wins);
  *   - max_live_cols: an UPPER BOUND on the number of live slots, sum_a min(max(ent_len[a],0),Ne), if the host knows it
  *     (it sizes the launch), or -1 = unknown (sized for all Na*Ne).  A bound that is too small is a caller error that is
  *     made visible: the live columns beyond it come back as (NaN, 0), never as a plausible wrong maximum;
- *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes: 1 MiB of arrival counters, then the per-row-block records of
- *     the live-column route at Qh = Na*Ne (F * ceil(Nb/32) * ceil(Q/32) * 256 bytes).  Round 4: the live-column route finishes
+ *   - workspace: nafae_sim_max_workspace_bytes(F, Nb, Na, Ne, D) bytes: 1 MiB of arrival counters, then the larger of the per-row-block
+ *     records of the live-column route at Qh = Na*Ne (F * ceil(Nb/32) * ceil(Q/32) * 256 bytes) and the pre-pass planes of the
+ *     many-live-column route.  Round 4: the live-column route finishes
  *     inside its one launch -- the last of a frame's row-block workgroups to arrive merges their records -- so the first 1 MiB
  *     (the counters) must be ZERO when the FIRST call on a workspace starts (hipMemsetAsync once, at allocation); every completed
  *     call leaves it zero, whatever its shape, so one workspace serves calls of different shapes on one stream.  (After an aborted
@@ -364,6 +364,26 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
                          const int32_t *ent_len, int F, int Na, int Ns, int Nb, int Ne, int D, int cluster_rows,
                          const void *workspace, const float *pre_scale, const float *grad_scale, float *dV,
                          float *dW, void *stream);
+
+/* ---- JPEG frame decoding (round 4; csrc/jpeg.hip) ----------------------------------------------------------------------------
+ * Replaces `cv2.imread(img_path)` of the reference's loader (lib/datasets/youcook2.py:212) on the device: baseline sequential JPEG
+ * (SOF0, 8-bit, Huffman, one interleaved scan; 1 component, or 3 with luma sampling h0 x v0 in {1x1, 2x1, 2x2} and chroma 1x1;
+ * optional restart intervals), decoded exactly as libjpeg does by default (jdhuff.c, jidctint.c ISLOW, jdsample.c fancy
+ * upsampling, jdcolor.c), written as uint8 BGR [n, H, W, 3].  The host parses the header segments and passes, all in device memory:
+ *   stream     the files' bytes back to back, every file starting at a multiple of 8, >= 16 bytes of padding after the last;
+ *   img_desc   int32 [n][32]: [0] offset of the entropy-coded data in `stream`, [1] bytes from there to the end of the file,
+ *              [2] restart interval in MCUs (0 = none), [3 + c] quantisation-table slot of component c,
+ *              [6 + c] (DC table slot << 16) | AC table slot;
+ *   seg_desc   int32 [n_segments][4]: (image, offset of the restart interval's data in `stream`, first MCU, number of MCUs) --
+ *              one entry per restart interval, one per image without restart markers;
+ *   qtabs      uint16 [slots][64], natural (row-major) order;
+ *   hufftabs   int32 [slots][384]: 512 x u16 9-bit look-ahead entries (len << 8 | symbol, 0 = longer code), maxcode[l] at
+ *              [256 + l] (l = 1..16, -1 = none), valoffset[l] at [274 + l], the huffval bytes at [292].
+ * All images share W, H, ncomp, h0, v0.  workspace: nafae_jpeg_workspace_bytes(...) bytes, 16-byte aligned, no initialisation.  */
+int64_t nafae_jpeg_workspace_bytes(int n_images, int W, int H, int ncomp, int h0, int v0);
+int nafae_jpeg_decode_batch(const uint8_t *stream, int64_t stream_bytes, const int32_t *img_desc, const int32_t *seg_desc,
+                            const uint16_t *qtabs, const int32_t *hufftabs, int n_images, int n_segments, int W, int H,
+                            int ncomp, int h0, int v0, void *workspace, int64_t workspace_bytes, uint8_t *out_bgr, void *stream_);
 
 /* ---- small embedding-tail ops (model.py:624-642) ------------------------------------------------ */
 

@@ -25,6 +25,7 @@ SOURCES = [
     ("simmax.hip", []),
     ("simfused.hip", []),
     ("simplanes.hip", []),
+    ("jpeg.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "--offload-arch=" + ARCH, "-fhip-fp32-correctly-rounded-divide-sqrt", "-std=c++17",
           "-Wall", "-Wno-unused-function"]

@@ -801,7 +801,10 @@ void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *_
     // disassembles the built object and asserts that this kernel touches M0 nowhere else)
     const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
     const char *b = (i < 8 ? abase + (size_t)i * astep : bbase + (size_t)(i - 8) * bstep) + (size_t)kt * (BK * sizeof(float));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? av : bv), "s"(b) : "memory", "m0");
+#pragma clang diagnostic pop
   };
   // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads the 16 B at logical slot 2 jj + h of its row: element e of step jj
   // is k = 8 jj + 4 h + e on both sides
@@ -1052,15 +1055,19 @@ int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, in
         (size_t)256 * ldb * sizeof(float) < (1ull << 31)) {
       const void *k4 = reinterpret_cast<const void *>(f32_gemm4_kernel);
       if (nafae::allow_dynamic_lds(k4, 2 * 512 * 128) != NAFAE_OK) return NAFAE_ELAUNCH;
+      NAFAE_TAG("f32_gemm4");
       hipLaunchKernelGGL(f32_gemm4_kernel, dim3((M / 256) * (N / 256)), dim3(256), 2 * 512 * 128, S(stream), A, lda, B, ldb, C, ldc,
                          bias, M, N, K, alpha, act, M / 256, N / 256);
       return launched();
     }
   }
-  if (N <= 64 || t128 < 2L * sk_num_cus())
+  if (N <= 64 || t128 < 2L * sk_num_cus()) {
+    NAFAE_TAG("gemm_nt<128,64>");
     launch_gemm_nt<128, 64, 4, 1>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
-  else
+  } else {
+    NAFAE_TAG("gemm_nt<128,128>");
     launch_gemm_nt<128, 128, 2, 2>(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, S(stream));
+  }
   return launched();
 }
 
@@ -1148,15 +1155,19 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
     // layers it serves best -- NAFAE_ELIMIT tells the caller to pool separately (odd sizes, tensors above 2 GiB, layers that go
     // to the stream-K schedule, whose gain is larger than the pool's)
     if ((H & 1) || (W & 1) || !small || !f32_single_buffer() || (workspace && Cout > 64 && f32_sk_pays(t128, sk_num_cus()))) return NAFAE_ELIMIT;
-    if (Cout <= 64)
+    if (Cout <= 64) {
+      NAFAE_TAG("conv3x3<128,64>+pool");
       launch_conv<128, 64, 4, 1, true>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
-    else
+    } else {
+      NAFAE_TAG("conv3x3<128,128>+pool");
       launch_conv<128, 128, 2, 2, true>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
+    }
     return launched();
   }
   if (Cout <= 64) {
     // (256 x 64 tiles -- the 64 MFMAs per wave and k-tile of the 128 x 128 kernel -- measured twice and rejected: 176 registers / two
     // workgroups per CU 2.44 vs 2.25 ms; after the buffer-load rewrite 152 registers / three per CU 2.21 vs 2.12 ms)
+    NAFAE_TAG("conv3x3<128,64>");
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) && small &&   // (buffer-addressed loads)
              workspace_bytes >= (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float)) {
@@ -1169,6 +1180,7 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
     // too short to reach its steady state, so below 4 rounds everything goes stream-K)
     const int rounds = (int)(t128 / sk_num_cus());
     const int full = rounds >= 4 ? rounds * sk_num_cus() : 0, rem = (int)t128 - full;
+    NAFAE_TAG(full > 0 ? "conv3x3<128,128> whole rounds + conv3x3_sk remainder" : "conv3x3_sk");
     if (full > 0) {
       hipLaunchKernelGGL((conv3x3_kernel<128, 128, 2, 2, true, true>), dim3(full), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias,
                          out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
@@ -1180,8 +1192,10 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
     hipLaunchKernelGGL((conv_sk_fixup_f32_kernel<128, 128, 2, 2>), dim3(G - 1), dim3(NTHREADS), 0, S(stream), (const float *)workspace, bias,
                        out, M, Cout, relu, tiles_m, tiles_n, 9 * (Cin / 32), G, full, rem);
   } else if (small_ok && t128 < 2 * 256) {
+    NAFAE_TAG("conv3x3<64,64>");
     launch_conv<64, 64, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   } else {
+    NAFAE_TAG("conv3x3<128,128>");
     launch_conv<128, 128, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   }
   return launched();
@@ -1218,6 +1232,11 @@ int nafae_frames_u8_to_nchw_f32(const uint8_t *frames_hwc, float *out_nchw, int 
   hipLaunchKernelGGL(frames_u8_kernel, dim3(blocks), dim3(256), 0, S(stream), frames_hwc, out_nchw, F, H, W);
   return launched();
 }
+
+#ifdef NAFAE_EXPERIMENTS
+/* experiments build only: the tag the calling thread's most recent dispatching call left (hip_util.h NAFAE_TAG) */
+const char *nafae_last_kernel_id(void) { return nafae::last_kernel_buf(); }
+#endif
 
 int nafae_version(char *buf, int cap) {
   static const char v[] = "nafae_hip 0.1 gfx950";

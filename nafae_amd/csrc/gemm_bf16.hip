@@ -104,67 +104,6 @@ __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, flo
   }
 }
 
-// ------------------------------------------------------------------------------------------------ GEMM
-template <int BX, int BW, int WX, int WW, bool SPLIT>
-__global__ __launch_bounds__(NT16) void gemm_nt_bf16_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
-                                                            int ldx, const __bf16 *__restrict__ Whi,
-                                                            const __bf16 *__restrict__ Wlo, int ldw,
-                                                            float *__restrict__ Cf, __bf16 *__restrict__ Chi,
-                                                            __bf16 *__restrict__ Clo, int ldc,
-                                                            const float *__restrict__ bias, int M, int N, int K,
-                                                            float alpha, int act, int tiles_m, int tiles_n) {
-  using E = EngineH<BX, BW, WX, WW, SPLIT>;
-  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
-  E e;
-  e.init();
-  int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BX, n0 = tn * BW;
-  const int nk = (K + BKH - 1) / BKH;
-
-  const __bf16 *gp[E::NCH];
-  bool ok[E::NCH], live[E::NCH];
-  int ldsoff[E::NCH], kslot[E::NCH];
-#pragma unroll
-  for (int i = 0; i < E::NCH; i++) {
-    const typename E::Chunk c = e.chunk(i);
-    ldsoff[i] = c.lds;
-    live[i] = c.valid;
-    kslot[i] = c.slot * 8;
-    if (!c.w) {
-      const int m = m0 + c.row;
-      ok[i] = m < M;
-      gp[i] = (c.plane ? Xlo : Xhi) + (size_t)(ok[i] ? m : 0) * ldx + c.slot * 8;
-    } else {
-      const int n = n0 + c.row;
-      ok[i] = n < N;
-      gp[i] = (c.plane ? Wlo : Whi) + (size_t)(ok[i] ? n : 0) * ldw + c.slot * 8;
-    }
-  }
-  bf16x8 rg[E::NCH];
-  auto fetch = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < E::NCH; i++) rg[i] = ldg8(gp[i] + kt * BKH, ok[i] && (kt * BKH + kslot[i] < K));
-  };
-  auto store = [&](__bf16 *stage) {
-#pragma unroll
-    for (int i = 0; i < E::NCH; i++)
-      if (live[i]) *reinterpret_cast<bf16x8 *>(&stage[ldsoff[i]]) = rg[i];
-  };
-  fetch(0);
-  store(smem16);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    __bf16 *cur = smem16 + (kt & 1) * E::STAGE;
-    __bf16 *nxt = smem16 + ((kt + 1) & 1) * E::STAGE;
-    if (kt + 1 < nk) fetch(kt + 1);
-    e.compute(cur);
-    if (kt + 1 < nk) store(nxt);
-    __syncthreads();
-  }
-  epilogue<E, SPLIT>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
-}
-
 // ------------------------------------------------------------------------------------------------ conv
 template <int BX, int BW, int WX, int WW, bool SPLIT>
 __global__ __launch_bounds__(NT16) void conv3x3_bf16_kernel(const __bf16 *__restrict__ Xhi, const __bf16 *__restrict__ Xlo,
@@ -260,10 +199,6 @@ __device__ __attribute__((aligned(64))) const unsigned int nafae_zero_page[16] =
 #define NAFAE_CONV_EXP 0
 #endif
 constexpr int CONV_EXP = NAFAE_CONV_EXP;
-#ifndef NAFAE_CONV_FENCE
-#define NAFAE_CONV_FENCE 1
-#endif
-constexpr bool CONV_SCHED_FENCE = NAFAE_CONV_FENCE;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -466,7 +401,10 @@ void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, f
     // disassembles the built object and asserts that this kernel touches M0 nowhere else)
     const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
     const char *b = (i < 8 ? xbase + (size_t)i * xstep : wbase + (size_t)(i - 8) * wstep) + (size_t)kt * (2 * BKH * sizeof(__bf16));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? xv : wv), "s"(b) : "memory", "m0");
+#pragma clang diagnostic pop
   };
   // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads 16 B at logical slot plane * 4 + 2 s + h of its row
   const int fr = lane & 31, h = lane >> 5, sw = (fr >> 1) & 7;
@@ -991,140 +929,6 @@ __global__ __launch_bounds__(NT16) void conv_sk_fixup_kernel(const float *__rest
                      jsel + 1);
 }
 
-// ------------------------------------------------------------------------------------------------ run-reuse conv, 3 taps / barrier
-// Same data flow as conv3x3_run_kernel for narrow layers (Cout <= 64, where a wave has only 12 MFMAs per tap and the
-// per-step barrier + waits cost as much as the matrix work): ONE barrier per row-offset group, i.e. per 3 taps.  The
-// three weight tap tiles of a group (8 KB each at 64 output channels) live in a 6-stage ring (2 groups), the
-// activation run ring is unchanged; every wait is vmcnt(0) on loads issued a whole group (36 MFMAs per wave) earlier.
-template <int BW, int WX, int WW, bool IL, bool S16>
-__global__ __launch_bounds__(NT16) void conv3x3_run3_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi, const __bf16 *Wlo,
-                                                            const float *__restrict__ bias, float *__restrict__ Cf,
-                                                            __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H,
-                                                            int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n) {
-  constexpr int BX = 256, PL = 2, RR = 320, ROFF = 32;
-  using E = EngineH<BX, BW, WX, WW, true, IL, S16>;
-  using L = typename E::L;
-  if (IL) {
-    Xlo = Xhi + BKH;
-    Wlo = Whi + BKH;
-  }
-  const int CinS = Cin * L::RS;
-  constexpr int TX = E::TX, TW = E::TW, NI = E::NI, NJ = E::NJ, MS = E::MS;
-  constexpr int XRUN = RR * BKH * PL, WST = BW * BKH * PL;
-  constexpr int NXC = RR * 4 * PL / NT16, NWC = BW * 4 * PL / NT16;
-  static_assert(RR * 4 * PL % NT16 == 0 && BW * 4 * PL % NT16 == 0, "every lane active in every staging instruction");
-  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
-  __bf16 *xbuf = smem16;              // 2 run buffers
-  __bf16 *wbuf = smem16 + 2 * XRUN;   // 6 weight stages: [group parity][tap in group]
-  E e;
-  e.init();
-  int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int M = F * H * W;
-  const int m0 = tm * BX, n0 = tn * BW;
-  const int cpt = Cin / BKH;
-  const int ngrp = 3 * cpt;
-  const int K9 = 9 * Cin;
-  const __bf16 *zero = reinterpret_cast<const __bf16 *>(nafae_zero_page);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-
-  const __bf16 *xp[NXC];
-  int xpix[NXC];
-#pragma unroll
-  for (int i = 0; i < NXC; i++) {
-    int plane, row, slot;
-    L::template decode<RR>(threadIdx.x + NT16 * i, row, plane, slot);
-    xpix[i] = m0 - ROFF + row;
-    xp[i] = (plane ? Xlo : Xhi) + slot * 8;
-  }
-  const __bf16 *wp[NWC];
-  bool wok[NWC];
-#pragma unroll
-  for (int i = 0; i < NWC; i++) {
-    int plane, row, slot;
-    L::template decode<BW>(threadIdx.x + NT16 * i, row, plane, slot);
-    const int n = n0 + row;
-    wok[i] = n < Cout;
-    wp[i] = (plane ? Wlo : Whi) + (size_t)(wok[i] ? n : 0) * K9 * L::RS + slot * 8;
-  }
-  unsigned tapmask[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int m = m0 + e.pm(j);
-    unsigned mk = 0;
-    if (m < M) {
-      const int x = m % W, y = (m / W) % H;
-#pragma unroll
-      for (int t = 0; t < 9; t++) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << t;
-      }
-    }
-    tapmask[j] = mk;
-  }
-  // staging of one whole group g = (cc, dy): the run + its three weight tap tiles
-  auto issue_group = [&](int g) {
-    const int cc = g / 3, dyi = g - cc * 3;
-#pragma unroll
-    for (int i = 0; i < NXC; i++) {
-      const long pix = (long)xpix[i] + (long)(dyi - 1) * W;
-      const __bf16 *src = (pix >= 0 && pix < M) ? xp[i] + pix * CinS + cc * L::KTS : zero;
-      char *dst = reinterpret_cast<char *>(xbuf + (size_t)(g & 1) * XRUN) + (NT16 * i + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-#pragma unroll
-      for (int i = 0; i < NWC; i++) {
-        const __bf16 *src = wok[i] ? wp[i] + (dyi * 3 + t) * CinS + cc * L::KTS : zero;
-        char *dst = reinterpret_cast<char *>(wbuf + (size_t)((g & 1) * 3 + t) * WST) + (NT16 * i + wave * 64) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-      }
-  };
-  const int fr = e.frow();
-  issue_group(0);
-  for (int g = 0; g < ngrp; g++) {
-    wait_vmcnt<0>();                 // group g (issued one whole group of matrix work ago) has landed
-    __builtin_amdgcn_s_barrier();    // ... for every wave; and everyone is done with group g-1's buffers
-    if (g + 1 < ngrp) issue_group(g + 1);
-    const __bf16 *sX = xbuf + (size_t)(g & 1) * XRUN;
-    const int dyi = g - (g / 3) * 3;
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const int tap = dyi * 3 + t;
-      const __bf16 *sW = wbuf + (size_t)((g & 1) * 3 + t) * WST;
-#pragma unroll
-      for (int s = 0; s < E::KSTEPS; s++) {
-        const int sl = e.fslot(s);
-        bf16x8 xa[NJ][PL], wa[NI][PL];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          const int rrow = e.wx * (TX * 32) + j * MS + fr + ROFF + t - 1;
-          const bool on = (tapmask[j] >> tap) & 1u;
-#pragma unroll
-          for (int p = 0; p < PL; p++) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(&sX[L::template frag<RR>(rrow, p, sl)]);
-            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            xa[j][p] = on ? v : z;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; i++)
-#pragma unroll
-          for (int p = 0; p < PL; p++)
-            wa[i][p] = *reinterpret_cast<const bf16x8 *>(&sW[L::template frag<BW>(e.ww * (TW * 32) + i * MS + fr, p, sl)]);
-#pragma unroll
-        for (int i = 0; i < NI; i++)
-#pragma unroll
-          for (int j = 0; j < NJ; j++) e.mma(i, j, wa[i], xa[j]);
-      }
-    }
-  }
-  epilogue<E, true>(e, m0, n0, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
-}
-
 // ------------------------------------------------------------------------------------------------ 2-D patch conv (narrow layers)
 // 3x3 conv for the layers where a 256-pixel x 64-channel tile holds only ~6 us of matrix work (conv1_2: 64 -> 64 at
 // 224^2) and the raster-run kernels above spend twice that on everything else: 387 KB of L2 -> LDS staging per tile (the run
@@ -1545,22 +1349,6 @@ __global__ __launch_bounds__(256) void maxpool_bf16_kernel(const __bf16 *ihi, co
 }
 
 template <int BX, int BW, int WX, int WW, bool SPLIT>
-int launch_gemm(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const void *Wlo, int ldw, float *Cf, void *Chi,
-                void *Clo, int ldc, const float *bias, int M, int N, int K, float alpha, int act, hipStream_t st) {
-  using E = EngineH<BX, BW, WX, WW, SPLIT>;
-  const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
-  const size_t lds = 2 * E::STAGE * sizeof(__bf16);
-  auto kern = gemm_nt_bf16_kernel<BX, BW, WX, WW, SPLIT>;
-  if (lds > 64 * 1024) {
-    if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
-  }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, ldx,
-                     (const __bf16 *)Whi, (const __bf16 *)Wlo, ldw, Cf, (__bf16 *)Chi, (__bf16 *)Clo, ldc, bias, M, N, K, alpha,
-                     act, tiles_m, tiles_n);
-  return launched();
-}
-
-template <int BX, int BW, int WX, int WW, bool SPLIT>
 int launch_conv(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
                 void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
   using E = EngineH<BX, BW, WX, WW, SPLIT>;
@@ -1568,6 +1356,7 @@ int launch_conv(const void *Xhi, const void *Xlo, const void *Whi, const void *W
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
   const size_t lds = 2 * E::STAGE * sizeof(__bf16);
   auto kern = conv3x3_bf16_kernel<BX, BW, WX, WW, SPLIT>;
+  NAFAE_TAG("conv3x3_bf16<%d,%d,split=%d> (register-staged)", BX, BW, (int)SPLIT);
   if (lds > 64 * 1024) {
     if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   }
@@ -1599,6 +1388,7 @@ int launch_dma(const void *Xhi, const void *Xlo, int ldx, const void *Whi, const
   using E = EngineH<BX, BW, WX, WW, SPLIT>;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (N + BW - 1) / BW;
   const size_t lds = NST * E::STAGE * sizeof(__bf16);
+  NAFAE_TAG("bf16_dma<%d,%d,split=%d,conv=%d,il=%d,pair=%d>", BX, BW, (int)SPLIT, (int)CONV, (int)IL, (int)PAIR);
   auto kern = (use_s16() && !PAIR) ? bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, true>
                                     : bf16_dma_kernel<BX, BW, WX, WW, SPLIT, CONV, NST, IL, false, PAIR>;
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
@@ -1635,6 +1425,7 @@ int launch_gemm4(const void *Xil, int ldx, const void *Wil, int ldw, float *Cf, 
   const int tiles_m = M / 256, tiles_n = N / 256;
   const size_t lds = 2 * 512 * 128;
   auto kern = bf16_gemm4_kernel<PAIR>;
+  NAFAE_TAG("bf16_gemm4<pair=%d>", (int)PAIR);
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, (const __bf16 *)Xil, ldx, (const __bf16 *)Wil, ldw, Cf,
                      (__bf16 *)Chi, (__bf16 *)Clo, ldc, bias, M, N, K, alpha, act, tiles_m, tiles_n);
@@ -1647,6 +1438,7 @@ int launch_conv_run(const void *Xhi, const void *Xlo, const void *Whi, const voi
   const int M = F * H * W;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
   constexpr int PL = SPLIT ? 2 : 1, RR = BX == 224 ? 256 : (SPLIT ? 320 : 384);
+  NAFAE_TAG("conv3x3_run<%d,%d,split=%d,il=%d,pair=%d>", BX, BW, (int)SPLIT, (int)IL, (int)PAIR);
   const size_t lds = (size_t)(2 * RR * BKH * PL + NSTW * BW * BKH * PL) * sizeof(__bf16);
   auto kern = (use_s16() && !PAIR) ? conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, true>
                                     : conv3x3_run_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, false, PAIR>;
@@ -1686,6 +1478,7 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   const int M = F * H * W;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
   auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>;
+  NAFAE_TAG("conv3x3_run_sk<%d,%d,split=%d,il=%d,pair=%d> + fixup", BX, BW, (int)SPLIT, (int)IL, (int)PAIR);
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)R::LDS_BYTES) != NAFAE_OK) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
                      (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch);
@@ -1697,24 +1490,11 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   return launched();
 }
 
-template <int BW, int WX, int WW, bool IL = false>
-int launch_conv_run3(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
-                     void *Clo, int F, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
-  const int M = F * H * W;
-  const int tiles_m = (M + 255) / 256, tiles_n = (Cout + BW - 1) / BW;
-  const size_t lds = (size_t)(2 * 320 * BKH * 2 + 6 * BW * BKH * 2) * sizeof(__bf16);
-  auto kern = use_s16() ? conv3x3_run3_kernel<BW, WX, WW, IL, true> : conv3x3_run3_kernel<BW, WX, WW, IL, false>;
-  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo,
-                     (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu,
-                     tiles_m, tiles_n);
-  return launched();
-}
-
 template <bool PAIR, bool POOL = false>
 int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void *Chi, void *Clo, int F, int H, int W,
                       int Cin, int Cout, int relu, hipStream_t st) {
   const int tiles_y = H / PT, tiles_x = W / PT, tiles_n = Cout / 64;
+  NAFAE_TAG("conv3x3_patch<pair=%d,pool=%d>", (int)PAIR, (int)POOL);
   const long T = (long)F * tiles_y * tiles_x * tiles_n;
   if (T >= (1L << 31)) return NAFAE_ELIMIT;
   const size_t lds = (size_t)(2 * PROWS * 64 + 6 * 64 * 64) * sizeof(__bf16);
@@ -1732,25 +1512,6 @@ int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void 
   hipLaunchKernelGGL((conv3x3_patch_kernel<PAIR, POOL>), dim3(G), dim3(NT16), lds, st, (const __bf16 *)Xhi, (const __bf16 *)Whi, bias,
                      (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_y, tiles_x, tiles_n);
   return launched();
-}
-
-// A/B switches: NAFAE_BF16_PIPE=reg selects the register-staged kernels; NAFAE_CONV_RUN=0 disables the run-reuse conv
-inline bool use_run() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = nafae::experiment_env("NAFAE_CONV_RUN");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
-}
-
-inline bool use_dma() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = nafae::experiment_env("NAFAE_BF16_PIPE");
-    v = (e && e[0] == 'r') ? 0 : 1;
-  }
-  return v == 1;
 }
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1787,8 +1548,7 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
 #endif
   const bool split = X_lo && W_lo;
   if (!split && (X_lo || W_lo)) return NAFAE_EINVAL;
-  if (host_il(X_hi, X_lo) && !use_dma()) return NAFAE_EINVAL;  // I32 operands: LDS-DMA kernels only
-  if (use_dma()) {
+  {
     static int big = -1;  // NAFAE_BF16_TILE=128 forces the 256x128 tile (A/B experiments)
     if (big < 0) {
       const char *e = nafae::experiment_env("NAFAE_BF16_TILE");
@@ -1839,11 +1599,7 @@ int nafae_gemm_nt_bf16(const void *X_hi, const void *X_lo, int ldx, const void *
     return launch_dma<256, 128, 4, 2, false, false>(X_hi, nullptr, ldx, W_hi, nullptr, ldw, C_f32, C_hi, nullptr, ldc, bias, M, N, K,
                                                     alpha, act, 0, 0, 0, S(stream));
   }
-  if (split)
-    return launch_gemm<256, 128, 4, 2, true>(X_hi, X_lo, ldx, W_hi, W_lo, ldw, C_f32, C_hi, C_lo, ldc, bias, M, N, K, alpha, act,
-                                             S(stream));
-  return launch_gemm<256, 128, 4, 2, false>(X_hi, nullptr, ldx, W_hi, nullptr, ldw, C_f32, C_hi, nullptr, ldc, bias, M, N, K,
-                                            alpha, act, S(stream));
+  // (every shape returned above: the register-staged GEMM of round 1 left with its last caller in round 4)
 }
 
 int64_t nafae_conv3x3_bf16_workspace_bytes(int F, int H, int W, int Cin, int Cout) {
@@ -1873,9 +1629,8 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
   if ((long)F * H * W >= (1L << 31)) return NAFAE_ELIMIT;
   const bool split = in_lo && w_lo;
   if (!split && (in_lo || w_lo)) return NAFAE_EINVAL;
-  if (host_il(in_hi, in_lo) && !(use_dma() && use_run())) return NAFAE_EINVAL;  // I32 operands: run-reuse kernels only
-  if ((relu & 16) && (!(use_dma() && use_run()) || (H & 1) || (W & 1))) return NAFAE_ELIMIT;
-  if (use_dma() && use_run()) {
+  if ((relu & 16) && ((H & 1) || (W & 1))) return NAFAE_ELIMIT;
+  {
     const int M = F * H * W;
     if (split) {
       const bool il = host_il(in_hi, in_lo);
@@ -1892,17 +1647,8 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
         if (relu & 16) return NAFAE_ELIMIT;   // fused max-pool exists in the patch kernel only: the caller pools separately
       }
       if (Cout <= 64) {
-        static int g3 = -1;  // NAFAE_CONV_RUN3=0: one barrier per tap instead of per 3-tap group (A/B)
-        if (g3 < 0) {
-          const char *e = nafae::experiment_env("NAFAE_CONV_RUN3");
-          g3 = (e && e[0] == '0') ? 0 : 1;
-        }
-        if (g3 && il)
-          return launch_conv_run3<64, 8, 1, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
-                                                  S(stream));
-        if (g3)
-          return launch_conv_run3<64, 8, 1>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,
-                                            S(stream));
+        // (round 2's one-barrier-per-3-taps kernel for this case, conv3x3_run3_kernel, left in round 4: the 64-channel layers of
+        // every frame size that is a multiple of 16 take the patch kernel above; what remains here are odd sizes and fp32 outputs)
         if (il)
           return launch_conv_run<64, 8, 1, 3, true, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout,
                                                           relu, S(stream));
@@ -1987,23 +1733,8 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
       return launch_conv_run<128, 4, 2, 3, false>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H, W, Cin, Cout,
                                                   relu, S(stream));
   }
-  if (use_dma()) {
-    const int M = F * H * W, K9 = 9 * Cin, act = relu ? NAFAE_ACT_RELU : NAFAE_ACT_NONE;
-    if (Cout <= 64 && split)
-      return launch_dma<256, 64, 8, 1, true, true>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M, Cout,
-                                                   K9, 1.0f, act, H, W, Cin, S(stream));
-    if (Cout >= 256 && split && M >= 256 * 128)  // wide layers with enough pixels to fill the chip: 256x256 tile, 2-stage ring
-      return launch_dma<256, 256, 2, 4, true, true, 2>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M,
-                                                       Cout, K9, 1.0f, act, H, W, Cin, S(stream));
-    if (Cout > 64) {
-      if (split)
-        return launch_dma<256, 128, 4, 2, true, true>(in_hi, in_lo, Cin, w_hi, w_lo, K9, out_f32, out_hi, out_lo, Cout, bias, M,
-                                                      Cout, K9, 1.0f, act, H, W, Cin, S(stream));
-      return launch_dma<256, 128, 4, 2, false, true>(in_hi, nullptr, Cin, w_hi, nullptr, K9, out_f32, out_hi, nullptr, Cout, bias, M,
-                                                     Cout, K9, 1.0f, act, H, W, Cin, S(stream));
-    }
-    // Cout <= 64 in plain bf16: 1280 chunks do not fill 512 lanes evenly -> register-staged kernel below
-  }
+  // what is left: plain bf16 with Cout <= 64 and Cin % 64 != 0 (1280 staging chunks do not fill 512 lanes evenly) -- the
+  // register-staged kernel (conv3x3_bf16_kernel)
   if (Cout <= 64) {
     if (split)
       return launch_conv<256, 64, 8, 1, true>(in_hi, in_lo, w_hi, w_lo, bias, out_f32, out_hi, out_lo, F, H, W, Cin, Cout, relu,

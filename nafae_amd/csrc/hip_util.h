@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include <map>
 #include <mutex>
 #include <utility>
@@ -46,5 +48,20 @@ inline const char *experiment_env(const char *name) {
   return nullptr;
 #endif
 }
+
+// Dispatch pinning.  Which kernel family an ABI call launched is a dispatch decision (shape, alignment,
+// workspace, tile count) that no output value reveals: a regression that silently falls back to a slower generation passes every
+// parity test.  In the experiments build every dispatcher leaves a tag naming the kernel it chose; nafae_last_kernel_id() returns the
+// tag of the calling thread's most recent call and tests/test_gpu_dispatch.py asserts it for every BASELINE layer / GEMM /
+// similarity shape.  The production build compiles the tags out.
+#ifdef NAFAE_EXPERIMENTS
+inline char *last_kernel_buf() {
+  static thread_local char buf[256] = "";
+  return buf;
+}
+#define NAFAE_TAG(...) snprintf(nafae::last_kernel_buf(), 256, __VA_ARGS__)
+#else
+#define NAFAE_TAG(...) do { } while (0)
+#endif
 
 }  // namespace nafae

@@ -1376,6 +1376,7 @@ int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_
   const int Q = Na * Ne;
   if (F > 65535) return NAFAE_ELIMIT;
   const size_t lds = (2 * E::STAGE + 128 * 33 + 2 * 8 * 32) * sizeof(float);
+  NAFAE_TAG("sim_max_kernel (exact-fp32 first generation)");
   hipLaunchKernelGGL(sim_max_kernel, dim3((Q + 31) / 32, F), dim3(NTHREADS), lds, S(stream), V, W, ent_len, Nb, Ne, Q, D,
                      S_max, D_ind);
   return launched();
@@ -1412,10 +1413,12 @@ int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float 
       return NAFAE_ELAUNCH;
     const size_t clds = (size_t)(2 * Ns + 1) * D * sizeof(float);
     if (train && Ns <= 64 && tail_lds <= 64 * 1024 && clds <= 64 * 1024) {     // both terms in one launch
+      NAFAE_TAG("loss_lds_cluster (tail + clustering term, one launch)");
       hipLaunchKernelGGL(loss_lds_cluster_kernel, dim3(1 + Na * Ne), dim3(1024), tail_lds > clds ? tail_lds : clds, S(stream), S_max,
                          D_ind, V, ent_len, Na, Ns, Ne, D, Delta, dS, ws, L, Lcap);
       cluster_done = true;
     } else {
+      NAFAE_TAG("loss_tail_lds%s", train ? " + cluster_kernel" : "");
       hipLaunchKernelGGL(loss_tail_lds_kernel, dim3(1), dim3(1024), tail_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws,
                          L, Lcap);
     }
@@ -1431,14 +1434,17 @@ int nafae_loss_fwd_bwd_ex(const float *S_max, const int64_t *D_ind, const float 
         return NAFAE_ELAUNCH;
       const size_t clds = (size_t)(2 * Ns + 1) * D * sizeof(float);
       if (train && Ns <= 64 && fwd_lds <= 64 * 1024 && clds <= 64 * 1024) {     // forward of the ranking term + clustering term
+        NAFAE_TAG("loss_segf_cluster + loss_seg_bwd (per-segment tail)");
         hipLaunchKernelGGL(loss_segf_cluster_kernel, dim3(Na + Na * Ne), dim3(512), fwd_lds > clds ? fwd_lds : clds, S(stream),
                            S_max, D_ind, V, ent_len, Na, Ns, Ne, D, ws, L);
         cluster_done = true;
       } else {
+        NAFAE_TAG("loss_seg_fwd + loss_seg_bwd%s", train ? " + cluster_kernel" : "");
         hipLaunchKernelGGL(loss_seg_fwd_kernel, dim3(Na), dim3(256), fwd_lds, S(stream), S_max, ent_len, Na, Ns, Ne, ws, L);
       }
       hipLaunchKernelGGL(loss_seg_bwd_kernel, dim3(Na), dim3(256), bwd_lds, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
     } else {
+      NAFAE_TAG("loss_tail (global memory)%s", train ? " + cluster_kernel" : "");
       hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, S(stream), S_max, ent_len, Na, Ns, Ne, Delta, dS, ws, L);
     }
   }
@@ -1477,6 +1483,7 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
   const int ncl = cluster_rows ? (Nb < R ? Nb : R) : 0;
   // (MC = float4 chunks per lane: 2 covers D <= 512 in 50-odd registers, i.e. 8 waves per SIMD instead of 5 -- the rows' dependent
   // round trips are hidden by the number of rows in flight)
+  NAFAE_TAG("sim_bwd<%d> (dV and dW, one launch)", D <= 512 ? 2 : MAXCH);
   if (D <= 512)
     hipLaunchKernelGGL(sim_bwd_kernel<2>, dim3(ncl + Q + (R + 3) / 4), dim3(256), bwd_lds, S(stream), dS, D_ind, V,
                        W, ent_len, F, R, Nb, Ne, Q, D, cluster_rows, Q * Ns, reinterpret_cast<const float *>(workspace), L,

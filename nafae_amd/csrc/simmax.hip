@@ -1,14 +1,15 @@
 // simmax.hip -- entry points and routing of the region x query similarity reduced to per-frame max / arg-max (DVSA.forward,
-// reference model.py:548-551, 580-583, 610-612), gfx950.  The kernels are in simfused.hip (sim_live_kernel + merge: fp32 matrix
-// cores, any number of live columns in blocks of 32; sim_frame_kernel: bf16x3 filter + exact fp32 finish per frame, for many
-// live columns) and simloss.hip (sim_max_kernel: the exact-fp32 first-generation kernel, the fallback for the shapes those do
-// not take).  In every route only the LIVE query slots (e < ent_len[a]) are contracted -- the reference zero-fills the S_ column
-// of a padded slot after the product (model.py:551), ~85 % of the columns at 2.07 entities per segment -- S_ is never written,
-// S_max is an fp32 dot product and D_ind follows torch.max (first maximal row, NaN first).
+// reference model.py:548-551, 580-583, 610-612), gfx950.  The kernels: simfused.hip (sim_live_kernel: fp32 matrix cores, any number
+// of live columns in blocks of 32, ONE launch), simplanes.hip (sim_planes_kernel: many live columns, the operands as matrix-core
+// planes -- attached by their producer, or split here in a pre-pass -- as a filter with an exact fp32 finish per frame) and
+// simloss.hip (sim_max_kernel: the exact-fp32 first-generation kernel, the fallback for the shapes those do not take).  In every
+// route only the LIVE query slots (e < ent_len[a]) are contracted -- the reference zero-fills the S_ column of a padded slot after
+// the product (model.py:551), ~85 % of the columns at 2.07 entities per segment -- S_ is never written, S_max is an fp32 dot
+// product and D_ind follows torch.max (first maximal row, NaN first).
 //
-// (Round 2's second-generation kernels -- a part / tile kernel streaming V into bf16x3 MFMA fragments, a W pre-pass and a finish
-// kernel that re-gathered the winners' rows -- lived here until the round-3 kernels covered every shape they took; their filter
-// margin assumed |V|, |W| <= 1, which no remaining route does.)
+// (History: round 2's part / tile + finish kernels assumed |V|, |W| <= 1 in their filter margin and left in round 3; round 3's
+// sim_frame_kernel converted fp32 -> bf16 hi / lo inside its k-loop, 59 us at C5 with every slot live, and left in round 4 when the
+// planes kernel took its shapes: 31 us with fp16 planes from the producer, ~43 us including this file's pre-pass.)
 //
 // Algorithmic bytes: 4*D*(R+Q) + 12*F*Q.  Everything is deterministic (no atomics).
 #include <hip/hip_runtime.h>
@@ -25,8 +26,9 @@ namespace nafae_sim {          // simfused.hip
 int64_t few_workspace_bytes(int F, int Nb, int Q);
 int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
                int64_t *D_ind, void *workspace, hipStream_t st);
-int launch_frames(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
-                  float *S_max, int64_t *D_ind, hipStream_t st);
+int64_t planes_scratch_bytes(int R, int Q, int D);
+int launch_frames_prepass(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
+                          float *S_max, int64_t *D_ind, void *scratch, hipStream_t st);
 // simplanes.hip
 int launch_planes_frames(const float *V, const float *W, const void *Vp, const void *Wp, const float *vstat, const float *wstat,
                          int kind, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh, float *S_max,
@@ -40,7 +42,7 @@ namespace {
 // 128 columns C5 49 / 44, C4 42 / 28, C2 23 / 20 (scripts/sim_sweep_live.py).
 constexpr int LIVE_MAX_DEFAULT = 64;
 
-// 0: the exact-fp32 fallback (simloss.hip), 1: sim_live_kernel + merge, 2: sim_frame_kernel
+// 0: the exact-fp32 fallback (simloss.hip), 1: sim_live_kernel, 2: sim_planes_kernel (simplanes.hip)
 inline int fused_route(int F, int Nb, int Na, int Ne, int D, int Qh) {
   if (D % 32 != 0 || D > 512 || Na > NA_MAX || F < 1 || Nb < 1) return 0;
   if ((long)Nb * D >= (1L << 30) || (long)Na * Ne * D >= (1L << 30)) return 0;      // 32-bit element offsets inside the kernels
@@ -60,7 +62,11 @@ int nafae_sim_max_fwd_frames(const float *V, const float *W, const int32_t *ent_
 
 int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D) {
   if (F <= 0 || Nb <= 0 || Na <= 0 || Ne <= 0 || D <= 0) return NAFAE_EINVAL;
-  return nafae_sim::few_workspace_bytes(F, Nb, Na * Ne);        // (the other routes need none)
+  // the live-column route's counters + records, or -- many live columns, fp32 operands only -- the counters' MiB (kept: one
+  // zeroed region whatever the route) + the operand planes of the pre-pass
+  const int64_t few = nafae_sim::few_workspace_bytes(F, Nb, Na * Ne);
+  const int64_t pre = (int64_t)FEW_NCNT * 4 + nafae_sim::planes_scratch_bytes(F * Nb, Na * Ne, D);
+  return few > pre ? few : pre;
 }
 
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
@@ -77,7 +83,11 @@ int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len,
     if (!workspace || workspace_bytes < nafae_sim::few_workspace_bytes(F, Nb, Qh)) return NAFAE_EINVAL;
     return nafae_sim::launch_few(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, workspace, as_stream(stream));
   }
-  if (route == 2) return nafae_sim::launch_frames(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, as_stream(stream));
+  if (route == 2) {   // fp32 operands only: split them into planes here (a pre-pass into the workspace), then the planes kernel
+    if (!workspace || workspace_bytes < (int64_t)FEW_NCNT * 4 + nafae_sim::planes_scratch_bytes(F * Nb, Q, D)) return NAFAE_EINVAL;
+    return nafae_sim::launch_frames_prepass(V, W, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind,
+                                            reinterpret_cast<unsigned char *>(workspace) + (size_t)FEW_NCNT * 4, as_stream(stream));
+  }
   return nafae_sim_max_fwd_frames(V, W, ent_len, F, Nb, Na, Ne, D, S_max, D_ind, stream);
 }
 

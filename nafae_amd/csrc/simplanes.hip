@@ -66,10 +66,20 @@ constexpr int KIND_BF16X3 = NAFAE_SIMPLANES_BF16X3, KIND_F16 = NAFAE_SIMPLANES_F
 template <int MODE>
 __global__ __launch_bounds__(256) void planes_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask, float scale,
                                                      uint64_t seed, uint32_t thresh, float *__restrict__ y, int rows, int D, int kind,
-                                                     unsigned char *__restrict__ planes, float *__restrict__ stats) {
+                                                     unsigned char *__restrict__ planes, float *__restrict__ stats,
+                                                     const float *__restrict__ x2, int rows2, unsigned char *__restrict__ planes2,
+                                                     float *__restrict__ stats2) {
   const int lane = threadIdx.x & 63;
   const int n4 = D >> 2;
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+  // (MODE 0 only: a second matrix x2 [rows2, D] -> planes2 / stats2 in the same launch: V and W of one similarity call)
+  for (int row0 = blockIdx.x * 4 + (threadIdx.x >> 6); row0 < rows + rows2; row0 += gridDim.x * 4) {
+    int row = row0;
+    if (MODE == 0 && row0 >= rows) {
+      row = row0 - rows;
+      x = x2;
+      planes = planes2;
+      stats = stats2;
+    }
     float amax = 0.f, ss = 0.f;
     for (int j = lane; j < n4; j += 64) {
       const size_t i4 = (size_t)row * n4 + j;
@@ -665,6 +675,7 @@ int launch_planes(const float *V, const float *W, const unsigned char *Vp, const
   const int grid = ((F + 7) / 8) * 8 * G;
   int dbg = 0;
   if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
+  NAFAE_TAG("sim_planes<%d,%d,%s>", RW, CW, KIND == KIND_F16 ? "f16" : "bf16x3");
   hipLaunchKernelGGL((sim_planes_kernel<RW, CW, KIND>), dim3(grid), dim3(512), lds, st, V, W, Vp, Wp, vstat, wstat, ent_len, F, Nb, Na,
                      Ne, D, G, S_max, D_ind, dbg);
   return launch_status();
@@ -709,6 +720,34 @@ int launch_planes_frames(const float *V, const float *W, const void *Vp, const v
   return NAFAE_ELIMIT;
 }
 
+// Callers that hold only the fp32 operands: split V and W here, in ONE pre-pass launch, into `scratch` (planes_scratch_bytes), then
+// run the planes kernel.  fp16 planes where the row is a whole number of line PAIRS (D % 128 == 0), else bf16x3 ones (D % 64 == 0).
+int64_t planes_scratch_bytes(int R, int Q, int D) {
+  const int64_t pb = (int64_t)D * (D % 128 == 0 ? 2 : 4);
+  return (((int64_t)R * pb + 255) & ~(int64_t)255) + (((int64_t)Q * pb + 255) & ~(int64_t)255) + (int64_t)(R + Q) * 8;
+}
+int launch_frames_prepass(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
+                          float *S_max, int64_t *D_ind, void *scratch, hipStream_t st) {
+  const int kind = D % 128 == 0 ? KIND_F16 : KIND_BF16X3;
+  const int R = F * Nb, Q = Na * Ne;
+  const int64_t pb = (int64_t)D * (kind == KIND_F16 ? 2 : 4);
+  unsigned char *vp = reinterpret_cast<unsigned char *>(scratch);
+  unsigned char *wp = vp + (((int64_t)R * pb + 255) & ~(int64_t)255);
+  float *vs = reinterpret_cast<float *>(wp + (((int64_t)Q * pb + 255) & ~(int64_t)255));
+  float *ws = vs + (size_t)R * 2;
+  hipLaunchKernelGGL(planes_kernel<0>, dim3(planes_grid(R + Q)), dim3(256), 0, st, V, (const uint8_t *)nullptr, 1.f, (uint64_t)0, 0u,
+                     (float *)nullptr, R, D, kind, vp, vs, W, Q, wp, ws);
+  const int rc = launch_planes_frames(V, W, vp, wp, vs, ws, kind, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind, st);
+#ifdef NAFAE_EXPERIMENTS
+  {   // (tag: the pre-pass in front of the kernel the call above named)
+    char t[200];
+    snprintf(t, sizeof t, "planes pre-pass + %s", nafae::last_kernel_buf());
+    NAFAE_TAG("%s", t);
+  }
+#endif
+  return rc;
+}
+
 }  // namespace nafae_sim
 
 extern "C" {
@@ -722,7 +761,8 @@ int nafae_sim_planes(const float *X, int rows, int D, int kind, void *planes, fl
   const int rc = planes_args_ok(X, rows, D, kind, planes, stats);
   if (rc != NAFAE_OK) return rc;
   hipLaunchKernelGGL(planes_kernel<0>, dim3(planes_grid(rows)), dim3(256), 0, as_stream(stream), X, (const uint8_t *)nullptr, 1.f,
-                     (uint64_t)0, 0u, (float *)nullptr, rows, D, kind, reinterpret_cast<unsigned char *>(planes), stats);
+                     (uint64_t)0, 0u, (float *)nullptr, rows, D, kind, reinterpret_cast<unsigned char *>(planes), stats,
+                     (const float *)nullptr, 0, (unsigned char *)nullptr, (float *)nullptr);
   return launch_status();
 }
 
@@ -731,7 +771,8 @@ int nafae_dropout_tanh_planes(const float *x, const uint8_t *mask, float scale, 
   const int rc = planes_args_ok(x, rows, D, kind, planes, stats);
   if (rc != NAFAE_OK || !y) return rc != NAFAE_OK ? rc : NAFAE_EINVAL;
   hipLaunchKernelGGL(planes_kernel<1>, dim3(planes_grid(rows)), dim3(256), 0, as_stream(stream), x, mask, scale, (uint64_t)0, 0u, y,
-                     rows, D, kind, reinterpret_cast<unsigned char *>(planes), stats);
+                     rows, D, kind, reinterpret_cast<unsigned char *>(planes), stats, (const float *)nullptr, 0, (unsigned char *)nullptr,
+                     (float *)nullptr);
   return launch_status();
 }
 
@@ -740,7 +781,8 @@ int nafae_dropout_tanh_seeded_planes(const float *x, uint64_t seed, float p, flo
   const int rc = planes_args_ok(x, rows, D, kind, planes, stats);
   if (rc != NAFAE_OK || !y || !(p >= 0.f) || !(p < 1.f)) return rc != NAFAE_OK ? rc : NAFAE_EINVAL;
   hipLaunchKernelGGL(planes_kernel<2>, dim3(planes_grid(rows)), dim3(256), 0, as_stream(stream), x, (const uint8_t *)nullptr,
-                     1.0f / (1.0f - p), seed, drop_threshold(p), y, rows, D, kind, reinterpret_cast<unsigned char *>(planes), stats);
+                     1.0f / (1.0f - p), seed, drop_threshold(p), y, rows, D, kind, reinterpret_cast<unsigned char *>(planes), stats,
+                     (const float *)nullptr, 0, (unsigned char *)nullptr, (float *)nullptr);
   return launch_status();
 }
 

@@ -1,7 +1,7 @@
 """Stand-alone timing (hipGraph of back-to-back calls) + in-kernel phase stamps of the many-live-column similarity kernels:
     [NAFAE_LIB=nafae_amd/csrc/libnafae_hip_exp.so] python scripts/simplanes_time.py [c2|c4|c5] [none|bf16x3|f16 ...]
-planes 'none' = round 3's sim_frame_kernel on the fp32 operands; the planes are produced OUTSIDE the timed region (in a step they
-come out of the embedding epilogue)."""
+planes 'none' = fp32 operands only: the entry point's own pre-pass + the planes kernel; otherwise the planes are produced OUTSIDE
+the timed region (in a step they come out of the embedding epilogue)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
-"""The similarity entry point nafae_sim_max_fwd_ws (live columns only; fp32-MFMA live-column kernel, bf16x3-filter frame kernel
-with exact fp32 finish, exact-fp32 fallback) against an fp64 evaluation of model.py:548-551,580-583,610-612 and against the
+"""The similarity entry points nafae_sim_max_fwd_ws / _planes (live columns only; fp32-MFMA live-column kernel, planes kernel with a
+bf16x3 / fp16 filter and exact fp32 finish, exact-fp32 fallback) against an fp64 evaluation of model.py:548-551,580-583,610-612 and against the
 first-generation exact-fp32 kernel, over ragged / degenerate / adversarial shapes."""
 import numpy as np
 import pytest
@@ -227,7 +227,7 @@ def test_sim_max_v2_is_deterministic_and_graph_capturable():
 @pytest.mark.parametrize("Ne,lens", [(8, [8, 5]), (40, [40, 33])], ids=["few", "dense"])
 def test_sim_max_unsquashed_embeddings_with_planted_near_ties(Ne, lens):
     """The reference's DVSA.forward accepts ANY embeddings (model.py:548), not only tanh outputs: |v| up to 10 here.  The few-column
-    kernel is exact fp32 throughout; the frame kernel measures max|V|, max|W| while staging and widens its refinement margin
+    kernel is exact fp32 throughout; the planes kernel builds its refinement margin from the operands' row statistics (max |x|, l2 norm)
     accordingly (round 2 assumed |V|, |W| <= 1).  Planted near-ties (exact gap ~1e-5 of the score scale) must come out like the
     fp64 arg-max in both index orders."""
     from nafae_amd import synthetic as syn
@@ -291,7 +291,7 @@ def test_sim_max_too_small_live_hint_is_loud(Ne, lens, hint):
             live_index[a * Ne + e] = n
             n += 1
     assert n > hint
-    # (the live-column route, hint <= 64, computes exactly `hint` columns; the frame kernel whole groups of 64)
+    # (the live-column route, hint <= 64, computes exactly `hint` columns; the planes kernel whole groups of 64)
     computed = (live_index >= 0) & (live_index < (hint if hint <= 64 else ((hint + 63) // 64) * 64))
     lost = (live_index >= 0) & ~computed
     assert lost.any() and torch.isnan(S[:, lost]).all() and (Di[:, lost] == 0).all()

@@ -64,8 +64,9 @@ def _ref64(V, W, lens, Na, Nb, Ne):
 @pytest.mark.parametrize("kind", ["bf16x3", "f16"])
 @pytest.mark.parametrize("cfg", [(8, 8, 300, 64), (8, 8, 256, 32), (8, 8, 128, 16), (2, 3, 700, 40)], ids=["C5", "C4", "C2x", "Nb700"])
 def test_planes_kernel_all_live_equals_round3_kernel(kind, cfg):
-    """Every slot live at the BASELINE shapes (and a frame of 700 proposals: three super-tiles): sim_planes_kernel == round 3's
-    sim_frame_kernel bit for bit (both end in the same exact-fp32 evaluation), and both match fp64 where fp64 is decided."""
+    """Every slot live at the BASELINE shapes (and a frame of 700 proposals: three super-tiles): planes attached by the caller ==
+    planes split by the entry point's own pre-pass (fp32 operands only) bit for bit, whatever the plane kind (every route ends in the
+    same exact-fp32 evaluation), and both match fp64 where fp64 is decided."""
     from nafae_amd import ops
     from nafae_amd import synthetic as syn
     Na, Ns, Nb, Ne = cfg
