@@ -13,6 +13,11 @@ lens = syn.entity_lengths(Na, Ne, seed=1234) if kind == "hist" else [Ne] * Na
 V, Wt = syn.embeddings(Na * Ns * Nb, Na * Ne, 512, seed=1)
 V, Wt = V.cuda(), Wt.cuda()
 lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+# the operand planes of the many-live-column kernel, as the embedding modules hand them over (written by their tanh epilogue, attached
+# to the tensors): produced once, outside the measured loop.  NAFAE_SIM_NO_PLANES=1: fp32 operands only (the entry point's pre-pass).
+if not os.environ.get("NAFAE_SIM_NO_PLANES"):
+    ops.attach_sim_planes(V, ops.sim_planes(V))
+    ops.attach_sim_planes(Wt, ops.sim_planes(Wt))
 ws = ops.loss_workspace(Na, Ns, Nb, Ne, 512, V.device)
 for _ in range(iters):
     S, D = ops.sim_max_fwd(V, Wt, lt, Na, Ns, Nb, Ne, lens=lens)
