@@ -370,7 +370,7 @@ int nafae_sim_bwd_frames(const float *dS, const int64_t *D_ind, const float *V, 
  * (SOF0, 8-bit, Huffman, one interleaved scan; 1 component, or 3 with luma sampling h0 x v0 in {1x1, 2x1, 2x2} and chroma 1x1;
  * optional restart intervals), decoded exactly as libjpeg does by default (jdhuff.c, jidctint.c ISLOW, jdsample.c fancy
  * upsampling, jdcolor.c), written as uint8 BGR [n, H, W, 3].  The host parses the header segments and passes, all in device memory:
- *   stream     the files' bytes back to back, every file starting at a multiple of 8, >= 16 bytes of padding after the last;
+ *   stream     the files' bytes back to back (pointer 16-byte aligned), >= 16 bytes of padding after the last file;
  *   img_desc   int32 [n][32]: [0] offset of the entropy-coded data in `stream`, [1] bytes from there to the end of the file,
  *              [2] restart interval in MCUs (0 = none), [3 + c] quantisation-table slot of component c,
  *              [6 + c] (DC table slot << 16) | AC table slot;

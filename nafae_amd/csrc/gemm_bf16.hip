@@ -367,45 +367,15 @@ struct EngineW4 {
   __device__ __forceinline__ int pn(int i, int g) const { return ww * 128 + i * 32 + 8 * g + 4 * (lane >> 5); }
 };
 
-template <bool PAIR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
-                       __bf16 *__restrict__ Clo, int ldc, const float *__restrict__ bias, int M, int N, int K, float alpha, int act,
-                       int tiles_m, int tiles_n) {
-  using E = EngineW4<PAIR>;
-  constexpr int STAGE_B = 512 * 128;           // bytes per LDS stage: (256 + 256) rows x 128 B (hi 32 | lo 32, or 64 plain k)
-  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
-  char *smem = reinterpret_cast<char *>(smem16);
-  E e;
-  e.init();
-  int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = K / BKH;                      // k-tiles: 32 (hi, lo) k, or 64 plain k
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- staging.  Chunk i of this thread = 16 B at LDS byte (tid + 256 i) * 16 of the stage: row (tid >> 3) + 32 i, physical slot
-  // tid & 7; the logical slot it must fetch undoes the read swizzle and is the same for all 16 chunks (32 i is 0 mod 16).
-  const int r0 = tid >> 3;
-  const int lsl = (tid & 7) ^ ((r0 >> 1) & 7); // plane * 4 + k-slot
-  // Everything that differs between the DMAs of a thread is UNIFORM (tile origin, chunk row step, k-tile, stage), so it travels in
-  // scalar registers: the per-lane offset is one constant VGPR per side, the source base and the LDS destination (M0) are scalar
-  // adds -- no vector instruction, no v_readfirstlane per DMA beside the only wave that feeds this SIMD's matrix pipe.
-  const unsigned xv = (unsigned)((((size_t)r0 * (2 * ldx)) + lsl * 8) * sizeof(__bf16));
-  const unsigned wv = (unsigned)((((size_t)r0 * (2 * ldw)) + lsl * 8) * sizeof(__bf16));
-  const char *xbase = reinterpret_cast<const char *>(Xil) + (size_t)m0 * (2 * ldx) * sizeof(__bf16);
-  const char *wbase = reinterpret_cast<const char *>(Wil) + (size_t)n0 * (2 * ldw) * sizeof(__bf16);
-  const size_t xstep = (size_t)32 * 2 * ldx * sizeof(__bf16), wstep = (size_t)32 * 2 * ldw * sizeof(__bf16);
-  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
-  auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index 0 .. 15 (0-7 activation side, 8-15 weight side)
-    // (M0, the LDS-DMA destination, is written and read inside ONE asm statement and declared clobbered; tests/test_build_isa.py
-    // disassembles the built object and asserts that this kernel touches M0 nowhere else)
-    const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
-    const char *b = (i < 8 ? xbase + (size_t)i * xstep : wbase + (size_t)(i - 8) * wstep) + (size_t)kt * (2 * BKH * sizeof(__bf16));
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? xv : wv), "s"(b) : "memory", "m0");
-#pragma clang diagnostic pop
-  };
+// The k-loop of that engine: nk >= 1 k-tiles through the two-stage ring.  `dma(i, kt, stage)` requests chunk i (compile-time: 0-7
+// rows 32 i .. of the activation side, 8-15 rows 32 (i - 8) .. of the weight side; thread t supplies row (t >> 3) of the 32, 16-byte
+// piece (t & 7) ^ ((t >> 4) & 7) of the line) of k-tile kt into `stage`; everything that differs between the DMAs of a thread has
+// to be UNIFORM there (scalar registers): the GEMM and the conv differ in nothing else.
+constexpr int W4_STAGE_B = 512 * 128;          // bytes per LDS stage: (256 + 256) rows x 128 B (hi 32 | lo 32, or 64 plain k)
+template <bool PAIR, class Dma>
+__device__ __forceinline__ void w4_kloop(EngineW4<PAIR> &e, char *smem, int nk, Dma dma) {
+  constexpr int STAGE_B = W4_STAGE_B;
+  const int lane = threadIdx.x & 63;
   // ---- fragments: lane (fr = lane & 31, h = lane >> 5) reads 16 B at logical slot plane * 4 + 2 s + h of its row
   const int fr = lane & 31, h = lane >> 5, sw = (fr >> 1) & 7;
   const int xrow = (e.wx * 128 + fr) * 128, wrow = (256 + e.ww * 128 + fr) * 128;   // byte offsets inside a stage
@@ -517,7 +487,189 @@ void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, f
     kt++;
   }
   tile(kt, std::false_type{}, std::false_type{});
+}
+
+template <bool PAIR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void bf16_gemm4_kernel(const __bf16 *Xil, int ldx, const __bf16 *Wil, int ldw, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                       __bf16 *__restrict__ Clo, int ldc, const float *__restrict__ bias, int M, int N, int K, float alpha, int act,
+                       int tiles_m, int tiles_n) {
+  using E = EngineW4<PAIR>;
+  constexpr int STAGE_B = W4_STAGE_B;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  char *smem = reinterpret_cast<char *>(smem16);
+  E e;
+  e.init();
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = K / BKH;                      // k-tiles: 32 (hi, lo) k, or 64 plain k
+  const int tid = threadIdx.x, wave = tid >> 6;
+  // ---- staging.  Chunk i of this thread = 16 B at LDS byte (tid + 256 i) * 16 of the stage: row (tid >> 3) + 32 i, physical slot
+  // tid & 7; the logical slot it must fetch undoes the read swizzle and is the same for all 16 chunks (32 i is 0 mod 16).
+  const int r0 = tid >> 3;
+  const int lsl = (tid & 7) ^ ((r0 >> 1) & 7); // plane * 4 + k-slot
+  // Everything that differs between the DMAs of a thread is UNIFORM (tile origin, chunk row step, k-tile, stage), so it travels in
+  // scalar registers: the per-lane offset is one constant VGPR per side, the source base and the LDS destination (M0) are scalar
+  // adds -- no vector instruction, no v_readfirstlane per DMA beside the only wave that feeds this SIMD's matrix pipe.
+  const unsigned xv = (unsigned)((((size_t)r0 * (2 * ldx)) + lsl * 8) * sizeof(__bf16));
+  const unsigned wv = (unsigned)((((size_t)r0 * (2 * ldw)) + lsl * 8) * sizeof(__bf16));
+  const char *xbase = reinterpret_cast<const char *>(Xil) + (size_t)m0 * (2 * ldx) * sizeof(__bf16);
+  const char *wbase = reinterpret_cast<const char *>(Wil) + (size_t)n0 * (2 * ldw) * sizeof(__bf16);
+  const size_t xstep = (size_t)32 * 2 * ldx * sizeof(__bf16), wstep = (size_t)32 * 2 * ldw * sizeof(__bf16);
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
+  auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index 0 .. 15 (0-7 activation side, 8-15 weight side)
+    // (M0, the LDS-DMA destination, is written and read inside ONE asm statement and declared clobbered; tests/test_build_isa.py
+    // disassembles the built object and asserts that this kernel touches M0 nowhere else)
+    const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
+    const char *b = (i < 8 ? xbase + (size_t)i * xstep : wbase + (size_t)(i - 8) * wstep) + (size_t)kt * (2 * BKH * sizeof(__bf16));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(i < 8 ? xv : wv), "s"(b) : "memory", "m0");
+#pragma clang diagnostic pop
+  };
+  w4_kloop<PAIR>(e, smem, nk, dma);
   epilogue<E, !PAIR>(e, m0, n0, M, N, alpha, bias, act, Cf, Chi, Clo, ldc);
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 conv on that engine
+// The long-K layers (Cin >= 256: K = 9 Cin = 2 304 / 4 608) as an implicit GEMM on the one-wave-per-SIMD engine.  A tile is 256
+// consecutive pixels in raster order x 256 output channels; k-tile kt = (channel chunk cc = kt / 9, tap = kt % 9) of the activation
+// side is the SAME pixel run shifted by (dy W + dx) pixels, so its address is uniform arithmetic as in the GEMM.  The conv padding
+// (and pixels beyond the tensor) is applied by the DMA itself: the activation side is fetched through a buffer resource
+// (buffer_load_dwordx4 ... offen lds), a lane whose source pixel is padding for this tap gets bit 31 set in its offset -- out of
+// range, and the DMA writes ZEROS for it (scripts/micro/buffer_lds_oob.hip checks exactly that on the chip).  No masks on the
+// fragments, no vector work beside the MFMAs except two instructions per activation DMA.
+// Schedule: stream-K over the launch's (tile, k-tile) list, tile-major, equal contiguous shares for gridDim.x workgroups; a tile
+// cut by a share boundary leaves fp32 partials in `scratch` and conv4_sk_fixup_kernel finishes it (same arithmetic and the same
+// determinism argument as conv3x3_run_sk_kernel).  gridDim.x == tiles: one whole tile per workgroup, no scratch.
+template <bool PAIR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void bf16_conv4_kernel(const __bf16 *X, const __bf16 *Wt, const float *__restrict__ bias, float *__restrict__ Cf,
+                       __bf16 *__restrict__ Chi, __bf16 *__restrict__ Clo, int F, int H, int W, int rowbytes, int Cout, int relu,
+                       int tiles_n, long U, float *__restrict__ scratch) {
+  using E = EngineW4<PAIR>;
+  constexpr int STAGE_B = W4_STAGE_B;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  char *smem = reinterpret_cast<char *>(smem16);
+  E e;
+  const int nkc = rowbytes >> 7, nk = 9 * nkc; // k-tiles per output tile: (32 (hi, lo) or 64 plain channels) x 9 taps
+  const int M = F * H * W;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int r0 = tid >> 3;
+  const int lsl = (tid & 7) ^ ((r0 >> 1) & 7);
+  const unsigned xv = (unsigned)r0 * (unsigned)rowbytes + (unsigned)lsl * 16u;
+  const unsigned wv = (unsigned)r0 * (unsigned)(9 * rowbytes) + (unsigned)lsl * 16u;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
+  // the resource starts (W + 1) pixels AHEAD of the tensor, so that the uniform offset of tap (dy, dx) in {0, 1, 2}^2 is >= 0
+  const unsigned shift = (unsigned)(W + 1) * (unsigned)rowbytes;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(X)) - shift, 0,
+                                                                       (int)(shift + (unsigned)M * (unsigned)rowbytes), 0x00020000);
+  const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
+  constexpr int NACC4 = E::NI * E::NJ * E::NG;
+  for (long u = u0; u < u1;) {
+    const int t = (int)(u / nk);
+    const int ka = (int)(u - (long)t * nk);
+    const int kb = (u1 - u) < (long)(nk - ka) ? ka + (int)(u1 - u) : nk;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;   // the n-tiles of one pixel run back to back
+    const int m0 = tm * 256, n0 = tn * 256;
+    if (u != u0) {
+      wait_vmcnt<0>();
+      __syncthreads();                                   // every wave is done with the previous segment's stages
+    }
+    e.init();
+    // bit 9 (i % 3) + tap of word i / 3: the source pixel of this thread's row r0 + 32 i is padding (or no pixel) for that tap
+    unsigned pad[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int m = m0 + r0 + 32 * i;
+      const int x = m % W, y = (m / W) % H;
+      unsigned mk = 0;
+#pragma unroll
+      for (int tp = 0; tp < 9; tp++) {
+        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+        if (m >= M || yy < 0 || yy >= H || xx < 0 || xx >= W) mk |= 1u << tp;
+      }
+      pad[i / 3] |= mk << (9 * (i % 3));
+    }
+    const char *wtile = reinterpret_cast<const char *>(Wt) + (size_t)n0 * (size_t)(9 * rowbytes);
+    auto dma = [&](int i, int kt, int stage) {
+      const int k = ka + kt;                             // uniform
+      const int cc = k / 9, tap = k - 9 * cc;
+      const unsigned m0v = lds0 + (unsigned)stage * STAGE_B + (unsigned)i * 4096;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+      if (i < 8) {
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const unsigned soff = (unsigned)(m0 + 32 * i + dy * W + dx) * (unsigned)rowbytes + (unsigned)cc * 128u;
+        const unsigned bit = __builtin_amdgcn_ubfe(pad[i / 3], (unsigned)(9 * (i % 3) + tap), 1u);
+        const unsigned voff = (bit << 31) | xv;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff), "s"(xr), "s"(soff)
+                     : "memory", "m0");
+      } else {
+        const char *b = wtile + (size_t)(32 * (i - 8)) * (size_t)(9 * rowbytes) + (size_t)tap * rowbytes + (size_t)cc * 128;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(wv), "s"(b) : "memory", "m0");
+      }
+#pragma clang diagnostic pop
+    };
+    w4_kloop<PAIR>(e, smem, kb - ka, dma);
+    if (ka == 0 && kb == nk) {
+      epilogue<E, !PAIR>(e, m0, n0, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout);
+    } else {
+      f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * 256 + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < E::NI; i++)
+#pragma unroll
+        for (int j = 0; j < E::NJ; j++)
+#pragma unroll
+          for (int g = 0; g < E::NG; g++) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
+            dst[(size_t)((i * E::NJ + j) * E::NG + g) * 256] = v;
+          }
+    }
+    u += kb - ka;
+  }
+}
+
+// One workgroup per (share boundary w, 32-pixel accumulator column j) of the kernel above; the boundary that is the FIRST one
+// strictly inside a tile owns that tile: it adds the contributors' partials in workgroup order and writes the tile.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void conv4_sk_fixup_kernel(const float *__restrict__ scratch, const float *__restrict__ bias,
+                                                             float *__restrict__ Cf, __bf16 *__restrict__ Chi,
+                                                             __bf16 *__restrict__ Clo, int M, int Cout, int relu, int tiles_n, int nk,
+                                                             long U, int G) {
+  using E = EngineW4<PAIR>;
+  const int w = blockIdx.x / E::NJ + 1, jsel = blockIdx.x - (w - 1) * E::NJ;
+  const long b = U * w / G;
+  const int t = (int)(b / nk);
+  const long t0 = (long)t * nk, t1 = t0 + nk;
+  if (b == t0) return;                       // the boundary lies on a tile edge
+  if (U * (w - 1) / G > t0) return;          // an earlier boundary lies strictly inside this tile and owns it
+  constexpr int NACC4 = E::NI * E::NJ * E::NG;
+  E e;
+  e.init();
+  for (int c = w - 1; c < G; c++) {
+    const long c0 = U * c / G;
+    if (c0 >= t1) break;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * 256 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < E::NI; i++)
+#pragma unroll
+      for (int j = 0; j < E::NJ; j++) {
+        if (j != jsel) continue;
+#pragma unroll
+        for (int g = 0; g < E::NG; g++) {
+          const f32x4 v = src[(size_t)((i * E::NJ + j) * E::NG + g) * 256];
+#pragma unroll
+          for (int q = 0; q < 4; q++) e.acc[i][j][4 * g + q] += v[q];
+        }
+      }
+  }
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  epilogue<E, !PAIR>(e, tm * 256, tn * 256, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout, jsel,
+                     jsel + 1);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv
@@ -1490,6 +1642,44 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   return launched();
 }
 
+// conv4: stream-K on G workgroups when `scratch` is there (cut tiles need it), else one whole tile per workgroup
+// OFF by default: measured SLOWER than the 8-wave run-reuse kernels on every long-K layer (C3, plain bf16: 256->256@56^2 0.328 against
+// 0.270 ms, 512->512@28^2 0.263 / 0.237; bf16x3: 0.595 / 0.573, 0.549 / 0.535 -- DESIGN.md, round-4 log: without the run reuse the
+// activation side costs three times the LDS-DMAs, and those are what stalls the one wave that feeds a SIMD).  NAFAE_CONV4=1 in the
+// experiments build selects it (tests/test_gpu_bf16.py keeps it correct against the 8-wave kernels).
+inline bool use_conv4() {
+  const char *e = nafae::experiment_env("NAFAE_CONV4");
+  return e && e[0] == '1';
+}
+inline bool conv4_shape(int M, int Cin, int Cout, int rowbytes) {
+  return Cin >= 256 && rowbytes % 128 == 0 && Cout % 256 == 0 && M >= 256 && (long)(M + 2 * 8192) * rowbytes < (1L << 31) &&
+         (long)Cout * 9 * rowbytes < (1L << 31);
+}
+template <bool PAIR>
+int launch_conv4(const void *X, const void *Wt, const float *bias, float *Cf, void *Chi, void *Clo, int F, int H, int W, int rowbytes,
+                 int Cout, int relu, float *scratch, int64_t scratch_bytes, hipStream_t st) {
+  const int M = F * H * W;
+  const int tiles_m = (M + 255) / 256, tiles_n = Cout / 256;
+  const int nk = 9 * (rowbytes / 128);
+  const long tiles = (long)tiles_m * tiles_n, U = tiles * nk;
+  int G = num_cus();
+  if (U / 8 < G) G = (int)(U / 8 > 0 ? U / 8 : 1);        // shares of at least eight k-tiles (and never an empty one: the fix-up reads every slot)
+  const char *ske = nafae::experiment_env("NAFAE_CONV_SK");
+  const bool cut = scratch && scratch_bytes >= (int64_t)sk_scratch_bytes(256, 256, G) && !(ske && ske[0] == '0') && tiles % G != 0;
+  if (!cut) G = (int)tiles;
+  auto kern = bf16_conv4_kernel<PAIR>;
+  NAFAE_TAG("bf16_conv4<pair=%d>%s", (int)PAIR, cut ? " + fixup" : "");
+  const size_t lds = 2 * W4_STAGE_B;
+  if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, (const __bf16 *)X, (const __bf16 *)Wt, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F,
+                     H, W, rowbytes, Cout, relu, tiles_n, U, scratch);
+  if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
+  if (!cut) return NAFAE_OK;
+  hipLaunchKernelGGL(conv4_sk_fixup_kernel<PAIR>, dim3((G - 1) * 4), dim3(256), 0, st, scratch, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo,
+                     M, Cout, relu, tiles_n, nk, U, G);
+  return launched();
+}
+
 template <bool PAIR, bool POOL = false>
 int launch_conv_patch(const void *Xhi, const void *Whi, const float *bias, void *Chi, void *Clo, int F, int H, int W,
                       int Cin, int Cout, int relu, hipStream_t st) {
@@ -1606,6 +1796,9 @@ int64_t nafae_conv3x3_bf16_workspace_bytes(int F, int H, int W, int Cin, int Cou
   if (F <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (long)F * H * W >= (1L << 31)) return NAFAE_EINVAL;
   if (Cout <= 64 || Cin % 32) return 0;
   const int M = F * H * W, G = num_cus();
+  // (the one-wave-per-SIMD conv cuts tiles whenever their count is not a multiple of the workgroup count, also below it)
+  if (use_conv4() && conv4_shape(M, Cin, Cout, Cin * 4) && ((long)((M + 255) / 256) * (Cout / 256)) % G != 0)
+    return (int64_t)sk_scratch_bytes(256, 256, G);
   const int bw = (Cout >= 256 && M >= 256 * 128) ? 256 : 128;
   const long tiles = (long)((M + 255) / 256) * ((Cout + bw - 1) / bw);
   return sk_pays(tiles, G) ? (int64_t)sk_scratch_bytes(256, bw, G) : 0;
@@ -1646,6 +1839,9 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
                              : launch_conv_patch<false>(in_hi, w_hi, bias, out_hi, out_lo, F, H, W, Cin, Cout, relu, S(stream));
         if (relu & 16) return NAFAE_ELIMIT;   // fused max-pool exists in the patch kernel only: the caller pools separately
       }
+      if (il && use_conv4() && conv4_shape(M, Cin, Cout, Cin * 4) && (!out_hi || (out_lo && host_il(out_hi, out_lo))))
+        return launch_conv4<false>(in_hi, w_hi, bias, out_f32, out_hi, out_lo, F, H, W, Cin * 4, Cout, relu, (float *)workspace,
+                                   workspace_bytes, S(stream));
       if (Cout <= 64) {
         // (round 2's one-barrier-per-3-taps kernel for this case, conv3x3_run3_kernel, left in round 4: the 64-channel layers of
         // every frame size that is a multiple of 16 take the patch kernel above; what remains here are odd sizes and fp32 outputs)
@@ -1703,6 +1899,9 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
           return (relu & 16) ? launch_conv_patch<true, true>(in_hi, w_hi, bias, out_hi, nullptr, F, H, W, Ce, Cout, relu, S(stream))
                              : launch_conv_patch<true>(in_hi, w_hi, bias, out_hi, nullptr, F, H, W, Ce, Cout, relu, S(stream));
         if (relu & 16) return NAFAE_ELIMIT;
+        if (use_conv4() && conv4_shape(M, Cin, Cout, Cin * 2))
+          return launch_conv4<true>(in_hi, w_hi, bias, out_f32, out_hi, nullptr, F, H, W, Cin * 2, Cout, relu, (float *)workspace,
+                                    workspace_bytes, S(stream));
         if (Cout >= 256 && M >= 256 * 128) {
           if (workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 255) / 256), G) &&
               workspace_bytes >= (int64_t)sk_scratch_bytes(256, 256, G))

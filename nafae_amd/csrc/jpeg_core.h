@@ -53,35 +53,47 @@ NAFAE_HD Geom make_geom(int W, int H, int ncomp, int h0, int v0) {
 }
 
 // ---------------------------------------------------------------------------------------------------- entropy decoding
+// The entropy-coded bytes are read through `buf[i & mask]`: on the GPU `buf` is a ring in LDS that the wave refills between MCUs
+// (jpeg.hip), on the host it is the stream itself (mask = all ones).  `pos` / `lim`: next unread byte and the end of the data, as
+// indices.  jdhuff.c jpeg_fill_bit_buffer: FF 00 is a stuffed FF, any other FF xx ends the interval (zero bits from there on).
 struct BitReader {
-  const unsigned char *p, *end;      // next unread byte of the stream / its end
-  unsigned long long win;            // the 8 bytes at (p & ~7), little endian
+  const unsigned char *buf;
+  unsigned mask, pos, lim;
   unsigned long long acc;            // bit reservoir, newest bits at the bottom
   int nbits;
   bool marker;                       // a marker was reached: zeros from here on (jdhuff.c: "fill with zero bits")
 
-  NAFAE_HD void init(const unsigned char *s, const unsigned char *e) {
-    p = s; end = e; acc = 0; nbits = 0; marker = false;
-    win = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)7);
+  NAFAE_HD void init(const unsigned char *b, unsigned m, unsigned p0, unsigned l) {
+    buf = b; mask = m; pos = p0; lim = l; acc = 0; nbits = 0; marker = false;
   }
-  NAFAE_HD unsigned raw() {   // next stream byte (0 beyond the end)
-    if (p >= end) { marker = true; return 0; }
-    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p) & 7) * 8;
-    const unsigned b = (unsigned)(win >> sh) & 0xffu;
-    p++;
-    if ((reinterpret_cast<uintptr_t>(p) & 7) == 0) win = *reinterpret_cast<const unsigned long long *>(p);   // (the buffer is padded)
-    return b;
-  }
+  NAFAE_HD unsigned byte_at(unsigned i) const { return buf[i & mask]; }
+  // at least 32 valid bits afterwards (a Huffman code is at most 16 bits, a value at most 16)
   NAFAE_HD void fill() {
-    while (nbits <= 48) {
+    if (nbits >= 32) return;
+    if (!marker && pos + 4 <= lim) {                       // four bytes at once unless one of them is FF
+      const unsigned w = (byte_at(pos) << 24) | (byte_at(pos + 1) << 16) | (byte_at(pos + 2) << 8) | byte_at(pos + 3);
+      const unsigned v = ~w;
+      if (((v - 0x01010101u) & ~v & 0x80808080u) == 0) {   // no zero byte in ~w
+        acc = (acc << 32) | w;
+        nbits += 32;
+        pos += 4;
+        return;
+      }
+    }
+    while (nbits < 32) {
       unsigned b = 0;
       if (!marker) {
-        b = raw();
-        if (b == 0xffu) {
-          const unsigned b2 = raw();
-          if (b2 != 0) {               // RSTn / EOI / anything else: the interval's data ends here
-            marker = true;
-            b = 0;
+        if (pos >= lim) {
+          marker = true;
+        } else {
+          b = byte_at(pos++);
+          if (b == 0xffu) {
+            const unsigned b2 = pos < lim ? byte_at(pos) : 0xd9u;
+            pos++;
+            if (b2 != 0) {             // RSTn / EOI / anything else: the interval's data ends here
+              marker = true;
+              b = 0;
+            }
           }
         }
       }
@@ -117,47 +129,146 @@ NAFAE_HD int huff_decode(BitReader &br, const int *tab) {
 
 NAFAE_HD int huff_extend(int r, int s) { return r < (1 << (s - 1)) ? r - (1 << s) + 1 : r; }
 
-
-// One restart interval: MCUs [m0, m1) of image-local coefficient array `cimg` (int16 [g.nblk][64], zero-initialised), entropy data
-// at [s, e).  tabs: the component's Huffman records, [2 c] = DC, [2 c + 1] = AC, HT_INTS ints each; nat: the zigzag -> natural map.
-NAFAE_HD void huffman_interval(const unsigned char *s, const unsigned char *e, const int *tabs, const unsigned char *nat, const Geom &g,
-                               int m0, int m1, short *cimg) {
-  BitReader br;
-  br.init(s, e);
-  int pred[3] = {0, 0, 0};
-  for (int mcu = m0; mcu < m1; mcu++) {
-    const int y0 = mcu / g.mx, x0 = mcu - y0 * g.mx;
-    for (int c = 0; c < g.ncomp; c++) {
-      const int h = c == 0 ? g.h0 : 1, v = c == 0 ? g.v0 : 1;
-      const int *dct = tabs + (2 * c) * HT_INTS, *act = tabs + (2 * c + 1) * HT_INTS;
-      for (int by = 0; by < v; by++)
-        for (int bx = 0; bx < h; bx++) {
-          short *blk = cimg + ((size_t)g.boff[c] + (size_t)(y0 * v + by) * g.bx[c] + (x0 * h + bx)) * 64;
-          int sy = huff_decode(br, dct);
+// One MCU (jdhuff.c decode_mcu) of image-local coefficient array `cimg` (int16 [g.nblk][64], zero-initialised).  tabs: the
+// components' Huffman records, [2 c] = DC, [2 c + 1] = AC, HT_INTS ints each; nat: the zigzag -> natural map; pred: the DC predictions.
+// An MCU consumes at most 6 blocks x 64 x 26 bits = 1 248 bytes, twice that with every byte stuffed.
+NAFAE_HD void huffman_mcu(BitReader &br, const int *tabs, const unsigned char *nat, const Geom &g, int mcu, int (&pred)[3], short *cimg) {
+  const int y0 = mcu / g.mx, x0 = mcu - y0 * g.mx;
+  for (int c = 0; c < g.ncomp; c++) {
+    const int h = c == 0 ? g.h0 : 1, v = c == 0 ? g.v0 : 1;
+    const int *dct = tabs + (2 * c) * HT_INTS, *act = tabs + (2 * c + 1) * HT_INTS;
+    for (int by = 0; by < v; by++)
+      for (int bx = 0; bx < h; bx++) {
+        short *blk = cimg + ((size_t)g.boff[c] + (size_t)(y0 * v + by) * g.bx[c] + (x0 * h + bx)) * 64;
+        int sy = huff_decode(br, dct);
+        if (sy) {
+          br.fill();
+          pred[c] += huff_extend(br.get(sy), sy);
+        }
+        blk[0] = (short)pred[c];
+        for (int k = 1; k < 64;) {
+          const int rs = huff_decode(br, act);
+          const int r = rs >> 4;
+          sy = rs & 15;
           if (sy) {
+            k += r;
             br.fill();
-            pred[c] += huff_extend(br.get(sy), sy);
-          }
-          blk[0] = (short)pred[c];
-          for (int k = 1; k < 64;) {
-            const int rs = huff_decode(br, act);
-            const int r = rs >> 4;
-            sy = rs & 15;
-            if (sy) {
-              k += r;
-              br.fill();
-              const int val = huff_extend(br.get(sy), sy);
-              if (k < 64) blk[nat[k]] = (short)val;
-              k++;
-            } else if (r == 15) {
-              k += 16;
-            } else {
-              break;
-            }
+            const int val = huff_extend(br.get(sy), sy);
+            if (k < 64) blk[nat[k]] = (short)val;
+            k++;
+          } else if (r == 15) {
+            k += 16;
+          } else {
+            break;
           }
         }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- parallel entropy decoding
+// The same decoding by MANY lanes per restart interval (self-synchronising Huffman decoding: a decoder started at a wrong place of a
+// Huffman-coded stream falls into step with the right one after a few symbols).  The interval's bytes are first compacted -- stuffed
+// zeros removed, cut at the first marker -- into big-endian 32-bit words `d32`, so that a position is a plain bit index and a reader
+// carries no state.  Lane i owns the bits [i S, (i + 1) S): round 0 decodes them from a guessed state (block 0, DC next), every later
+// round re-decodes them from the exit state of lane i - 1, until no exit state changes -- then every lane's entry state is the
+// sequential decoder's (lane 0's always was).  A prefix sum of the MCUs each lane completed gives it its absolute position, a last
+// pass writes the coefficients (DC as DIFFERENCES: the predictions are a prefix sum over the blocks afterwards).
+struct SpanState {
+  unsigned bp;                       // next unread bit
+  int b, k;                          // block inside the MCU, next coefficient (0: the DC symbol comes next)
+};
+NAFAE_HD bool same_state(const SpanState &a, const SpanState &b) { return a.bp == b.bp && a.b == b.b && a.k == b.k; }
+
+// 32 bits from bit bp on (MSB first); d32 has two zero words beyond the data
+NAFAE_HD unsigned peek32(const uint32_t *d32, unsigned bp) {
+  const unsigned j = bp >> 5, sh = bp & 31;
+  const unsigned long long w = ((unsigned long long)d32[j] << 32) | d32[j + 1];
+  return (unsigned)((w << sh) >> 32);
+}
+// the symbol whose code starts at the top of v; len: its code length
+NAFAE_HD int huff_peek(unsigned v, const int *tab, int &len) {
+  const unsigned e = reinterpret_cast<const unsigned short *>(tab)[v >> (32 - LOOK)];
+  if (e) {
+    len = (int)(e >> 8);
+    return (int)(e & 0xffu);
+  }
+  const unsigned code16 = v >> 16;
+  for (int l = LOOK + 1; l <= 16; l++) {
+    const int c = (int)(code16 >> (16 - l));
+    if (c <= tab[256 + l]) {
+      len = l;
+      return (int)reinterpret_cast<const unsigned char *>(tab + 292)[(c + tab[274 + l]) & 255];
     }
   }
+  len = 16;                          // corrupt data: consume and carry on, as huff_decode does
+  return 0;
+}
+
+// Decode symbols from state `s` while s.bp < end_bp (and < total_bits); returns the MCUs completed.  WRITE: store the coefficients of
+// MCUs [.., mcu_end) -- `mcu` is the index (inside the image) of the MCU the state is in.
+template <bool WRITE>
+NAFAE_HD int span_decode(const uint32_t *d32, unsigned total_bits, unsigned end_bp, SpanState &s, const int *tabs, const unsigned char *nat,
+                         const Geom &g, int mcu, int mcu_end, short *cimg) {
+  const int ny = g.h0 * g.v0, nb = g.ncomp == 1 ? 1 : ny + 2;
+  const unsigned stop = end_bp < total_bits ? end_bp : total_bits;
+  int done = 0;
+  unsigned bp = s.bp;
+  int b = s.b, k = s.k;
+  while (bp < stop) {
+    const int c = b < ny ? 0 : b - ny + 1;
+    const unsigned v = peek32(d32, bp);
+    int len;
+    if (k == 0) {
+      const int sy = huff_peek(v, tabs + (2 * c) * HT_INTS, len) & 15;
+      int diff = 0;
+      if (sy) diff = huff_extend((int)((v << len) >> (32 - sy)), sy);
+      bp += (unsigned)(len + sy);
+      if (WRITE && mcu < mcu_end) {
+        const int y0 = mcu / g.mx, x0 = mcu - y0 * g.mx;
+        const int h = c == 0 ? g.h0 : 1, vv = c == 0 ? g.v0 : 1, by = c == 0 ? b / g.h0 : 0, bx = c == 0 ? b - by * g.h0 : 0;
+        cimg[((size_t)g.boff[c] + (size_t)(y0 * vv + by) * g.bx[c] + (x0 * h + bx)) * 64] = (short)diff;
+      }
+      k = 1;
+    } else {
+      const int rs = huff_peek(v, tabs + (2 * c + 1) * HT_INTS, len);
+      const int r = rs >> 4, sy = rs & 15;
+      if (sy) {
+        k += r;
+        const int val = huff_extend((int)((v << len) >> (32 - sy)), sy);
+        if (WRITE && k < 64 && mcu < mcu_end) {
+          const int y0 = mcu / g.mx, x0 = mcu - y0 * g.mx;
+          const int h = c == 0 ? g.h0 : 1, vv = c == 0 ? g.v0 : 1, by = c == 0 ? b / g.h0 : 0, bx = c == 0 ? b - by * g.h0 : 0;
+          cimg[((size_t)g.boff[c] + (size_t)(y0 * vv + by) * g.bx[c] + (x0 * h + bx)) * 64 + nat[k]] = (short)val;
+        }
+        k++;
+        bp += (unsigned)(len + sy);
+      } else {
+        bp += (unsigned)len;
+        k = r == 15 ? k + 16 : 64;   // ZRL / end of block
+      }
+    }
+    if (k >= 64) {
+      k = 0;
+      if (++b == nb) {
+        b = 0;
+        mcu++;
+        done++;
+      }
+    }
+  }
+  s.bp = bp;
+  s.b = b;
+  s.k = k;
+  return done;
+}
+
+// block n (decode order) of component c inside an interval that starts at MCU m0 -> its index in the image's coefficient array
+NAFAE_HD size_t dc_block(const Geom &g, int c, int m0, int n) {
+  const int h = c == 0 ? g.h0 : 1, v = c == 0 ? g.v0 : 1;
+  const int per = h * v, mcu = m0 + n / per, sub = n - (n / per) * per;
+  const int y0 = mcu / g.mx, x0 = mcu - y0 * g.mx, by = sub / h, bx = sub - by * h;
+  return (size_t)g.boff[c] + (size_t)(y0 * v + by) * g.bx[c] + (x0 * h + bx);
 }
 
 // ---------------------------------------------------------------------------------------------------- inverse DCT

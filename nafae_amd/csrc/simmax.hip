@@ -26,6 +26,9 @@ namespace nafae_sim {          // simfused.hip
 int64_t few_workspace_bytes(int F, int Nb, int Q);
 int launch_few(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Lh, float *S_max,
                int64_t *D_ind, void *workspace, hipStream_t st);
+int launch_planes_narrow(const float *V, const float *W, const void *Vp, const void *Wp, const float *vstat, const float *wstat,
+                         const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh, float *S_max, int64_t *D_ind,
+                         hipStream_t st);
 int64_t planes_scratch_bytes(int R, int Q, int D);
 int launch_frames_prepass(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh,
                           float *S_max, int64_t *D_ind, void *scratch, hipStream_t st);
@@ -103,6 +106,19 @@ int nafae_sim_max_fwd_planes(const float *V, const float *W, const int32_t *ent_
   int Qh = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
   if (Qh < 1) Qh = 1;
   const bool have = V_planes && V_stats && W_planes && W_stats;
+  // few live columns + fp16 planes (what the embedding modules attach) + LONG frames: the narrow planes kernel.  Measured (hipGraph of
+  // back-to-back calls, data set's entity histogram): C5 (300 proposals) 17.0 us against sim_live_kernel's 17.9, C4 (256) 13.8 / 15.4,
+  // C2 (128) 13.5 / 11.4 -- one workgroup per frame streams half the bytes but has the whole frame's latency chain to itself, so
+  // short frames stay on the fp32 live-column kernel, which splits a frame over row-block workgroups.  (NAFAE_SIM_NARROW=0/1 in the
+  // experiments build forces one or the other.)
+  {
+    const char *ne = nafae::experiment_env("NAFAE_SIM_NARROW");
+    const bool narrow_on = ne ? ne[0] != '0' : Nb >= 224;
+    if (have && narrow_on && kind == NAFAE_SIMPLANES_F16 && Qh <= 64 && Nb > 32 && D % 128 == 0 && D <= 512 && Na <= NA_MAX &&
+        (long)Nb * D < (1L << 30) && (long)Q * D < (1L << 30))
+      return nafae_sim::launch_planes_narrow(V, W, V_planes, W_planes, V_stats, W_stats, ent_len, F, Nb, Na, Ne, D, Qh, S_max, D_ind,
+                                             as_stream(stream));
+  }
   // (the kernel takes the 128-byte lines of a row two at a time: D % 128 == 0 for fp16 planes, D % 64 == 0 for bf16x3 ones)
   if (have && fused_route(F, Nb, Na, Ne, D, Qh) == 2 && D % (kind == NAFAE_SIMPLANES_F16 ? 128 : 64) == 0)
     return nafae_sim::launch_planes_frames(V, W, V_planes, W_planes, V_stats, W_stats, kind, ent_len, F, Nb, Na, Ne, D, Qh, S_max,

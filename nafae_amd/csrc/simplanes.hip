@@ -169,14 +169,14 @@ __device__ __forceinline__ void mask_row(float &v, int lim, float ninf) {
 struct PlanesLds {
   int qmap, wst, wam, cmax, cflag, ccnt, clist, vst, prefix, total;
 };
-template <int RT, int GC>
+template <int RT, int GC, int WR, int NST>
 __host__ __device__ inline PlanesLds planes_lds(int Na) {
   PlanesLds o;
-  int p = 2 * (RT + GC) * 128;                 // [2 stages][(RT + GC) rows][128 B]; after the k-loops: the exact phase's lists
+  int p = NST * (RT + GC) * 128;               // [NST stages][(RT + GC) rows][128 B]; after the k-loops: the exact phase's lists
   o.qmap = p;   p += GC * 4;                   // live column -> query row (-1: beyond the live count)
   o.wst = p;    p += GC * 4;                   // the column's W statistic the margin uses
   o.wam = p;    p += GC * 4;                   // the column's max |w| (fp16 planes: range check)
-  o.cmax = p;   p += 2 * GC * 4;               // [row half][column] filter maximum of the current super-tile
+  o.cmax = p;   p += WR * GC * 4;              // [row part][column] filter maximum of the current super-tile
   o.cflag = p;  p += GC * 4;                   // bit 0: NaN / Inf seen, bit 1: more than PL_LANEC hits in one lane
   o.ccnt = p;   p += GC * 4;                   // listed candidates
   o.clist = p;  p += GC * PL_MAXC * 4;         // their rows
@@ -188,20 +188,27 @@ __host__ __device__ inline PlanesLds planes_lds(int Na) {
 
 // grid ceil(F/8)*8*G workgroups of 512 threads (one per CU); workgroup = (frame f, column group g); the G workgroups of a frame
 // share an XCD (blockIdx % 8), so the second to G-th pass over the frame's planes can hit its L2.
-template <int RW, int CW, int KIND>
+// WR: how the four MFMA waves split the tile -- 2: two row halves x two column halves (many live columns: 64 CW per workgroup);
+//     4: four row quarters x ONE 32-column block (few live columns, round 4: the frame's rows stream ONCE, against 32 columns).
+// NST: stages of the LDS ring = lines of look-ahead + 1.  With two stages a trip costs DMA issue + the FULL latency of its line
+//     (1.06 us per 57 KB line at C5); where the stage is small enough for more (the narrow form: 20 KB at 128 rows, 37 KB at 256),
+//     the lines of the next NST - 2 trips are already in flight and the wait is counted (vmcnt).
+template <int RW, int CW, int KIND, int WR = 2, int NST = 2>
 __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict__ V, const float *__restrict__ Wm,
                                                          const unsigned char *__restrict__ Vp, const unsigned char *__restrict__ Wp,
                                                          const float *__restrict__ vstat, const float *__restrict__ wstat,
                                                          const int32_t *__restrict__ ent_len, int F, int Nb, int Na, int Ne, int D,
                                                          int G, float *__restrict__ S_max, int64_t *__restrict__ D_ind, int dbg) {
-  constexpr int RT = 2 * RW * 32;            // rows per super-tile (two row halves)
-  constexpr int GC = 64 * CW;                // live columns per workgroup (two column halves)
+  constexpr int WC = 4 / WR;                 // column parts among the MFMA waves
+  static_assert(WR == 2 || WR == 4, "row parts");
+  constexpr int RT = WR * RW * 32;           // rows per super-tile
+  constexpr int GC = WC * 32 * CW;           // live columns per workgroup
   constexpr int STAGE = (RT + GC) * 128;
   constexpr int CK = KIND == KIND_F16 ? 64 : 32;      // k per 128-byte line
   constexpr int ST = KIND == KIND_F16 ? 1 : 0;        // which row statistic the margin uses (1: l2 norm, 0: max |x|)
   (void)dbg;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const PlanesLds lo = planes_lds<RT, GC>(Na);
+  const PlanesLds lo = planes_lds<RT, GC, WR, NST>(Na);
   int *qmap = reinterpret_cast<int *>(smem + lo.qmap);
   float *wst = reinterpret_cast<float *>(smem + lo.wst);
   float *wam = reinterpret_cast<float *>(smem + lo.wam);
@@ -218,6 +225,32 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
   const int Q = Na * Ne;
   const int nch = D / CK;
   const int rowbytes = nch * 128;
+
+  // The staging waves request the V part of the first NST - 1 lines before anything else: it depends on the launch arguments only,
+  // and the prologue below (prefix sums, column map, the frame's statistics: 1.0-1.3 us) then runs under the loads' latency.
+  constexpr int NV = RT / 32, NW = GC / 32;    // DMAs per staging wave and line: instruction n = j * 4 + sw covers stage rows [8n, 8n + 8)
+  constexpr int PER = NV + NW;
+  const unsigned char *Vpf = Vp + (size_t)f * Nb * rowbytes;
+  auto v_offsets = [&](int rt, unsigned (&voff)[NV]) {
+    const int sw = wave - 4, lr8 = lane >> 3, ls = lane & 7;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int sr = (j * 4 + sw) * 8 + lr8;
+      int row = rt * RT + sr;
+      row = row < Nb ? row : Nb - 1;           // (a row beyond the frame re-reads its last row; masked before the scan)
+      voff[j] = (unsigned)row * (unsigned)rowbytes + (unsigned)((ls ^ frame_swz(sr)) << 4);
+    }
+  };
+  auto issue_v = [&](int ci, const unsigned (&voff)[NV]) {       // V rows of line ci -> stage ci % NST
+    unsigned char *st = smem + (ci % NST) * STAGE + (wave - 4) * 1024;
+#pragma unroll
+    for (int j = 0; j < NV; j++) lds_dma16(Vpf + (size_t)ci * 128, voff[j], st + j * 4096);
+  };
+  if (wave >= 4) {
+    unsigned voff[NV];
+    v_offsets(0, voff);
+    for (int ci = 0; ci < NST - 1 && ci < nch; ci++) issue_v(ci, voff);
+  }
 
   build_prefix(ent_len, Na, Ne, prefix);
   if (tid < GC) {
@@ -240,7 +273,10 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
       }
     }
   }
-  if (g * GC >= Ql) return;                  // over-provisioned column group
+  if (g * GC >= Ql) {                        // over-provisioned column group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (no LDS-DMA may be in flight when the workgroup's LDS is released)
+    return;
+  }
   if (tid < GC) {
     const int c = g * GC + tid;
     int q = -1;
@@ -276,7 +312,6 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
   const float vst = __int_as_float(vsti[0]), vam = __int_as_float(vsti[1]);
   (void)vam;
   const float *Vf = V + (size_t)f * Nb * D;
-  const unsigned char *Vpf = Vp + (size_t)f * Nb * rowbytes;
   const int nsuper = (Nb + RT - 1) / RT;
   PSTAMP(0);
 
@@ -288,7 +323,6 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
     // form.  With the MFMAs compiled out the DMA loop alone runs at 0.7 us per chunk = 82 GB/s into one CU.)
     const int sw = wave - 4;
     const int lr8 = lane >> 3, ls = lane & 7;
-    constexpr int NV = 2 * RW, NW = 2 * CW;    // DMAs per wave and chunk: instruction n = j * 4 + sw covers stage rows [8n, 8n + 8)
     unsigned woff[NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) {
@@ -298,29 +332,35 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
     }
     for (int rt = 0; rt < nsuper; rt++) {
       unsigned voff[NV];
+      v_offsets(rt, voff);
+      auto issue_w = [&](int ci) {
+        unsigned char *st = smem + (ci % NST) * STAGE + sw * 1024;
 #pragma unroll
-      for (int j = 0; j < NV; j++) {
-        const int sr = (j * 4 + sw) * 8 + lr8;
-        int row = rt * RT + sr;
-        row = row < Nb ? row : Nb - 1;
-        voff[j] = (unsigned)row * (unsigned)rowbytes + (unsigned)((ls ^ frame_swz(sr)) << 4);
-      }
-      auto issue = [&](int ci, int stage) {
-        unsigned char *st = smem + stage * STAGE + sw * 1024;
-        const unsigned char *vb = Vpf + (size_t)ci * 128, *wb = Wp + (size_t)ci * 128;
-#pragma unroll
-        for (int j = 0; j < NV; j++) lds_dma16(vb, voff[j], st + j * 4096);
-#pragma unroll
-        for (int j = 0; j < NW; j++) lds_dma16(wb, woff[j], st + RT * 128 + j * 4096);
+        for (int j = 0; j < NW; j++) lds_dma16(Wp + (size_t)ci * 128, woff[j], st + RT * 128 + j * 4096);
       };
-      issue(0, 0);
-      if (rt > 0) lds_barrier();               // (X1 of the previous super-tile)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();                           // chunk 0 has landed
+      auto issue = [&](int ci) {               // line ci -> stage ci % NST
+        issue_v(ci, voff);
+        issue_w(ci);
+      };
+      // (the stages are free: their last readers passed the previous super-tile's last trip barrier)
+      // (super-tile 0: the V rows of these lines were requested at the top of the kernel; all of them have to land with line 0's W
+      // rows, as the counter sees them in issue order -- they have had the prologue's time)
+      for (int ci = 0; ci < NST - 1 && ci < nch; ci++) {
+        if (rt > 0) issue_v(ci, voff);
+        issue_w(ci);
+      }
+      if (rt > 0) lds_barrier();               // (X1 of the previous super-tile: the MFMA waves exchange their column maxima)
+      if (NST > 2 && nch >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();                           // line 0 has landed
       PSTAMP(1);
-      for (int ci = 0; ci < nch; ci++) {
-        if (ci + 1 < nch) issue(ci + 1, (ci + 1) & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int ci = 0; ci < nch; ci++) {       // trip ci: the MFMA waves compute line ci; request line ci + NST - 1, wait for line ci + 1
+        if (ci + NST - 1 < nch) {
+          issue(ci + NST - 1);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         lds_barrier();
       }
       PSTAMP(2);
@@ -329,7 +369,7 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
   } else {
     // ================================================================ MFMA waves
     const int lr = lane & 31, h = lane >> 5;
-    const int rh = (wave >> 1) & 1, ch = wave & 1;
+    const int rh = WR == 4 ? wave : (wave >> 1) & 1, ch = WR == 4 ? 0 : wave & 1;
     const int aswz = frame_swz(lr);
     const int a_base = (rh * RW * 32 + lr) * 128;
     const int b_base = (RT + ch * CW * 32 + lr) * 128;
@@ -357,7 +397,7 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
       lds_barrier();                           // chunk 0 is in its stage
       PSTAMP(1);
       for (int ci = 0; ci < nch; ci++) {
-        const unsigned char *st = smem + (ci & 1) * STAGE;      // (nch is even: every super-tile starts in stage 0)
+        const unsigned char *st = smem + (ci % NST) * STAGE;
 #ifdef NAFAE_EXPERIMENTS
         if (dbg & 2) {                         // timing experiment: no fragment reads, no MFMAs
           lds_barrier();
@@ -451,7 +491,10 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
 #pragma unroll
       for (int cb = 0; cb < CW; cb++) {
         const int c = (ch * CW + cb) * 32 + lr;
-        bmr[cb] = fmaxf(bmr[cb], fmaxf(cmax[c], cmax[GC + c]));
+        float tmx = cmax[c];
+#pragma unroll
+        for (int p2 = 1; p2 < WR; p2++) tmx = fmaxf(tmx, cmax[p2 * GC + c]);
+        bmr[cb] = fmaxf(bmr[cb], tmx);
         const float bm = bmr[cb];
         float margin;
         if (KIND == KIND_F16) {
@@ -659,25 +702,25 @@ __global__ __launch_bounds__(512) void sim_planes_kernel(const float *__restrict
   PSTAMP(6);
 }
 
-template <int RW, int CW, int KIND>
+template <int RW, int CW, int KIND, int WR = 2, int NST = 2>
 int launch_planes(const float *V, const float *W, const unsigned char *Vp, const unsigned char *Wp, const float *vstat,
                   const float *wstat, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int G, float *S_max,
                   int64_t *D_ind, hipStream_t st) {
-  constexpr int RT = 2 * RW * 32, GC = 64 * CW;
-  const size_t lds = (size_t)planes_lds<RT, GC>(Na).total;
-  static_assert((size_t)(3 * (GC + GC * PL_MAXC) + 2 + GC + 16) * 4 <= (size_t)2 * (RT + GC) * 128, "exact-phase scratch fits the stages");
-  const void *k = reinterpret_cast<const void *>(sim_planes_kernel<RW, CW, KIND>);
+  constexpr int RT = WR * RW * 32, GC = (4 / WR) * 32 * CW;
+  const size_t lds = (size_t)planes_lds<RT, GC, WR, NST>(Na).total;
+  static_assert((size_t)(3 * (GC + GC * PL_MAXC) + 2 + GC + 16) * 4 <= (size_t)NST * (RT + GC) * 128, "exact-phase scratch fits the stages");
+  const void *k = reinterpret_cast<const void *>(sim_planes_kernel<RW, CW, KIND, WR, NST>);
+  if (lds > 160 * 1024) return NAFAE_ELIMIT;
   if (lds > 64 * 1024) {
     const int rc = allow_dynamic_lds(k, 160 * 1024);
     if (rc != NAFAE_OK) return rc;
   }
-  if (lds > 160 * 1024) return NAFAE_ELIMIT;
   const int grid = ((F + 7) / 8) * 8 * G;
   int dbg = 0;
   if (const char *e = nafae::experiment_env("NAFAE_SIM_DBG")) dbg = atoi(e);
-  NAFAE_TAG("sim_planes<%d,%d,%s>", RW, CW, KIND == KIND_F16 ? "f16" : "bf16x3");
-  hipLaunchKernelGGL((sim_planes_kernel<RW, CW, KIND>), dim3(grid), dim3(512), lds, st, V, W, Vp, Wp, vstat, wstat, ent_len, F, Nb, Na,
-                     Ne, D, G, S_max, D_ind, dbg);
+  NAFAE_TAG("sim_planes<%d,%d,%s%s>", RW, CW, KIND == KIND_F16 ? "f16" : "bf16x3", WR == 4 ? ",narrow" : "");
+  hipLaunchKernelGGL((sim_planes_kernel<RW, CW, KIND, WR, NST>), dim3(grid), dim3(512), lds, st, V, W, Vp, Wp, vstat, wstat, ent_len, F, Nb,
+                     Na, Ne, D, G, S_max, D_ind, dbg);
   return launch_status();
 }
 
@@ -717,6 +760,23 @@ int launch_planes_frames(const float *V, const float *W, const void *Vp, const v
   NAFAE_PL(2, 1) NAFAE_PL(3, 1) NAFAE_PL(4, 1) NAFAE_PL(5, 1)
   NAFAE_PL(2, 2) NAFAE_PL(3, 2) NAFAE_PL(4, 2) NAFAE_PL(5, 2)
 #undef NAFAE_PL
+  return NAFAE_ELIMIT;
+}
+
+// FEW live columns (Qh <= 64) with fp16 operand planes: the narrow form -- four row quarters x one 32-column block per workgroup, the
+// frame's rows stream once per 32 live columns, a ring as deep as the stage size allows.  Nb > 32.
+int launch_planes_narrow(const float *V, const float *W, const void *Vp, const void *Wp, const float *vstat, const float *wstat,
+                         const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D, int Qh, float *S_max, int64_t *D_ind,
+                         hipStream_t st) {
+  const int nrb = (Nb + 31) / 32;
+  int rw = (nrb + 3) / 4;                     // row blocks per wave so that one super-tile covers the frame, at most 4 (two stages of
+  rw = rw > 4 ? 4 : rw;                       // 544 rows = 139 KB of LDS; longer frames take several super-tiles)
+  const int G = (Qh + 31) / 32;
+  const unsigned char *vp = reinterpret_cast<const unsigned char *>(Vp), *wp = reinterpret_cast<const unsigned char *>(Wp);
+#define NAFAE_PN(RW_, NST_) \
+  if (rw == RW_) return launch_planes<RW_, 1, KIND_F16, 4, NST_>(V, W, vp, wp, vstat, wstat, ent_len, F, Nb, Na, Ne, D, G, S_max, D_ind, st);
+  NAFAE_PN(1, 6) NAFAE_PN(2, 3) NAFAE_PN(3, 2) NAFAE_PN(4, 2)
+#undef NAFAE_PN
   return NAFAE_ELIMIT;
 }
 

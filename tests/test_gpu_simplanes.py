@@ -86,6 +86,34 @@ def test_planes_kernel_all_live_equals_round3_kernel(kind, cfg):
     assert float((S1.cpu().double() - m).abs().max()) < 2e-6 * scale
 
 
+@pytest.mark.parametrize("cfg", [(8, 8, 300, 64, None), (8, 8, 256, 32, None), (2, 3, 224, 40, [1, 0]), (2, 2, 700, 64, [64, 0]),
+                                 (3, 2, 333, 30, [30, 30, 4]), (1, 5, 640, 8, [8])],
+                         ids=["C5hist", "C4hist", "one-live", "Nb700-64live", "two-groups", "Nb640"])
+def test_narrow_planes_kernel_few_live_columns(cfg):
+    """Few live columns, long frames, fp16 planes: the narrow form of the planes kernel (four row quarters x one 32-column block, ring
+    of 2-3 stages) == the fp32 live-column kernel bit for bit (both end in the same exact fp32 evaluation), one and two column
+    groups, one to three super-tiles, frames that end inside a row block; masked slots (0, 0)."""
+    from nafae_amd import ops
+    from nafae_amd import synthetic as syn
+    Na, Ns, Nb, Ne, lens = cfg
+    D = 512
+    lens = lens or syn.entity_lengths(Na, Ne, seed=1234)
+    assert sum(lens) <= 64 and Nb >= 224
+    V, W = syn.embeddings(Na * Ns * Nb, Na * Ne, D, seed=9)
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    Vg, Wg = V.cuda(), W.cuda()
+    S0, D0 = ops.sim_max_fwd(Vg, Wg, lt, Na, Ns, Nb, Ne, lens=lens, planes=False)
+    S1, D1 = ops.sim_max_fwd(Vg, Wg, lt, Na, Ns, Nb, Ne, lens=lens, planes="f16")
+    m, i, gap, masked = _ref64(V, W, lens, Na, Nb, Ne)
+    scale = float(m.abs().max())
+    assert not ((D1.cpu() != i) & (gap > 1e-5 * scale)).any()
+    assert float((S1.cpu().double() - m).abs().max()) < 2e-6 * scale
+    assert (S1.cpu()[masked] == 0).all() and (D1.cpu()[masked] == 0).all()
+    assert torch.equal(D0, D1) and torch.allclose(S0, S1, rtol=0, atol=3e-6 * scale)
+    S2, D2 = ops.sim_max_fwd(Vg, Wg, lt, Na, Ns, Nb, Ne, lens=lens, planes="f16")
+    assert torch.equal(S1, S2) and torch.equal(D1, D2)
+
+
 @pytest.mark.parametrize("kind", ["bf16x3", "f16"])
 def test_planes_kernel_extreme_values_and_mass_ties(kind):
     """What the one-product fp16 filter cannot represent must still come out exactly: rows scaled beyond the fp16 range (Inf in the

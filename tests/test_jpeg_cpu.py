@@ -66,16 +66,19 @@ def host_harness():
     return ctypes.CDLL(out)
 
 
-def host_decode(L, files):
+def host_decode(L, files, lanes=0):
+    """lanes = 0: the one-lane entropy decoder; lanes > 0: the many-lane (self-synchronising) algorithm of jpeg_huffman_par_kernel,
+    its lanes emulated one after the other.  Returns (frames, prepared tables[, most re-decoding rounds any interval needed])."""
     from nafae_amd import jpeg as NJ
     P = NJ.prepare(files)
     W, H, nc, h0, v0 = P["geom"]
     out = np.zeros((len(files), H, W, 3), np.uint8)
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    rc = L.jpeg_host_decode(ptr(P["stream"]), ptr(P["desc"]), ptr(P["seg"]), ptr(P["qtabs"]), ptr(P["hufftabs"]), len(files),
-                            P["seg"].shape[0], W, H, nc, h0, v0, ptr(out))
+    rounds = ctypes.c_int(0)
+    rc = L.jpeg_host_decode_lanes(ptr(P["stream"]), ptr(P["desc"]), ptr(P["seg"]), ptr(P["qtabs"]), ptr(P["hufftabs"]), len(files),
+                                  P["seg"].shape[0], W, H, nc, h0, v0, ptr(out), int(lanes), ctypes.byref(rounds))
     assert rc == 0
-    return out, P
+    return (out, P, rounds.value) if lanes else (out, P)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_q%d_s%d_r%d%s" % (c[0], c[1], c[2], c[3], c[4], "_grey" if c[5] else ""))
@@ -87,6 +90,29 @@ def test_device_arithmetic_on_host_matches_libjpeg(case, host_harness):
     if case[4]:
         assert P["seg"].shape[0] > 3             # restart intervals became independent work items
     assert len(P["hufftabs"]) <= 4 and len(P["qtabs"]) <= 2        # identical tables are shared across the batch
+
+
+@pytest.mark.parametrize("lanes", [2, 7, 64, 256])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_q%d_s%d_r%d%s" % (c[0], c[1], c[2], c[3], c[4], "_grey" if c[5] else ""))
+def test_many_lane_entropy_decoder_on_host_matches_libjpeg(case, lanes, host_harness):
+    """The self-synchronising decoder (jpeg_core.h span_decode + the round structure of jpeg_huffman_par_kernel) with 2 ... 256 lanes
+    per restart interval: wrong guesses at the lane starts must all fall into step -- bit-exact frames -- in a few rounds."""
+    files = [make_jpeg(*case, seed=s) for s in range(2)]
+    got, P, rounds = host_decode(host_harness, files, lanes=lanes)
+    assert np.array_equal(got, np.stack([pil_bgr(f) for f in files]))
+    assert 1 <= rounds <= lanes
+
+
+def test_many_lane_decoder_hands_truncated_data_to_the_one_lane_decoder(host_harness):
+    """Fewer MCUs in the data than the frame has (a truncated file): the many-lane pass notices and the one-lane decoder, which feeds
+    zero bits as libjpeg does, takes the interval -- same frames as lanes = 0."""
+    f = make_jpeg(64, 48, 90, 2, seed=5)
+    from nafae_amd import jpeg as NJ
+    hdr = NJ.parse_header(f)
+    cut = f[:hdr["scan"] + (len(f) - hdr["scan"]) // 2] + b"\xff\xd9"
+    a, _ = host_decode(host_harness, [cut])
+    b, _, _ = host_decode(host_harness, [cut], lanes=16)
+    assert np.array_equal(a, b)
 
 
 def test_unsupported_files_are_refused_loudly():
