@@ -299,6 +299,10 @@ __global__ __launch_bounds__(NTHREADS) F32_TILE_OCC void conv3x3_kernel(const fl
 #ifndef NAFAE_F32_SK_WPE
 #define NAFAE_F32_SK_WPE 2
 #endif
+// 16-byte accesses another workgroup / XCD sees without a fence (see the in-kernel fix-up below); the load returns asynchronously
+__device__ __forceinline__ void store16_sc1(void *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void load16_sc1(f32x4 &v, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
+
 template <class E>
 __device__ __forceinline__ void conv_epilogue(const E &e, int m0, int n0, int M, int Cout, const float *__restrict__ bias, int relu,
                                               float *__restrict__ out) {
@@ -324,7 +328,8 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_F32_SK_WPE, NAFAE_F32_SK_WPE))) void conv3x3_sk_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                               const float *__restrict__ bias, float *__restrict__ out, int F, int H,
                                                               int W, int Cin, int Cout, int relu, int tiles_m, int tiles_n,
-                                                              float *__restrict__ scratch, int bid0, int ntiles) {
+                                                              float *__restrict__ scratch, int bid0, int ntiles,
+                                                              int *__restrict__ counters) {
   using E = Engine<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   E e;
@@ -404,22 +409,78 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
     const int lane0 = e.lane;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(e.lane), "+v"(tid));
-    if (ka == 0 && kb == nk) {
-      conv_epilogue(e, m0, n0, M, Cout, bias, relu, out);
-    } else {
-      f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NTHREADS + tid;
+    bool finish = ka == 0 && kb == nk;
+    if (!finish) {
+      // In-kernel fix-up (round 4).  Who works on tile t: the non-empty shares among workgroups cf .. cl.  The LOWEST one finishes the
+      // tile: it has the tile as the last segment of its share (the others had it first and wrote their partials long ago), keeps its
+      // own part in registers, waits for the others' arrivals and adds their partials in workgroup order -- the same fp32 sum as the
+      // fix-up launch's 0 + p_cf + p_cf+1 + ...  Hand-off without fences (MI355X_MICROARCH.md, inter-workgroup visibility): every
+      // byte stored sc1, the storing waves' vmcnt(0), ONE agent-scope add per workgroup, sc1 loads behind the poll and a barrier.
+      // No deadlock even if not every workgroup is resident: a contributor's partial of this tile is the first thing it produces.
+      const int G = gridDim.x;
+      const long t0 = (long)t * nk, t1 = t0 + nk;
+      int cf = 0, cl = 0, others = 0;
+      if (counters) {
+        cf = (int)(t0 * G / U);
+        cl = (int)((t1 - 1) * G / U);
+        while (U * (cf + 1) / G <= t0) cf++;
+        while (U * cf / G > t0) cf--;
+        while (U * (cl + 1) / G <= t1 - 1) cl++;
+        while (U * cl / G > t1 - 1) cl--;
+        for (int c = cf + 1; c <= cl; c++) others += (U * (c + 1) / G > U * c / G) ? 1 : 0;   // (empty shares do not arrive)
+      }
+      const bool finisher = counters && (int)blockIdx.x == cf;
+      if (!finisher) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NTHREADS + tid;
 #pragma unroll
-      for (int i = 0; i < E::TM; i++)
+        for (int i = 0; i < E::TM; i++)
 #pragma unroll
-        for (int j = 0; j < E::TN; j++)
+          for (int j = 0; j < E::TN; j++)
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            f32x4 v;
+            for (int q = 0; q < 4; q++) {
+              f32x4 v;
 #pragma unroll
-            for (int c = 0; c < 4; c++) v[c] = e.acc[i][j][4 * q + c];
-            dst[(size_t)((i * E::TN + j) * 4 + q) * NTHREADS] = v;
-          }
+              for (int c = 0; c < 4; c++) v[c] = e.acc[i][j][4 * q + c];
+              if (counters)
+                store16_sc1(dst + (size_t)((i * E::TN + j) * 4 + q) * NTHREADS, v);
+              else
+                dst[(size_t)((i * E::TN + j) * 4 + q) * NTHREADS] = v;
+            }
+      }
+      if (counters) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          if (!finisher)
+            __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            while (__hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < others) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        for (int c = cf + 1; finisher && c <= cl; c++) {
+          const long c0 = U * c / G;
+          if (U * (c + 1) / G == c0) continue;
+          const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NTHREADS + tid;
+#pragma unroll
+          for (int i = 0; i < E::TM; i++)
+#pragma unroll
+            for (int j = 0; j < E::TN; j++) {
+              f32x4 v[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) load16_sc1(v[q], src + (size_t)((i * E::TN + j) * 4 + q) * NTHREADS);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                asm volatile("" : "+v"(v[q]));
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) e.acc[i][j][4 * q + cc] += v[q][cc];
+              }
+            }
+        }
+        finish = finisher;
+      }
     }
+    if (finish) conv_epilogue(e, m0, n0, M, Cout, bias, relu, out);
     e.lane = lane0;
     u += kb - ka;
   }
@@ -1124,12 +1185,17 @@ inline bool f32_sk_pays(long tiles, int cus) {
 constexpr int F32_SK_WG_PER_CU = NAFAE_F32_SK_WPE;   // workgroups per CU the stream-K kernel is compiled for (its register cap)
 }  // namespace
 
+// stream-K workspace: two partial-accumulator slots per workgroup + the arrival counters of the in-kernel fix-up (the stream-K
+// launch never covers more than 4 rounds of tiles: 1 023 counters)
+constexpr int64_t F32_SK_COUNTER_BYTES = 4096;
+static int64_t f32_sk_partial_bytes() { return (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float); }
+
 int64_t nafae_conv3x3_workspace_bytes(int F, int H, int W, int Cin, int Cout) {
   if (F <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (long)F * H * W >= (1L << 31)) return NAFAE_EINVAL;
   if (Cout <= 64 || Cin % 32) return 0;
   const long tiles = (((long)F * H * W + 127) / 128) * ((Cout + 127) / 128);
   if (!f32_sk_pays(tiles, sk_num_cus())) return 0;
-  return (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * sizeof(float);
+  return f32_sk_partial_bytes() + F32_SK_COUNTER_BYTES;
 }
 
 int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float *out, int F, int H, int W, int Cin,
@@ -1170,7 +1236,7 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
     NAFAE_TAG("conv3x3<128,64>");
     launch_conv<128, 64, 4, 1>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));
   } else if (workspace && aligned16(workspace) && f32_sk_pays(t128, sk_num_cus()) && small &&   // (buffer-addressed loads)
-             workspace_bytes >= (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float)) {
+             workspace_bytes >= f32_sk_partial_bytes() + F32_SK_COUNTER_BYTES) {
     // whole rounds (a multiple of #CUs tiles: every CU gets the same number) go through the tile kernel at its three workgroups
     // per CU; only the remainder -- the part that would leave most CUs idle -- runs on the stream-K schedule (two per CU)
     using E = Engine<128, 128, 2, 2>;
@@ -1186,9 +1252,15 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
                          out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
       if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
     }
+    // NAFAE_SK_FIXUP=kernel (experiments build): round 2's separate fix-up launch instead of the last-arriver fix-up in the kernel
+    const char *fe = nafae::experiment_env("NAFAE_SK_FIXUP");
+    const bool in_kernel = !(fe && fe[0] == 'k') && rem * 4 <= F32_SK_COUNTER_BYTES;
+    int *counters = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + f32_sk_partial_bytes());
+    if (in_kernel && hipMemsetAsync(counters, 0, (size_t)rem * sizeof(int), S(stream)) != hipSuccess) return NAFAE_ELAUNCH;
     hipLaunchKernelGGL((conv3x3_sk_kernel<128, 128, 2, 2>), dim3(G), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias, out, F,
-                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace, full, rem);
+                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace, full, rem, in_kernel ? counters : (int *)nullptr);
     if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
+    if (in_kernel) return NAFAE_OK;
     hipLaunchKernelGGL((conv_sk_fixup_f32_kernel<128, 128, 2, 2>), dim3(G - 1), dim3(NTHREADS), 0, S(stream), (const float *)workspace, bias,
                        out, M, Cout, relu, tiles_m, tiles_n, 9 * (Cin / 32), G, full, rem);
   } else if (small_ok && t128 < 2 * 256) {

@@ -704,7 +704,7 @@ struct ConvRun {
   static constexpr int NWC = BW * 4 * PL / NT16;
   static_assert(RR * 4 * PL % NT16 == 0 && BW * 4 * PL % NT16 == 0, "every lane active in every staging instruction");
   static constexpr int DIST = NSTW - 1;
-  static_assert(NSTW == 2 || NSTW == 3, "weight ring of 2 or 3 stages");
+  static_assert(NSTW >= 2 && NSTW <= 4, "weight ring of 2 to 4 stages");
   static constexpr int NGRP = E::NGRP;
   static constexpr size_t LDS_BYTES = (size_t)(2 * XRUN + NSTW * WST) * sizeof(__bf16);
 
@@ -828,16 +828,35 @@ struct ConvRun {
         wait_vmcnt<NXC>();
       else
         wait_vmcnt<0>();
-    } else if (LAST) {
-      if (S == 2)
-        wait_vmcnt<0>();
-      else
-        wait_vmcnt<NWC>();
+    } else if (DIST == 2) {
+      if (LAST) {
+        if (S == 2)
+          wait_vmcnt<0>();
+        else
+          wait_vmcnt<NWC>();
+      } else {
+        if (S == 0)
+          wait_vmcnt<NWC>();
+        else
+          wait_vmcnt<NWC + NXC>();
+      }
     } else {
-      if (S == 0)
-        wait_vmcnt<NWC>();
-      else
-        wait_vmcnt<NWC + NXC>();
+      //   DIST == 3 (W(st) issued by step st-3, the same S of the previous group): S == 0 -> the run this group reads was issued right
+      //   behind W(st), so only the two weight tiles after it may be in flight; otherwise two weight tiles and the next group's run
+      //   (last group: nothing is issued any more, W(st + 1 ..) are what is left)
+      if (LAST) {
+        if (S == 0)
+          wait_vmcnt<2 * NWC>();
+        else if (S == 1)
+          wait_vmcnt<NWC>();
+        else
+          wait_vmcnt<0>();
+      } else {
+        if (S == 0)
+          wait_vmcnt<2 * NWC>();
+        else
+          wait_vmcnt<2 * NWC + NXC>();
+      }
     }
     if (!(CONV_EXP & 1)) __builtin_amdgcn_s_barrier();
     const int cc = grp / 3, dyi = grp - cc * 3;
@@ -944,19 +963,29 @@ struct ConvRun {
   }
 };
 
+// 16-byte accesses that other workgroups / XCDs see without a fence (MI355X_MICROARCH.md, inter-workgroup visibility: every byte
+// stored `sc1`, the storing wave's vmcnt(0), ONE agent-scope add per storing workgroup, `sc1` loads by the workgroup whose add came
+// last -- its other waves behind a workgroup barrier).  The load returns asynchronously: wait_vmcnt<0>() and pin() before the use.
+__device__ __forceinline__ void store16_sc1(void *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void load16_sc1(f32x4 &v, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
+
 // The work of one workgroup: units [u0, u1) of the launch's (tile, row-offset group) list, tile-major (ngrp = 3 * Cin/32 units
 // per tile).  A share that is exactly one tile is the plain one-tile-per-workgroup kernel; shares cut at arbitrary units are
 // the stream-K schedule below.  Segments = the pieces of a share that lie inside one tile.  A tile wholly inside the share is
-// finished here (epilogue); for a cut tile the fp32 partial accumulators go to `scratch` (slot 2w for the workgroup's first
-// segment, 2w+1 for its last).  Kept as ONE loop nest with run-time bounds for both kernels: with the straight-line
-// begin / loop / epilogue form the compiler computes the epilogue's per-lane addresses ahead of the loop and spills
+// finished here (epilogue).  For a cut tile the fp32 partial accumulators go to `scratch` (slot 2w for the workgroup's first
+// segment, 2w+1 for its last); with `counters` (one int per tile, zero at launch) the tile's LOWEST contributor keeps its part in
+// registers, waits for the others' arrivals and adds their partials in workgroup order -- the sum a fix-up launch (the path without
+// counters) forms -- and finishes the tile.  Kept as ONE loop nest with run-time bounds for both kernels: with the
+// straight-line begin / loop / epilogue form the compiler computes the epilogue's per-lane addresses ahead of the loop and spills
 // loop-carried values to make room for them.
 template <class R, bool SPLITOUT>
 __device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, const ConvArgs &a, long u0, long u1, int ngrp, int tiles_n,
                                           const float *__restrict__ bias, int relu, float *__restrict__ Cf, __bf16 *__restrict__ Chi,
-                                          __bf16 *__restrict__ Clo, float *__restrict__ scratch) {
+                                          __bf16 *__restrict__ Clo, float *__restrict__ scratch, int *__restrict__ counters, long U) {
   using E = typename R::E;
   constexpr int NACC4 = E::NI * E::NJ * E::NG;   // float4 pieces of the accumulator per lane
+  const int G = gridDim.x;
   R r;
   for (long u = u0; u < u1;) {
     const int t = (int)(u / ngrp);
@@ -972,23 +1001,77 @@ __device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, cons
     r.begin(e, smem16, a, m0, n0, 3 * ga, 3 * gb);
     for (int grp = ga; grp + 1 < gb; grp++) r.template group<false>(e, grp);
     r.template group<true>(e, gb - 1);
-    if (ga == 0 && gb == ngrp) {
+    bool finish = ga == 0 && gb == ngrp;
+    if (!finish) {
+      // who works on tile t: the workgroups cf .. cl whose shares overlap its units [t0, t1)
+      const long t0 = (long)t * ngrp, t1 = t0 + ngrp;
+      int cf = 0, cl = 0;
+      if (counters) {
+        cf = (int)(t0 * G / U);
+        cl = (int)((t1 - 1) * G / U);
+        while (U * (cf + 1) / G <= t0) cf++;
+        while (U * cf / G > t0) cf--;
+        while (U * (cl + 1) / G <= t1 - 1) cl++;
+        while (U * cl / G > t1 - 1) cl--;
+      }
+      // The LOWEST contributor finishes the tile: the tile is the last segment of its share, while the others had it as their
+      // first and wrote their partials long ago, so its wait below is a formality -- and its own part never leaves the registers.
+      const bool finisher = counters && (int)blockIdx.x == cf;
+      if (!finisher) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < E::NI; i++)
+#pragma unroll
+          for (int j = 0; j < E::NJ; j++)
+#pragma unroll
+            for (int g = 0; g < E::NG; g++) {
+              f32x4 v;
+#pragma unroll
+              for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
+              if (counters)
+                store16_sc1(dst + (size_t)((i * E::NJ + j) * E::NG + g) * NT16, v);
+              else
+                dst[(size_t)((i * E::NJ + j) * E::NG + g) * NT16] = v;
+            }
+      }
+      if (counters) {
+        wait_vmcnt<0>();                                 // this wave's partial has left
+        __syncthreads();                                 // ... and every wave's
+        // (no deadlock even if not every workgroup of the launch is resident: a contributor's partial of this tile is the first
+        // thing it produces, nothing can hold it up before that, and workgroups start in index order)
+        if (threadIdx.x == 0) {
+          if (!finisher)
+            __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            while (__hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cl - cf) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        // partials in workgroup order on top of this workgroup's own: the same fp32 sum as 0 + p_cf + p_cf+1 + ...
+        for (int c = cf + 1; finisher && c <= cl; c++) {
+          const long c0 = U * c / G;
+          const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
+#pragma unroll
+          for (int i = 0; i < E::NI; i++)
+#pragma unroll
+            for (int j = 0; j < E::NJ; j++) {
+              f32x4 v[E::NG];
+#pragma unroll
+              for (int g = 0; g < E::NG; g++) load16_sc1(v[g], src + (size_t)((i * E::NJ + j) * E::NG + g) * NT16);
+              wait_vmcnt<0>();
+#pragma unroll
+              for (int g = 0; g < E::NG; g++) {
+                pin(v[g]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) e.acc[i][j][4 * g + q] += v[g][q];
+              }
+            }
+        }
+        finish = finisher;
+      }
+    }
+    if (finish)
       epilogue<E, SPLITOUT>(e, m0, n0, a.F * a.H * a.W, a.Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo,
                             a.Cout);
-    } else {
-      f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
-#pragma unroll
-      for (int i = 0; i < E::NI; i++)
-#pragma unroll
-        for (int j = 0; j < E::NJ; j++)
-#pragma unroll
-          for (int g = 0; g < E::NG; g++) {
-            f32x4 v;
-#pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
-            dst[(size_t)((i * E::NJ + j) * E::NG + g) * NT16] = v;
-          }
-    }
     u += gb - ga;
   }
 }
@@ -1008,7 +1091,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
   const ConvArgs a{Xhi, Xlo, Whi, Wlo, F, H, W, Cin, Cout, 0};
   const int ngrp = 3 * (Cin / BKH);
   const long u0 = (long)(tm * tiles_n + tn) * ngrp;   // exactly one tile
-  run_share<R, SPLIT && !PAIR>(e, smem16, a, u0, u0 + ngrp, ngrp, tiles_n, bias, relu, Cf, Chi, Clo, nullptr);
+  run_share<R, SPLIT && !PAIR>(e, smem16, a, u0, u0 + ngrp, ngrp, tiles_n, bias, relu, Cf, Chi, Clo, nullptr, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ run-reuse conv, stream-K
@@ -1026,7 +1109,8 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi,
                                                               const __bf16 *Wlo, const float *__restrict__ bias,
                                                               float *__restrict__ Cf, __bf16 *__restrict__ Chi,
                                                               __bf16 *__restrict__ Clo, int F, int H, int W, int Cin, int Cout,
-                                                              int relu, int tiles_m, int tiles_n, float *__restrict__ scratch) {
+                                                              int relu, int tiles_m, int tiles_n, float *__restrict__ scratch,
+                                                              int *__restrict__ counters) {
   using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false, PAIR>;
   using E = typename R::E;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
@@ -1036,7 +1120,7 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi,
   const int ngrp = 3 * (Cin / BKH);
   const long U = (long)tiles_m * tiles_n * ngrp;
   const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
-  run_share<R, SPLIT && !PAIR>(e, smem16, a, u0, u1, ngrp, tiles_n, bias, relu, Cf, Chi, Clo, scratch);
+  run_share<R, SPLIT && !PAIR>(e, smem16, a, u0, u1, ngrp, tiles_n, bias, relu, Cf, Chi, Clo, scratch, counters, U);
 }
 
 // One workgroup per share boundary w (between workgroups w-1 and w of the kernel above).  The boundary that is the FIRST
@@ -1621,7 +1705,10 @@ inline bool sk_pays(long tiles, int G) {
   const long rounds = (tiles + G - 1) / G;
   return (double)(rounds * G - tiles) / (double)(rounds * G) > 0.10;
 }
-inline size_t sk_scratch_bytes(int BX, int BW, int G) { return (size_t)2 * G * BX * BW * sizeof(float); }
+// partial accumulators (two slots per workgroup) + the per-tile arrival counters of the in-kernel fix-up
+constexpr int SK_MAX_TILES = 16384;
+inline size_t sk_partial_bytes(int BX, int BW, int G) { return (size_t)2 * G * BX * BW * sizeof(float); }
+inline size_t sk_scratch_bytes(int BX, int BW, int G) { return sk_partial_bytes(BX, BW, G) + (size_t)SK_MAX_TILES * sizeof(int); }
 
 template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX = 256, bool PAIR = false>
 int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
@@ -1629,12 +1716,21 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   using R = ConvRun<BW, WX, WW, NSTW, SPLIT, IL, BX, false, PAIR>;
   const int M = F * H * W;
   const int tiles_m = (M + BX - 1) / BX, tiles_n = (Cout + BW - 1) / BW;
+  if ((long)tiles_m * tiles_n > SK_MAX_TILES)            // (more tiles than arrival counters: whole tiles, the quantisation loss is < 2 %)
+    return launch_conv_run<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>(Xhi, Xlo, Whi, Wlo, bias, Cf, Chi, Clo, F, H, W, Cin, Cout, relu, st);
   auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>;
-  NAFAE_TAG("conv3x3_run_sk<%d,%d,split=%d,il=%d,pair=%d> + fixup", BX, BW, (int)SPLIT, (int)IL, (int)PAIR);
+  // NAFAE_SK_FIXUP=kernel (experiments build): round 2's separate fix-up launch instead of the last-arriver fix-up inside the kernel
+  const char *fe = nafae::experiment_env("NAFAE_SK_FIXUP");
+  const bool in_kernel = !(fe && fe[0] == 'k');
+  NAFAE_TAG("conv3x3_run_sk<%d,%d,split=%d,il=%d,pair=%d>%s", BX, BW, (int)SPLIT, (int)IL, (int)PAIR, in_kernel ? "" : " + fixup");
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)R::LDS_BYTES) != NAFAE_OK) return NAFAE_ELAUNCH;
+  int *counters = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + sk_partial_bytes(BX, BW, G));
+  if (in_kernel && hipMemsetAsync(counters, 0, (size_t)tiles_m * tiles_n * sizeof(int), st) != hipSuccess) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
-                     (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch);
+                     (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch,
+                     in_kernel ? counters : (int *)nullptr);
   if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
+  if (in_kernel) return NAFAE_OK;
   // (PAIR: plain output -- the fix-up only needs the accumulator geometry, so the plain-epilogue instantiation serves)
   using EF = EngineH<BX, BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, false>;
   hipLaunchKernelGGL((conv_sk_fixup_kernel<BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, BX>), dim3((G - 1) * EF::NJ), dim3(NT16), 0, st, scratch, bias, Cf,
@@ -1902,6 +1998,17 @@ int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi
         if (use_conv4() && conv4_shape(M, Cin, Cout, Cin * 2))
           return launch_conv4<true>(in_hi, w_hi, bias, out_f32, out_hi, nullptr, F, H, W, Cin * 2, Cout, relu, (float *)workspace,
                                     workspace_bytes, S(stream));
+        // experiments: NAFAE_PAIR_DEEP=1 -> 256x128 tiles with a FOUR-stage weight ring (three steps of look-ahead) for every layer
+        // of more than 64 output channels
+        const char *pd = nafae::experiment_env("NAFAE_PAIR_DEEP");
+        if (pd && pd[0] == '1' && Cout > 64) {
+          if (workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 127) / 128), G) &&
+              workspace_bytes >= (int64_t)sk_scratch_bytes(256, 128, G))
+            return launch_conv_run_sk<128, 4, 2, 4, true, true, 256, true>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr,
+                                                                           F, H, W, Ce, Cout, relu, (float *)workspace, G, S(stream));
+          return launch_conv_run<128, 4, 2, 4, true, true, 256, true>(in_hi, nullptr, w_hi, nullptr, bias, out_f32, out_hi, nullptr, F, H,
+                                                                      W, Ce, Cout, relu, S(stream));
+        }
         if (Cout >= 256 && M >= 256 * 128) {
           if (workspace && sk_pays((long)((M + 255) / 256) * ((Cout + 255) / 256), G) &&
               workspace_bytes >= (int64_t)sk_scratch_bytes(256, 256, G))

@@ -16,7 +16,8 @@ wait
 for a in "$@"; do
   n=${a%%=*}
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o nafae_amd/csrc/variants/libnafae_hip_$n.so nafae_amd/csrc/variants/gemm_bf16_$n.o \
-      nafae_amd/csrc/gemm.o nafae_amd/csrc/proposal.o nafae_amd/csrc/simloss.o nafae_amd/csrc/simmax.o
+      nafae_amd/csrc/gemm.o nafae_amd/csrc/proposal.o nafae_amd/csrc/simloss.o nafae_amd/csrc/simmax.o nafae_amd/csrc/simfused.o \
+      nafae_amd/csrc/simplanes.o nafae_amd/csrc/jpeg.o
   rm nafae_amd/csrc/variants/gemm_bf16_$n.o
 done
 ls nafae_amd/csrc/variants/
