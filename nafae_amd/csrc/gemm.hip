@@ -289,9 +289,9 @@ __global__ __launch_bounds__(NTHREADS) F32_TILE_OCC void conv3x3_kernel(const fl
 // 12.5 % idle), the 14^2 layers 392 tiles = 1.53 per CU (23 % idle).  Here the launch is the list of (tile, k-tile) units,
 // tile-major, and G workgroups each take an equal CONTIGUOUS share.  A tile wholly inside a share is finished there; a tile
 // cut by a share boundary gets fp32 partial accumulators in `scratch` (slot 2w for the first segment of workgroup w, 2w+1 for
-// its last) and conv_sk_fixup_kernel -- the kernel boundary is the only synchronisation -- adds them in workgroup order and
-// runs the epilogue.  Deterministic (the order is fixed by the share arithmetic); a cut tile's K sum is split into two or three
-// fp32 chains instead of one, so the last bit differs from the tile kernel's.  Single LDS buffer as above.
+// its last) and its lowest contributor adds them in workgroup order to its own part and runs the epilogue (in the kernel since
+// round 4; a fix-up launch before).  Deterministic (the order is fixed by the share arithmetic); a cut tile's K sum is split into two
+// or three fp32 chains instead of one, so the last bit differs from the tile kernel's.  Single LDS buffer as above.
 // ------------------------------------------------------------------------------------------------
 // Workgroups per CU the stream-K kernel is compiled and launched for.  At 3 (the tile kernel's occupancy, 168 registers) the
 // segment loop spills its staging registers inside the k loop and the 56^2 layers come out 4-9 % SLOWER than the tile kernel;
@@ -419,17 +419,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
       // No deadlock even if not every workgroup is resident: a contributor's partial of this tile is the first thing it produces.
       const int G = gridDim.x;
       const long t0 = (long)t * nk, t1 = t0 + nk;
-      int cf = 0, cl = 0, others = 0;
-      if (counters) {
-        cf = (int)(t0 * G / U);
-        cl = (int)((t1 - 1) * G / U);
-        while (U * (cf + 1) / G <= t0) cf++;
-        while (U * cf / G > t0) cf--;
-        while (U * (cl + 1) / G <= t1 - 1) cl++;
-        while (U * cl / G > t1 - 1) cl--;
-        for (int c = cf + 1; c <= cl; c++) others += (U * (c + 1) / G > U * c / G) ? 1 : 0;   // (empty shares do not arrive)
-      }
-      const bool finisher = counters && (int)blockIdx.x == cf;
+      int cf = (int)(t0 * G / U), cl = (int)((t1 - 1) * G / U), others = 0;
+      while (U * (cf + 1) / G <= t0) cf++;
+      while (U * cf / G > t0) cf--;
+      while (U * (cl + 1) / G <= t1 - 1) cl++;
+      while (U * cl / G > t1 - 1) cl--;
+      for (int c = cf + 1; c <= cl; c++) others += (U * (c + 1) / G > U * c / G) ? 1 : 0;   // (empty shares do not arrive)
+      const bool finisher = (int)blockIdx.x == cf;
       if (!finisher) {
         f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NTHREADS + tid;
 #pragma unroll
@@ -441,13 +437,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
               f32x4 v;
 #pragma unroll
               for (int c = 0; c < 4; c++) v[c] = e.acc[i][j][4 * q + c];
-              if (counters)
-                store16_sc1(dst + (size_t)((i * E::TN + j) * 4 + q) * NTHREADS, v);
-              else
-                dst[(size_t)((i * E::TN + j) * 4 + q) * NTHREADS] = v;
+              store16_sc1(dst + (size_t)((i * E::TN + j) * 4 + q) * NTHREADS, v);
             }
       }
-      if (counters) {
+      {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -484,44 +477,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
     e.lane = lane0;
     u += kb - ka;
   }
-}
-
-// One workgroup per share boundary w (between workgroups w-1 and w of the kernel above).  The FIRST boundary strictly inside a
-// tile owns it: it adds the contributors' partials in workgroup order and writes the tile.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS) void conv_sk_fixup_f32_kernel(const float *__restrict__ scratch, const float *__restrict__ bias,
-                                                                     float *__restrict__ out, int M, int Cout, int relu, int tiles_m,
-                                                                     int tiles_n, int nk, int G, int bid0, int ntiles) {
-  using E = Engine<BM, BN, WM, WN>;
-  const int w = blockIdx.x + 1;
-  const long U = (long)ntiles * nk;
-  const long b = U * w / G;
-  const int t = (int)(b / nk);
-  const long t0 = (long)t * nk, t1 = t0 + nk;
-  if (b == t0) return;                       // the boundary lies on a tile edge
-  if (U * (w - 1) / G > t0) return;          // an earlier boundary lies strictly inside this tile and owns it
-  E e;
-  e.init();
-  constexpr int NACC4 = E::TM * E::TN * 4;
-  for (int c = w - 1; c < G; c++) {
-    const long c0 = U * c / G;
-    if (c0 >= t1) break;
-    if (U * (c + 1) / G == c0) continue;       // an empty share (fewer units than workgroups) wrote nothing
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NTHREADS + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < E::TM; i++)
-#pragma unroll
-      for (int j = 0; j < E::TN; j++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const f32x4 v = src[(size_t)((i * E::TN + j) * 4 + q) * NTHREADS];
-#pragma unroll
-          for (int cc = 0; cc < 4; cc++) e.acc[i][j][4 * q + cc] += v[cc];
-        }
-  }
-  int tm, tn;
-  tile_coords(bid0 + t, tiles_m, tiles_n, tm, tn);
-  conv_epilogue(e, tm * BM, tn * BN, M, Cout, bias, relu, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1252,17 +1207,10 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
                          out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
       if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
     }
-    // NAFAE_SK_FIXUP=kernel (experiments build): round 2's separate fix-up launch instead of the last-arriver fix-up in the kernel
-    const char *fe = nafae::experiment_env("NAFAE_SK_FIXUP");
-    const bool in_kernel = !(fe && fe[0] == 'k') && rem * 4 <= F32_SK_COUNTER_BYTES;
     int *counters = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + f32_sk_partial_bytes());
-    if (in_kernel && hipMemsetAsync(counters, 0, (size_t)rem * sizeof(int), S(stream)) != hipSuccess) return NAFAE_ELAUNCH;
+    if (hipMemsetAsync(counters, 0, (size_t)rem * sizeof(int), S(stream)) != hipSuccess) return NAFAE_ELAUNCH;
     hipLaunchKernelGGL((conv3x3_sk_kernel<128, 128, 2, 2>), dim3(G), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias, out, F,
-                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace, full, rem, in_kernel ? counters : (int *)nullptr);
-    if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
-    if (in_kernel) return NAFAE_OK;
-    hipLaunchKernelGGL((conv_sk_fixup_f32_kernel<128, 128, 2, 2>), dim3(G - 1), dim3(NTHREADS), 0, S(stream), (const float *)workspace, bias,
-                       out, M, Cout, relu, tiles_m, tiles_n, 9 * (Cin / 32), G, full, rem);
+                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace, full, rem, counters);
   } else if (small_ok && t128 < 2 * 256) {
     NAFAE_TAG("conv3x3<64,64>");
     launch_conv<64, 64, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));

@@ -974,9 +974,9 @@ __device__ __forceinline__ void pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
 // per tile).  A share that is exactly one tile is the plain one-tile-per-workgroup kernel; shares cut at arbitrary units are
 // the stream-K schedule below.  Segments = the pieces of a share that lie inside one tile.  A tile wholly inside the share is
 // finished here (epilogue).  For a cut tile the fp32 partial accumulators go to `scratch` (slot 2w for the workgroup's first
-// segment, 2w+1 for its last); with `counters` (one int per tile, zero at launch) the tile's LOWEST contributor keeps its part in
-// registers, waits for the others' arrivals and adds their partials in workgroup order -- the sum a fix-up launch (the path without
-// counters) forms -- and finishes the tile.  Kept as ONE loop nest with run-time bounds for both kernels: with the
+// segment, 2w+1 for its last), and the tile's LOWEST contributor -- `counters`: one arrival counter per tile, zero at launch -- keeps
+// its part in registers, waits for the others and adds their partials in workgroup order (the sum round 2's fix-up launch formed,
+// bit for bit), then finishes the tile.  Kept as ONE loop nest with run-time bounds for both kernels: with the
 // straight-line begin / loop / epilogue form the compiler computes the epilogue's per-lane addresses ahead of the loop and spills
 // loop-carried values to make room for them.
 template <class R, bool SPLITOUT>
@@ -1005,18 +1005,14 @@ __device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, cons
     if (!finish) {
       // who works on tile t: the workgroups cf .. cl whose shares overlap its units [t0, t1)
       const long t0 = (long)t * ngrp, t1 = t0 + ngrp;
-      int cf = 0, cl = 0;
-      if (counters) {
-        cf = (int)(t0 * G / U);
-        cl = (int)((t1 - 1) * G / U);
-        while (U * (cf + 1) / G <= t0) cf++;
-        while (U * cf / G > t0) cf--;
-        while (U * (cl + 1) / G <= t1 - 1) cl++;
-        while (U * cl / G > t1 - 1) cl--;
-      }
+      int cf = (int)(t0 * G / U), cl = (int)((t1 - 1) * G / U);
+      while (U * (cf + 1) / G <= t0) cf++;
+      while (U * cf / G > t0) cf--;
+      while (U * (cl + 1) / G <= t1 - 1) cl++;
+      while (U * cl / G > t1 - 1) cl--;
       // The LOWEST contributor finishes the tile: the tile is the last segment of its share, while the others had it as their
       // first and wrote their partials long ago, so its wait below is a formality -- and its own part never leaves the registers.
-      const bool finisher = counters && (int)blockIdx.x == cf;
+      const bool finisher = (int)blockIdx.x == cf;
       if (!finisher) {
         f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
 #pragma unroll
@@ -1028,13 +1024,10 @@ __device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, cons
               f32x4 v;
 #pragma unroll
               for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
-              if (counters)
-                store16_sc1(dst + (size_t)((i * E::NJ + j) * E::NG + g) * NT16, v);
-              else
-                dst[(size_t)((i * E::NJ + j) * E::NG + g) * NT16] = v;
+              store16_sc1(dst + (size_t)((i * E::NJ + j) * E::NG + g) * NT16, v);
             }
       }
-      if (counters) {
+      {
         wait_vmcnt<0>();                                 // this wave's partial has left
         __syncthreads();                                 // ... and every wave's
         // (no deadlock even if not every workgroup of the launch is resident: a contributor's partial of this tile is the first
@@ -1100,10 +1093,9 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_kernel(const __bf16 *Xhi, co
 // frames 0.755-0.80 ms, 84 frames 0.94 ms at 256->256 @56^2), so a quarter of the chip idles in the last round.  Here the
 // work of a launch is the list of (tile, row-offset group) units, tile-major; G = #CUs workgroups each take an equal
 // CONTIGUOUS share of it (stream-K).  A workgroup finishes the tiles that lie wholly inside its share exactly as the
-// kernel above does; for the tile(s) cut by a share boundary it writes the fp32 partial accumulators to `scratch` (slot
-// 2w for its first segment, 2w+1 for its last), and conv_sk_fixup_kernel -- the kernel boundary is the only
-// synchronisation -- adds the partials of each cut tile in workgroup order and runs the normal epilogue.  Deterministic:
-// the summation order is fixed by the share arithmetic.
+// kernel above does; a tile cut by a share boundary is finished by its lowest contributor, which adds the others' fp32 partials
+// (`scratch`) in workgroup order to its own and runs the normal epilogue (run_share; until round 4 a separate fix-up launch did
+// that).  Deterministic: the summation order is fixed by the share arithmetic.
 template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX, bool PAIR = false>
 __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi, const __bf16 *Xlo, const __bf16 *Whi,
                                                               const __bf16 *Wlo, const float *__restrict__ bias,
@@ -1121,48 +1113,6 @@ __global__ __launch_bounds__(NT16) void conv3x3_run_sk_kernel(const __bf16 *Xhi,
   const long U = (long)tiles_m * tiles_n * ngrp;
   const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
   run_share<R, SPLIT && !PAIR>(e, smem16, a, u0, u1, ngrp, tiles_n, bias, relu, Cf, Chi, Clo, scratch, counters, U);
-}
-
-// One workgroup per share boundary w (between workgroups w-1 and w of the kernel above).  The boundary that is the FIRST
-// one strictly inside a tile owns that tile: it adds the contributors' partials in workgroup order and writes the tile.
-template <int BW, int WX, int WW, bool SPLIT, bool IL, int BX>
-__global__ __launch_bounds__(NT16) void conv_sk_fixup_kernel(const float *__restrict__ scratch, const float *__restrict__ bias,
-                                                             float *__restrict__ Cf, __bf16 *__restrict__ Chi,
-                                                             __bf16 *__restrict__ Clo, int M, int Cout, int relu, int tiles_m,
-                                                             int tiles_n, int ngrp, int G) {
-  using E = EngineH<BX, BW, WX, WW, SPLIT, IL, false>;
-  // NJ workgroups per boundary, one per 32-pixel accumulator tile column j: the kernel is all memory traffic (2-3 partials of
-  // 256 KB in, one tile out through 8-byte pieces), and one 8-wave workgroup per cut tile does not keep enough of it in flight
-  const int w = blockIdx.x / E::NJ + 1, jsel = blockIdx.x - (w - 1) * E::NJ;
-  const long U = (long)tiles_m * tiles_n * ngrp;
-  const long b = U * w / G;
-  const int t = (int)(b / ngrp);
-  const long t0 = (long)t * ngrp, t1 = t0 + ngrp;
-  if (b == t0) return;                       // the boundary lies on a tile edge
-  if (U * (w - 1) / G > t0) return;          // an earlier boundary lies strictly inside this tile and owns it
-  E e;
-  e.init();
-  constexpr int NACC4 = E::NI * E::NJ * E::NG;
-  for (int c = w - 1; c < G; c++) {
-    const long c0 = U * c / G;
-    if (c0 >= t1) break;
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < E::NI; i++)
-#pragma unroll
-      for (int j = 0; j < E::NJ; j++) {
-        if (j != jsel) continue;
-#pragma unroll
-        for (int g = 0; g < E::NG; g++) {
-          const f32x4 v = src[(size_t)((i * E::NJ + j) * E::NG + g) * NT16];
-#pragma unroll
-          for (int q = 0; q < 4; q++) e.acc[i][j][4 * g + q] += v[q];
-        }
-      }
-  }
-  const int tm = t / tiles_n, tn = t - tm * tiles_n;
-  epilogue<E, SPLIT>(e, tm * BX, tn * BW, M, Cout, 1.0f, bias, (relu & 1) ? NAFAE_ACT_RELU : NAFAE_ACT_NONE, Cf, Chi, Clo, Cout, jsel,
-                     jsel + 1);
 }
 
 // ------------------------------------------------------------------------------------------------ 2-D patch conv (narrow layers)
@@ -1701,6 +1651,8 @@ inline bool sk_pays(long tiles, int G) {
   // NAFAE_CONV_SK=0 disables it (A/B, and runs that must not depend on the batch size in the last bit: which tiles are
   // cut -- hence the order their partial sums are added in -- depends on the tile count).  Read on every call.
   const char *e = nafae::experiment_env("NAFAE_CONV_SK");
+  // (fewer tiles than CUs -- the 14^2 layers' 196 tiles of 256 x 128 as 256 shares of 0.77 tiles -- was measured once the fix-up had
+  // moved into the kernel: bf16x3 0.161 -> 0.153 ms, plain bf16 0.067 -> 0.074: not adopted)
   if ((e && e[0] == '0') || tiles <= G) return false;
   const long rounds = (tiles + G - 1) / G;
   return (double)(rounds * G - tiles) / (double)(rounds * G) > 0.10;
@@ -1719,22 +1671,13 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   if ((long)tiles_m * tiles_n > SK_MAX_TILES)            // (more tiles than arrival counters: whole tiles, the quantisation loss is < 2 %)
     return launch_conv_run<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>(Xhi, Xlo, Whi, Wlo, bias, Cf, Chi, Clo, F, H, W, Cin, Cout, relu, st);
   auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>;
-  // NAFAE_SK_FIXUP=kernel (experiments build): round 2's separate fix-up launch instead of the last-arriver fix-up inside the kernel
-  const char *fe = nafae::experiment_env("NAFAE_SK_FIXUP");
-  const bool in_kernel = !(fe && fe[0] == 'k');
-  NAFAE_TAG("conv3x3_run_sk<%d,%d,split=%d,il=%d,pair=%d>%s", BX, BW, (int)SPLIT, (int)IL, (int)PAIR, in_kernel ? "" : " + fixup");
+  NAFAE_TAG("conv3x3_run_sk<%d,%d,split=%d,il=%d,pair=%d>", BX, BW, (int)SPLIT, (int)IL, (int)PAIR);
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)R::LDS_BYTES) != NAFAE_OK) return NAFAE_ELAUNCH;
   int *counters = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + sk_partial_bytes(BX, BW, G));
-  if (in_kernel && hipMemsetAsync(counters, 0, (size_t)tiles_m * tiles_n * sizeof(int), st) != hipSuccess) return NAFAE_ELAUNCH;
+  if (hipMemsetAsync(counters, 0, (size_t)tiles_m * tiles_n * sizeof(int), st) != hipSuccess) return NAFAE_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
                      (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch,
-                     in_kernel ? counters : (int *)nullptr);
-  if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
-  if (in_kernel) return NAFAE_OK;
-  // (PAIR: plain output -- the fix-up only needs the accumulator geometry, so the plain-epilogue instantiation serves)
-  using EF = EngineH<BX, BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, false>;
-  hipLaunchKernelGGL((conv_sk_fixup_kernel<BW, WX, WW, SPLIT && !PAIR, IL && !PAIR, BX>), dim3((G - 1) * EF::NJ), dim3(NT16), 0, st, scratch, bias, Cf,
-                     (__bf16 *)Chi, (__bf16 *)Clo, M, Cout, relu, tiles_m, tiles_n, 3 * (Cin / BKH), G);
+                     counters);
   return launched();
 }
 

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 Image = pytest.importorskip("PIL.Image")
-from test_jpeg_cpu import CASES, make_jpeg, pil_bgr      # noqa: E402  (same generated files as the CPU-side checks)
+from test_jpeg_cpu import CASES, host_harness, make_jpeg, pil_bgr      # noqa: E402,F401  (same generated files as the CPU-side checks)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_q%d_s%d_r%d%s" % (c[0], c[1], c[2], c[3], c[4], "_grey" if c[5] else ""))
@@ -55,3 +55,31 @@ def test_gpu_decode_rejects_what_it_cannot_decode():
     from nafae_amd import jpeg
     with pytest.raises(jpeg.JpegUnsupported):
         jpeg.decode_batch([make_jpeg(32, 32, 90, 2, progressive=True)])
+
+
+def test_gpu_decode_large_files_take_the_one_lane_decoder():
+    """A frame whose entropy-coded data exceeds what the many-lane decoder keeps in LDS (112 KB): the kernel flags the file before it writes
+    anything and the one-lane decoder (reading through its LDS ring, refilled many times) takes it -- mixed in one batch with a file
+    that does fit, same size and sampling."""
+    from nafae_amd import jpeg
+    big = make_jpeg(1024, 768, 100, 0, seed=1)                # 4:4:4 at quality 100: several hundred KB of scan data
+    small = make_jpeg(1024, 768, 15, 0, seed=2)
+    assert len(big) > 200 * 1024 and len(small) < 100 * 1024
+    got = jpeg.decode_batch([big, small, big]).cpu().numpy()
+    ref = np.stack([pil_bgr(f) for f in (big, small, big)])
+    assert np.array_equal(got, ref)
+
+
+def test_gpu_decode_truncated_file_equals_the_sequential_rules(host_harness):
+    """Half of the scan data gone: libjpeg (and the one-lane decoder) go on with zero bits after the marker; the many-lane decoder counts
+    fewer MCUs than the frame has and hands the file over.  Checked against the same functions run on the host."""
+    from nafae_amd import jpeg
+    from test_jpeg_cpu import host_decode
+    f = make_jpeg(96, 64, 90, 2, seed=5)
+    hdr = jpeg.parse_header(f)
+    cut = f[:hdr["scan"] + (len(f) - hdr["scan"]) // 2] + b"\xff\xd9"
+    whole = make_jpeg(96, 64, 90, 2, seed=6)
+    got = jpeg.decode_batch([cut, whole]).cpu().numpy()
+    want, _ = host_decode(host_harness, [cut, whole])
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[1], pil_bgr(whole))
