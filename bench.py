@@ -223,7 +223,13 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
     by_fb = by_f + 4.0 * D * (R + Q) + 4.0 * D * F * Q            # + dense dV, dW and the arg-max row re-reads
     fl = 2.0 * R * Q * D
     traffic, src = pmc_traffic(pmc_key) if pmc_key else (None, None)
-    return {"R": R, "Q": Q, "operand_planes": ("%s planes of V and W attached by the producer (used by the many-live-column kernel "
+    if live > 64:
+        route = "sim_planes_kernel (many live columns: fp16-MFMA filter on the producer's planes + exact fp32 finish; simplanes.hip)"
+    elif Nb >= 224:
+        route = "sim_planes_kernel, narrow form (few live columns on long frames: fp16-MFMA filter + exact fp32 finish; simplanes.hip)"
+    else:
+        route = "sim_live_kernel (few live columns: fp32 MFMA, one launch, last-arriver merge; simfused.hip)"
+    return {"R": R, "Q": Q, "kernel": route, "operand_planes": ("%s planes of V and W attached by the producer (used by the many-live-column kernel "
                                                "only; their production is outside the timed region)" % ops.SIM_PLANES_DEFAULT),
             "fwd_traffic": traffic,
             "fwd_traffic_source": ("static: %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/sim_only.py at this "
@@ -480,7 +486,7 @@ def run_rank(a):
         if world == 1:
             # the similarity kernel alone at this workload's shape, and at C5 (the HBM-roofline configuration)
             so = sim_loss_only(Na, Ns, Nb, Ne, dev, pmc_key="sim_%s_hist" % workload)
-            out["roofline_sim"] = {"kernel": "sim_live_kernel + sim_few_merge_kernel (nafae_sim_max_fwd_ws: fp32-MFMA few-live-column route; stand-alone, this workload's shape and entity-length histogram)",
+            out["roofline_sim"] = {"kernel": so["kernel"] + " -- stand-alone, this workload's shape and entity-length histogram",
                                    "bound": "hbm", "achieved": so["fwd_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": so["fwd_hbm_frac"], "avg_ms": so["fwd_ms"], "algorithmic_bytes": so["fwd_algorithmic_bytes"],
                                    "traffic": so["fwd_traffic"], "traffic_source": so["fwd_traffic_source"],

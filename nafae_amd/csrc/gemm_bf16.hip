@@ -1446,8 +1446,12 @@ __global__ __launch_bounds__(256) void conv1_bf16_kernel(const void *__restrict_
     for (int ky = 0; ky < 3; ky++)
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
+        // (the load is unconditional, from the nearest pixel inside the frame, and the padding is a select behind it: a load under
+        // a condition is a branch with its own wait, 27 L2 latencies one after the other)
         const int yy = y + ky - 1, xx = x + kx - 1;
-        v[ci * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? conv1_tap<IN>(in, n, ci, yy, xx, H, W) : 0.f;
+        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const float t = conv1_tap<IN>(in, n, ci, yc, xc, H, W);
+        v[ci * 9 + ky * 3 + kx] = (yy == yc && xx == xc) ? t : 0.f;
       }
   const bool il = plane_il(ohi, olo);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

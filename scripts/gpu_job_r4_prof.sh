@@ -2,7 +2,7 @@
 # trace domains).  The whole GPU suite runs in scripts/gpu_job_r4_tests.sh.
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4p
+O=$R/gpurun_out/r4final
 mkdir -p $O
 cd $R
 (timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench_c2.json 2> $O/bench_c2.err; echo rc=$? >> $O/bench_c2.err)
