@@ -646,12 +646,16 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
     for (int c4 = 0; c4 < 8; c4++) {
       f32x4 o;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
+      for (int c = 0; c < 4; c += 2) {                    // two channels per v_pk_fma_f32 (same IEEE fma per component)
         const int co = half * 32 + c4 * 4 + c;
-        float a = bias[co];
+        f32x2 a = {bias[co], bias[co + 1]};
 #pragma unroll
-        for (int k = 0; k < 27; k++) a = fmaf(v[k], w[co * 27 + k], a);
-        o[c] = fmaxf(a, 0.f);
+        for (int k = 0; k < 27; k++) {
+          const f32x2 ww = {w[co * 27 + k], w[(co + 1) * 27 + k]}, vv = {v[k], v[k]};
+          a = __builtin_elementwise_fma(vv, ww, a);
+        }
+        o[c] = fmaxf(a[0], 0.f);
+        o[c + 1] = fmaxf(a[1], 0.f);
       }
       *reinterpret_cast<f32x4 *>(row + c4 * 4) = o;
     }

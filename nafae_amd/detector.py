@@ -277,12 +277,12 @@ class _fasterRCNN(nn.Module):
                 with ops.timed("fc6"):
                     _, fc6 = ops.gemm_nt_bf16(pooled_pl.view(R, -1), P['fc6_w_h'], P['fc6_b'], act=ops.ACT_RELU)
                 with ops.timed("fc7"):
-                    sp = self.precision == 'bf16x3'
+                    # fc7's bf16 planes travel with it: VisEbd (model.py:624-629) continues in the mode's own arithmetic (split planes
+                    # in 'bf16x3', one plane in 'bf16') instead of an fp32-MFMA GEMM at 1/16 of the rate
                     fc7, fc7_pl = ops.gemm_nt_bf16(fc6, P['fc7_w_h'], P['fc7_b'], act=ops.ACT_RELU, want_f32=True,
-                                                   want_planes=sp)
-                    if sp:      # VisEbd (model.py:624-629) continues on the same arithmetic without re-splitting fc7
-                        fc7._nafae_planes = fc7_pl
-                        fc7._nafae_planes_version = fc7._version       # an in-place edit of fc7 invalidates the planes
+                                                   want_planes=True)
+                    fc7._nafae_planes = fc7_pl
+                    fc7._nafae_planes_version = fc7._version           # an in-place edit of fc7 invalidates the planes
             else:
                 with ops.timed("roi_align"):
                     pooled = ops.roi_align_avg_nhwc(base_feat, rois.view(R, 5), 1.0 / 16.0)  # [R,7,7,512]

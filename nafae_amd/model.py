@@ -145,9 +145,10 @@ class _VisEbdFn(torch.autograd.Function):
         ctx.params = (weight, bias)
         with ops.timed("vis_ebd"):
             if planes is not None:
-                # fc7 arrived with its split-bf16 planes (detector in 'bf16x3' mode): the same 3-MFMA arithmetic as fc6 / fc7
-                # (~1e-5, inside the 1e-4 bar) instead of fp32 MFMA at 1/16 of the rate.  The backward below stays fp32.
-                wp = ops.split_bf16(weight.detach(), True, planes.il)
+                # fc7 arrived with its bf16 planes (detector in 'bf16x3' / 'bf16' mode): the same arithmetic as fc6 / fc7 -- three
+                # MFMAs per product on split planes (~1e-5, inside the 1e-4 bar), one on plain bf16 (config C3's tolerance) -- instead
+                # of fp32 MFMA at 1/16 of the rate.  The backward below stays fp32.
+                wp = ops.split_bf16(weight.detach(), planes.lo is not None, planes.il)
                 pre, _ = ops.gemm_nt_bf16(planes, wp, bias, alpha=0.01, want_f32=True, want_planes=False)
             else:
                 pre = ops.gemm_nt(feats, weight, bias, alpha=0.01)  # (x/100) W^T + b  ==  0.01 (x W^T) + b
