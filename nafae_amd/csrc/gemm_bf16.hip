@@ -69,6 +69,29 @@ __device__ __forceinline__ void epilogue(E &e, int m0, int n0, int M, int N, flo
       }
     return;
   }
+  // the same for PLAIN bf16 output (config C3's conv and fc layers): bias present, tile inside the matrix, one plane
+  if (!SPLIT && !Cf && Chi && !Clo && bias && m0 + E::BXT <= M && n0 + E::BWT <= N && act >= 0) {
+#pragma unroll
+    for (int i = 0; i < E::NI; i++)
+#pragma unroll
+      for (int g = 0; g < E::NG; g++) {
+        const int n = n0 + e.pn(i, g);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n);
+#pragma unroll
+        for (int j = 0; j < E::NJ; j++) {
+          if (j < jlo || j >= jhi) continue;
+          bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float t = alpha * e.acc[i][j][4 * g + q] + bv[q];
+            if (act == NAFAE_ACT_RELU) t = t > 0.f ? t : 0.f;
+            o[q] = (__bf16)t;
+          }
+          *reinterpret_cast<bf16x4 *>(Chi + (size_t)(m0 + e.pm(j)) * ldc + n) = o;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < E::NJ; j++) {
     const int m = m0 + e.pm(j);
@@ -1302,7 +1325,11 @@ __global__ __launch_bounds__(NT16) void conv3x3_patch_kernel(const __bf16 *X, co
         if (relu & 1) v = v > 0.f ? v : 0.f;
         if (POOL) {
           v = fmaxf(v, __shfl_xor(v, 1));
-          v = fmaxf(v, __shfl_xor(v, 16));
+          // the y neighbour sits 16 lanes away: v_permlane16_swap exchanges the odd 16-lane rows of one copy with the even rows of
+          // the other, after which every lane holds its own value in one copy and its neighbour's in the other -- one vector
+          // instruction instead of __shfl_xor(v, 16)'s ds_bpermute_b32 through the LDS crossbar (32 of them per lane and tile)
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+          v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
         return v;
       };
