@@ -128,6 +128,10 @@ int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float
  * bytes (0 = the layer does not need one; the plain kernel then runs, as it does for workspace == NULL).  Deterministic; a tile
  * cut by the schedule sums its K range as two or three fp32 chains instead of one, so results can differ from
  * nafae_conv3x3_relu in the last bit, and WHICH tiles are cut depends on F.
+ * Workspace contract (both stream-K convs, this one and nafae_conv3x3_bf16_ws; one buffer may serve both): its first 64 KB are the
+ * tiles' arrival counters and must be ZERO when the first call on a workspace starts (hipMemsetAsync once, at allocation); every
+ * completed call leaves them zero, whatever its shape.  The rest needs no initialisation.  Calls that share a workspace must be
+ * stream-ordered; after an aborted launch zero it again.
  * relu: bit 0 = ReLU; bit 4 = also apply the 2x2/2 max-pool that follows the layer (vgg16_rpn.py:38: conv1_2, conv2_2, conv3_3,
  * conv4_3) inside the conv's epilogue -- `out` is then [F, H/2, W/2, Cout] and equals nafae_maxpool2x2(conv) bit for bit.
  * NAFAE_ELIMIT = the fused form is not offered for this call (odd H or W, tensors above 2 GiB, or a layer that goes to the
@@ -217,8 +221,9 @@ int nafae_conv3x3_bf16(const void *in_hi, const void *in_lo, const void *w_hi, c
 /* Same, with a caller-owned scratch buffer that enables the stream-K schedule for launches whose tile count would leave
  * the last round of workgroups mostly empty (49*2^k-pixel layers: 784 / 392 tiles on 256 CUs).  Deterministic (fixed
  * summation order); without a workspace, or when the schedule does not pay, identical to nafae_conv3x3_bf16.
- * nafae_conv3x3_bf16_workspace_bytes: bytes this shape wants (0 = none needed), < 0 on invalid sizes.  The workspace
- * needs no initialisation and must not be shared by launches that may run concurrently.  */
+ * nafae_conv3x3_bf16_workspace_bytes: bytes this shape wants (0 = none needed), < 0 on invalid sizes.  The workspace's
+ * first 64 KB must be zero before its first use (contract above, at nafae_conv3x3_relu_ws) and it must not be shared by launches
+ * that may run concurrently.  */
 int64_t nafae_conv3x3_bf16_workspace_bytes(int F, int H, int W, int Cin, int Cout);
 int nafae_conv3x3_bf16_ws(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo, const float *bias,
                           float *out_f32, void *out_hi, void *out_lo, int F, int H, int W, int Cin, int Cout, int relu,

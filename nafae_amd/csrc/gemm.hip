@@ -446,8 +446,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
         if (tid == 0) {
           if (!finisher)
             __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else
+          else {
             while (__hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < others) __builtin_amdgcn_s_sleep(4);
+            __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: zero for the next launch
+          }
         }
         __syncthreads();
         for (int c = cf + 1; finisher && c <= cl; c++) {
@@ -1148,9 +1150,10 @@ inline bool f32_sk_pays(long tiles, int cus) {
 constexpr int F32_SK_WG_PER_CU = NAFAE_F32_SK_WPE;   // workgroups per CU the stream-K kernel is compiled for (its register cap)
 }  // namespace
 
-// stream-K workspace: two partial-accumulator slots per workgroup + the arrival counters of the in-kernel fix-up (the stream-K
-// launch never covers more than 4 rounds of tiles: 1 023 counters)
-constexpr int64_t F32_SK_COUNTER_BYTES = 4096;
+// stream-K workspace: [64 KB of arrival counters of the in-kernel fix-up][two partial-accumulator slots per workgroup] -- the layout
+// of gemm_bf16.hip's, so that one zeroed-once workspace serves both families (the stream-K launch here never covers more than 4
+// rounds of tiles: 1 023 counters used); every launch leaves the counters zero
+constexpr int64_t F32_SK_COUNTER_BYTES = 65536;
 static int64_t f32_sk_partial_bytes() { return (int64_t)2 * F32_SK_WG_PER_CU * sk_num_cus() * 128 * 128 * (int64_t)sizeof(float); }
 
 int64_t nafae_conv3x3_workspace_bytes(int F, int H, int W, int Cin, int Cout) {
@@ -1215,10 +1218,10 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
                          out, F, H, W, Cin, Cout, relu, tiles_m, tiles_n);
       if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
     }
-    int *counters = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + f32_sk_partial_bytes());
-    if (hipMemsetAsync(counters, 0, (size_t)rem * sizeof(int), S(stream)) != hipSuccess) return NAFAE_ELAUNCH;
+    int *counters = reinterpret_cast<int *>(workspace);
+    float *partials = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + F32_SK_COUNTER_BYTES);
     hipLaunchKernelGGL((conv3x3_sk_kernel<128, 128, 2, 2>), dim3(G), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias, out, F,
-                       H, W, Cin, Cout, relu, tiles_m, tiles_n, (float *)workspace, full, rem, counters);
+                       H, W, Cin, Cout, relu, tiles_m, tiles_n, partials, full, rem, counters);
   } else if (small_ok && t128 < 2 * 256) {
     NAFAE_TAG("conv3x3<64,64>");
     launch_conv<64, 64, 2, 2>(in, w, bias, out, F, H, W, Cin, Cout, relu, S(stream));

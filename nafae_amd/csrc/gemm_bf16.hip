@@ -998,7 +998,8 @@ __device__ __forceinline__ void pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
 // per tile).  A share that is exactly one tile is the plain one-tile-per-workgroup kernel; shares cut at arbitrary units are
 // the stream-K schedule below.  Segments = the pieces of a share that lie inside one tile.  A tile wholly inside the share is
 // finished here (epilogue).  For a cut tile the fp32 partial accumulators go to `scratch` (slot 2w for the workgroup's first
-// segment, 2w+1 for its last), and the tile's LOWEST contributor -- `counters`: one arrival counter per tile, zero at launch -- keeps
+// segment, 2w+1 for its last), and the tile's LOWEST contributor -- `counters`: one arrival counter per tile, zero at launch, zero again
+// when the tile is done -- keeps
 // its part in registers, waits for the others and adds their partials in workgroup order (the sum round 2's fix-up launch formed,
 // bit for bit), then finishes the tile.  Kept as ONE loop nest with run-time bounds for both kernels: with the
 // straight-line begin / loop / epilogue form the compiler computes the epilogue's per-lane addresses ahead of the loop and spills
@@ -1059,8 +1060,10 @@ __device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, cons
         if (threadIdx.x == 0) {
           if (!finisher)
             __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else
+          else {
             while (__hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cl - cf) __builtin_amdgcn_s_sleep(4);
+            __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: zero for the next launch
+          }
         }
         __syncthreads();
         // partials in workgroup order on top of this workgroup's own: the same fp32 sum as 0 + p_cf + p_cf+1 + ...
@@ -1695,10 +1698,15 @@ inline bool sk_pays(long tiles, int G) {
   const long rounds = (tiles + G - 1) / G;
   return (double)(rounds * G - tiles) / (double)(rounds * G) > 0.10;
 }
-// partial accumulators (two slots per workgroup) + the per-tile arrival counters of the in-kernel fix-up
+// Stream-K workspace: [64 KB of per-tile arrival counters][partial accumulators, two slots per workgroup].  The counters sit at the
+// START, at the same place for every tile shape and for the fp32 kernels of gemm.hip, and every launch leaves them ZERO (the
+// finisher of a tile clears its counter): the caller zeroes a workspace once, before its first use, and may then share it between
+// stream-ordered launches of any shape (include/nafae_hip.h).  (A hipMemsetAsync per launch, as in the first form of the in-kernel
+// fix-up, is a dispatch of its own in front of every conv: 6-10 per step, 5 us + two launch gaps each.)
 constexpr int SK_MAX_TILES = 16384;
+constexpr size_t SK_COUNTER_BYTES = (size_t)SK_MAX_TILES * sizeof(int);
 inline size_t sk_partial_bytes(int BX, int BW, int G) { return (size_t)2 * G * BX * BW * sizeof(float); }
-inline size_t sk_scratch_bytes(int BX, int BW, int G) { return sk_partial_bytes(BX, BW, G) + (size_t)SK_MAX_TILES * sizeof(int); }
+inline size_t sk_scratch_bytes(int BX, int BW, int G) { return SK_COUNTER_BYTES + sk_partial_bytes(BX, BW, G); }
 
 template <int BW, int WX, int WW, int NSTW, bool SPLIT, bool IL, int BX = 256, bool PAIR = false>
 int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const void *Wlo, const float *bias, float *Cf, void *Chi,
@@ -1711,10 +1719,10 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   auto kern = conv3x3_run_sk_kernel<BW, WX, WW, NSTW, SPLIT, IL, BX, PAIR>;
   NAFAE_TAG("conv3x3_run_sk<%d,%d,split=%d,il=%d,pair=%d>", BX, BW, (int)SPLIT, (int)IL, (int)PAIR);
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)R::LDS_BYTES) != NAFAE_OK) return NAFAE_ELAUNCH;
-  int *counters = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + sk_partial_bytes(BX, BW, G));
-  if (hipMemsetAsync(counters, 0, (size_t)tiles_m * tiles_n * sizeof(int), st) != hipSuccess) return NAFAE_ELAUNCH;
+  int *counters = reinterpret_cast<int *>(scratch);
+  float *partials = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + SK_COUNTER_BYTES);
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
-                     (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, scratch,
+                     (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, partials,
                      counters);
   return launched();
 }
@@ -1748,11 +1756,12 @@ int launch_conv4(const void *X, const void *Wt, const float *bias, float *Cf, vo
   NAFAE_TAG("bf16_conv4<pair=%d>%s", (int)PAIR, cut ? " + fixup" : "");
   const size_t lds = 2 * W4_STAGE_B;
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds) != NAFAE_OK) return NAFAE_ELAUNCH;
+  float *partials = scratch ? reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + SK_COUNTER_BYTES) : nullptr;   // (never the counters)
   hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, (const __bf16 *)X, (const __bf16 *)Wt, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F,
-                     H, W, rowbytes, Cout, relu, tiles_n, U, scratch);
+                     H, W, rowbytes, Cout, relu, tiles_n, U, partials);
   if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
   if (!cut) return NAFAE_OK;
-  hipLaunchKernelGGL(conv4_sk_fixup_kernel<PAIR>, dim3((G - 1) * 4), dim3(256), 0, st, scratch, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo,
+  hipLaunchKernelGGL(conv4_sk_fixup_kernel<PAIR>, dim3((G - 1) * 4), dim3(256), 0, st, partials, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo,
                      M, Cout, relu, tiles_n, nk, U, G);
   return launched();
 }

@@ -322,11 +322,12 @@ _conv_ws = {}
 
 def _conv_workspace(nbytes, device):
     """Scratch of the stream-K conv schedule, one buffer per (device, stream): launches on one stream are ordered, so they
-    can share it; concurrent streams (pipelined trainer, conv_streams) each get their own."""
+    can share it; concurrent streams (pipelined trainer, conv_streams) each get their own.  Zeroed at allocation: the first 64 KB are
+    the tiles' arrival counters, which every launch leaves zero (include/nafae_hip.h)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _conv_ws.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        t = torch.zeros(nbytes, device=device, dtype=torch.uint8)
         _conv_ws[key] = t
     return t
 
