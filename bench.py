@@ -202,7 +202,9 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=st):
+            # (thread_local: with a process group up, RCCL's watchdog thread polls events while this thread captures -- in the default
+            # global mode that invalidates the capture now and then)
+            with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
                 for _ in range(iters):
                     fn()
             g.replay()

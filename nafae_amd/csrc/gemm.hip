@@ -411,22 +411,22 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
     asm volatile("" : "+v"(e.lane), "+v"(tid));
     bool finish = ka == 0 && kb == nk;
     if (!finish) {
-      // In-kernel fix-up (round 4).  Who works on tile t: the non-empty shares among workgroups cf .. cl.  The LOWEST one finishes the
-      // tile: it has the tile as the last segment of its share (the others had it first and wrote their partials long ago), keeps its
-      // own part in registers, waits for the others' arrivals and adds their partials in workgroup order -- the same fp32 sum as the
-      // fix-up launch's 0 + p_cf + p_cf+1 + ...  Hand-off without fences (MI355X_MICROARCH.md, inter-workgroup visibility): every
-      // byte stored sc1, the storing waves' vmcnt(0), ONE agent-scope add per workgroup, sc1 loads behind the poll and a barrier.
-      // No deadlock even if not every workgroup is resident: a contributor's partial of this tile is the first thing it produces.
+      // In-kernel fix-up (round 4).  Who works on tile t: the non-empty shares among workgroups cf .. cl.  Every one of them stores its
+      // partial and adds 1 to the tile's arrival counter; the one whose add comes LAST sums all the partials in workgroup order (its own
+      // read back like the others: the sum does not depend on who was last, and it is the fix-up launch's 0 + p_cf + p_cf+1 + ...),
+      // finishes the tile and clears the counter.  Nobody ever waits -- with two workgroups per CU and up to eight contributors per tile
+      // a waiting finisher (the form the bf16 kernels use, one workgroup per CU) was seen to crawl when two processes shared the GPU.
+      // Hand-off without fences (MI355X_MICROARCH.md, inter-workgroup visibility): every byte stored sc1, the storing waves'
+      // vmcnt(0), ONE agent-scope add per workgroup, sc1 loads by the workgroup whose add came last, its other waves behind a barrier.
       const int G = gridDim.x;
       const long t0 = (long)t * nk, t1 = t0 + nk;
-      int cf = (int)(t0 * G / U), cl = (int)((t1 - 1) * G / U), others = 0;
+      int cf = (int)(t0 * G / U), cl = (int)((t1 - 1) * G / U), contributors = 0;
       while (U * (cf + 1) / G <= t0) cf++;
       while (U * cf / G > t0) cf--;
       while (U * (cl + 1) / G <= t1 - 1) cl++;
       while (U * cl / G > t1 - 1) cl--;
-      for (int c = cf + 1; c <= cl; c++) others += (U * (c + 1) / G > U * c / G) ? 1 : 0;   // (empty shares do not arrive)
-      const bool finisher = (int)blockIdx.x == cf;
-      if (!finisher) {
+      for (int c = cf; c <= cl; c++) contributors += (U * (c + 1) / G > U * c / G) ? 1 : 0;   // (empty shares do not arrive)
+      {
         f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NTHREADS + tid;
 #pragma unroll
         for (int i = 0; i < E::TM; i++)
@@ -440,19 +440,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
               store16_sc1(dst + (size_t)((i * E::TN + j) * 4 + q) * NTHREADS, v);
             }
       }
-      {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-          if (!finisher)
-            __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else {
-            while (__hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < others) __builtin_amdgcn_s_sleep(4);
-            __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: zero for the next launch
-          }
-        }
-        __syncthreads();
-        for (int c = cf + 1; finisher && c <= cl; c++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int *flag = reinterpret_cast<int *>(smem);
+      if (tid == 0) {
+        const bool last = __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == contributors - 1;
+        if (last) __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+        flag[0] = last ? 1 : 0;
+      }
+      __syncthreads();
+      finish = flag[0] != 0;                             // (uniform)
+      if (finish) {
+        e.zero_acc();
+        for (int c = cf; c <= cl; c++) {
           const long c0 = U * c / G;
           if (U * (c + 1) / G == c0) continue;
           const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NTHREADS + tid;
@@ -472,7 +472,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NAFAE_
               }
             }
         }
-        finish = finisher;
       }
     }
     if (finish) conv_epilogue(e, m0, n0, M, Cout, bias, relu, out);

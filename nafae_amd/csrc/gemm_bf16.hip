@@ -998,10 +998,9 @@ __device__ __forceinline__ void pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
 // per tile).  A share that is exactly one tile is the plain one-tile-per-workgroup kernel; shares cut at arbitrary units are
 // the stream-K schedule below.  Segments = the pieces of a share that lie inside one tile.  A tile wholly inside the share is
 // finished here (epilogue).  For a cut tile the fp32 partial accumulators go to `scratch` (slot 2w for the workgroup's first
-// segment, 2w+1 for its last), and the tile's LOWEST contributor -- `counters`: one arrival counter per tile, zero at launch, zero again
-// when the tile is done -- keeps
-// its part in registers, waits for the others and adds their partials in workgroup order (the sum round 2's fix-up launch formed,
-// bit for bit), then finishes the tile.  Kept as ONE loop nest with run-time bounds for both kernels: with the
+// segment, 2w+1 for its last); the tile's LOWEST contributor -- `counters`: one arrival counter per tile, zero at launch, zero again
+// when the tile is done -- normally finds the others arrived, keeps its part in registers and adds their partials in workgroup
+// order (the sum round 2's fix-up launch formed, bit for bit), else the last arriver does it from the partials (see below).  Kept as ONE loop nest with run-time bounds for both kernels: with the
 // straight-line begin / loop / epilogue form the compiler computes the epilogue's per-lane addresses ahead of the loop and spills
 // loop-carried values to make room for them.
 template <class R, bool SPLITOUT>
@@ -1035,10 +1034,34 @@ __device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, cons
       while (U * cf / G > t0) cf--;
       while (U * (cl + 1) / G <= t1 - 1) cl++;
       while (U * cl / G > t1 - 1) cl--;
-      // The LOWEST contributor finishes the tile: the tile is the last segment of its share, while the others had it as their
-      // first and wrote their partials long ago, so its wait below is a formality -- and its own part never leaves the registers.
-      const bool finisher = (int)blockIdx.x == cf;
-      if (!finisher) {
+      // The LOWEST contributor is meant to finish the tile: the tile is the last segment of its share, while the others had it as
+      // their first and stored their partials long ago -- so it looks at the arrival counter, normally finds everyone there, and adds
+      // their partials to its own part, which never leaves the registers.  The look is BOUNDED (SK_POLLS polls, ~0.1 ms): if the
+      // others are not there -- their workgroups not even started because another process holds the CUs -- it stores its partial like
+      // everybody else and leaves, and the contributor whose arrival is the last one finishes the tile from the partials alone.
+      // Nobody waits without a bound (an unbounded wait made the fp32 kernels of gemm.hip crawl with two processes on one GPU).
+      // Either way the sum is p_cf + p_cf+1 + ... in workgroup order (0 + p_cf is exact), so the result does not depend on the path.
+      constexpr int SK_POLLS = 2048;
+      const int total = cl - cf + 1;
+      int *flag = reinterpret_cast<int *>(smem16);
+      bool fast = false;                                 // (uniform) the lowest contributor found all the others arrived
+      if ((int)blockIdx.x == cf) {
+        __syncthreads();                                 // every wave is done with the LDS buffers (flag lives there)
+        if (threadIdx.x == 0) {
+          int polls = 0;
+          while (__hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total - 1 && polls < SK_POLLS) {
+            __builtin_amdgcn_s_sleep(4);
+            polls++;
+          }
+          const bool ok = __hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total - 1;
+          if (ok) __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+          flag[0] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        fast = flag[0] != 0;
+      }
+      bool last = false;                                 // (uniform) this workgroup's arrival completed the tile
+      if (!fast) {
         f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + (size_t)(2 * blockIdx.x + (u == u0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
 #pragma unroll
         for (int i = 0; i < E::NI; i++)
@@ -1051,42 +1074,37 @@ __device__ __forceinline__ void run_share(typename R::E &e, __bf16 *smem16, cons
               for (int q = 0; q < 4; q++) v[q] = e.acc[i][j][4 * g + q];
               store16_sc1(dst + (size_t)((i * E::NJ + j) * E::NG + g) * NT16, v);
             }
-      }
-      {
         wait_vmcnt<0>();                                 // this wave's partial has left
         __syncthreads();                                 // ... and every wave's
-        // (no deadlock even if not every workgroup of the launch is resident: a contributor's partial of this tile is the first
-        // thing it produces, nothing can hold it up before that, and workgroups start in index order)
         if (threadIdx.x == 0) {
-          if (!finisher)
-            __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else {
-            while (__hip_atomic_load(&counters[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cl - cf) __builtin_amdgcn_s_sleep(4);
-            __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: zero for the next launch
-          }
+          const bool l = __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+          if (l) __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          flag[1] = l ? 1 : 0;
         }
         __syncthreads();
-        // partials in workgroup order on top of this workgroup's own: the same fp32 sum as 0 + p_cf + p_cf+1 + ...
-        for (int c = cf + 1; finisher && c <= cl; c++) {
-          const long c0 = U * c / G;
-          const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
+        last = flag[1] != 0;
+        if (last) e.zero_acc();
+      }
+      finish = fast || last;
+      // partials in workgroup order (on top of this workgroup's own part in the fast case)
+      for (int c = fast ? cf + 1 : cf; finish && c <= cl; c++) {
+        const long c0 = U * c / G;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch) + (size_t)(2 * c + (c0 >= t0 ? 0 : 1)) * NACC4 * NT16 + threadIdx.x;
 #pragma unroll
-          for (int i = 0; i < E::NI; i++)
+        for (int i = 0; i < E::NI; i++)
 #pragma unroll
-            for (int j = 0; j < E::NJ; j++) {
-              f32x4 v[E::NG];
+          for (int j = 0; j < E::NJ; j++) {
+            f32x4 v[E::NG];
 #pragma unroll
-              for (int g = 0; g < E::NG; g++) load16_sc1(v[g], src + (size_t)((i * E::NJ + j) * E::NG + g) * NT16);
-              wait_vmcnt<0>();
+            for (int g = 0; g < E::NG; g++) load16_sc1(v[g], src + (size_t)((i * E::NJ + j) * E::NG + g) * NT16);
+            wait_vmcnt<0>();
 #pragma unroll
-              for (int g = 0; g < E::NG; g++) {
-                pin(v[g]);
+            for (int g = 0; g < E::NG; g++) {
+              pin(v[g]);
 #pragma unroll
-                for (int q = 0; q < 4; q++) e.acc[i][j][4 * g + q] += v[g][q];
-              }
+              for (int q = 0; q < 4; q++) e.acc[i][j][4 * g + q] += v[g][q];
             }
-        }
-        finish = finisher;
+          }
       }
     }
     if (finish)
