@@ -201,12 +201,19 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
         torch.cuda.synchronize()
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
-            g = torch.cuda.CUDAGraph()
-            # (thread_local: with a process group up, RCCL's watchdog thread polls events while this thread captures -- in the default
-            # global mode that invalidates the capture now and then)
-            with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
-                for _ in range(iters):
-                    fn()
+            # (with a process group up, RCCL's watchdog thread polls events while this thread captures, which now and then invalidates
+            # the capture: captured again, up to three times)
+            for attempt in range(3):
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g, stream=st):
+                        for _ in range(iters):
+                            fn()
+                    break
+                except RuntimeError:
+                    if attempt == 2:
+                        raise
+                    torch.cuda.synchronize()
             g.replay()
             st.synchronize()
             best = None
