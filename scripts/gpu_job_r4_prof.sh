@@ -5,13 +5,13 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r4final
 mkdir -p $O
 cd $R
-(timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench_c2.json 2> $O/bench_c2.err; echo rc=$? >> $O/bench_c2.err)
+(timeout -s ABRT 300 python -X faulthandler bench.py --steps 20 --warmup 3 > $O/bench_c2.json 2> $O/bench_c2.err; echo rc=$? >> $O/bench_c2.err)
 for w in c4 c5; do
-  (timeout 600 python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; echo rc=$? >> $O/bench_$w.err)
+  (timeout -s ABRT 240 python -X faulthandler bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; echo rc=$? >> $O/bench_$w.err)
 done
-(timeout 300 python bench.py --gpus 1 --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-other-precisions > $O/bench_c2_force_dist.json 2> $O/bench_fd.err)
+(timeout -s ABRT 240 python -X faulthandler bench.py --gpus 1 --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-other-precisions > $O/bench_c2_force_dist.json 2> $O/bench_fd.err)
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof_bench.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof_bench.err
 for c in "c5 hist" "c5 dense" "c2 hist" "c4 hist"; do set -- $c
   timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sim_$1_$2 -o t -- python3 $R/scripts/sim_only.py $1 $2 20 > $O/sim_$1_$2.log 2>&1
   timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/simloss_$1_$2 -o t -- python3 $R/scripts/simloss_only.py $1 $2 20 > $O/simloss_$1_$2.log 2>&1
