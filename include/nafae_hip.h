@@ -140,6 +140,24 @@ int64_t nafae_conv3x3_workspace_bytes(int F, int H, int W, int Cin, int Cout);
 int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, float *out, int F, int H, int W,
                           int Cin, int Cout, int relu, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same layer as Winograd F(2x2, 3x3) on the fp32 matrix cores (wino.hip): 2.25x fewer matrix multiply-adds than the implicit
+ * GEMM above, every operation still fp32; agrees with nafae_conv3x3_relu to fp32 rounding (the summation order differs), not bit for
+ * bit.  Replaces the same reference layers (vgg16_rpn.py:38 RCNN_base convs 1_2 .. 5_3, rpn/rpn.py:63 RPN_Conv), which the reference
+ * runs through cuDNN.
+ *   nafae_conv3x3_wino_supported    1 when nafae_conv3x3_wino takes the shape: H, W even, H >= 8, W >= 8, Cin >= 64, Cin % 32 == 0,
+ *                                   Cout % 64 == 0, activations below 2 GiB; otherwise 0 (use nafae_conv3x3_relu_ws).
+ *   nafae_conv3x3_wino_weight_bytes bytes of the transformed weights U = G g G^T (16 Cin Cout floats).
+ *   nafae_conv3x3_wino_pack         w [Cout,3,3,Cin] (the layout of nafae_conv3x3_relu) -> U, in the kernel's fragment order;
+ *                                   once per set of weights.
+ *   nafae_conv3x3_wino              in NHWC [F,H,W,Cin], U, bias [Cout] -> out NHWC [F,H,W,Cout]; relu bit 0 = ReLU, bit 4 = also the
+ *                                   2x2/2 max-pool that follows (out is [F,H/2,W/2,Cout]).  No workspace, no initialisation contract.
+ *                                   NAFAE_ELIMIT for a shape nafae_conv3x3_wino_supported rejects.  */
+int nafae_conv3x3_wino_supported(int F, int H, int W, int Cin, int Cout);
+int64_t nafae_conv3x3_wino_weight_bytes(int Cin, int Cout);
+int nafae_conv3x3_wino_pack(const float *w, float *U, int Cin, int Cout, void *stream);
+int nafae_conv3x3_wino(const float *in, const float *U, const float *bias, float *out, int F, int H, int W, int Cin, int Cout,
+                       int relu, void *stream);
+
 /* 2x2 stride-2 max-pool on NHWC.  H, W even; C % 4 == 0.  (RCNN_base pools, vgg16_rpn.py:38.)  */
 int nafae_maxpool2x2(const float *in, float *out, int F, int H, int W, int C, void *stream);
 

@@ -32,6 +32,10 @@ SIGNATURES = {
     "nafae_conv3x3_relu": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "nafae_conv3x3_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "nafae_conv3x3_relu_ws": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P]),
+    "nafae_conv3x3_wino_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "nafae_conv3x3_wino_weight_bytes": (c_int64, [c_int, c_int]),
+    "nafae_conv3x3_wino_pack": (c_int, [P, P, c_int, c_int, P]),
+    "nafae_conv3x3_wino": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "nafae_maxpool2x2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_rpn_decode": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "nafae_sort_desc": (c_int, [P, P, c_int, c_int, P]),

@@ -19,6 +19,7 @@ ARCH = "gfx950"
 # lists) are compared bit-for-bit with the CPU oracle.
 SOURCES = [
     ("gemm.hip", []),
+    ("wino.hip", []),
     ("gemm_bf16.hip", []),
     ("proposal.hip", ["-ffp-contract=off"]),
     ("simloss.hip", []),

@@ -1,0 +1,518 @@
+// wino.hip -- 3x3 convolution (pad 1, stride 1) + bias + ReLU (+ 2x2/2 max-pool) as Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// The direct implicit-GEMM convs of gemm.hip are MFMA-bound at 0.72-0.86 of the fp32 matrix peak (profiles/r04_layer_times_f32.txt):
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate, so the only way to take time out of the conv stack in exact-fp32 arithmetic
+// is to issue fewer multiply-adds.  F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input patch with 16 multiplies per (cin, cout)
+// instead of 36 -- 2.25x fewer matrix flops -- and every multiply and add is still an fp32 operation (no reduced-precision
+// operand anywhere): Y = A^T [ (G g G^T) (.) (B^T d B) ] A, summed over cin.  The reference's conv is cuDNN's (vgg16_rpn.py:38,
+// rpn/rpn.py:63), which picks the same algorithm family for 3x3 fp32 layers; results agree with the direct kernels to fp32 rounding
+// (tests/test_gpu_wino.py: <= 2e-5 of the layer's largest output on the VGG shapes).
+//
+// One workgroup = 4 waves, ONE wave per SIMD (512 registers per lane), owns 64 Winograd tiles (128 output pixels... x 2 = 256) x 64
+// output channels x all 16 transform positions:
+//   * waves 2 x 2: wave (wt, wc) = tiles 32 wt .. +31, channels 32 wc .. +31, and ALL 16 positions: sixteen 32x32 accumulator
+//     tiles = 256 AGPRs.  Because a lane holds the 16 positions of its (tile, channel) pairs, the output transform A^T M A is
+//     lane-local: no shuffle, no LDS, and the 2x2 max-pool that follows conv1_2 / 2_2 / 3_3 / 4_3 is a max over the lane's four
+//     outputs of one tile.
+//   * MFMA "A" operand = transformed input patches: lane (t = lane & 31, h = lane >> 5) owns tile t and the k-quad h of the 8-channel
+//     chunk; it reads its raw 4x4 patch (16 B = 4 channels per pixel) from an LDS image of the input, applies B^T d B in registers
+//     (32 vector adds per position row) and feeds the results straight to the MFMAs -- the transformed patches never touch LDS.
+//   * MFMA "B" operand = transformed weights U = G g G^T, packed once (nafae_conv3x3_wino_pack) in exactly the order the fragments
+//     are read: [cout block 64][chunk of 8 cin][position 16][wc 2][lane 64][4 floats], so a chunk is 32 KB contiguous, staged by
+//     sixteen-byte LDS-DMA (global_load_lds_dwordx4) with lane-linear destinations and read back by one conflict-free ds_read_b128
+//     per fragment.
+//   * input image in LDS: the workgroup's tiles are 64 consecutive tiles of the linear order (frame, column strip of TW tiles,
+//     tile row, tile-in-strip); the raw rows they need are staged 16 channels at a time as 4 planes (one per channel quad) of up
+//     to 28 rows x 320 B, columns de-interleaved by parity (row = [even columns | odd columns]) so that the 32 tiles of a wave read
+//     consecutive 16-B slots.  Staging is buffer_load_dwordx4 ... offen lds: a lane whose pixel is conv padding (or beyond the
+//     frame / strip / tensor) carries bit 31 in its offset, is out of range, and the DMA writes zeros.  Vertical neighbours inside
+//     a frame share their two overlap rows; a frame / strip change starts a new row group.
+//   * schedule: persistent workgroups (one per CU) walk units u = blockIdx.x + i * gridDim.x, unit = (64-tile group, cout block),
+//     cout block fastest, so every workgroup -- and with round-robin dispatch every XCD -- keeps ONE cout block: its transformed
+//     weights (Cin x 4 KB) stay in that XCD's L2.  The DMA stream runs ahead of the MFMAs across tile boundaries; per 8-channel
+//     chunk (64 MFMAs per wave = 4 096 cycles) there is one barrier, the DMAs are counted with vmcnt by hand, and everything
+//     else a wave does (16 + 16 fragment reads, 128 transform adds, ~10 DMA issues) is placed one piece per MFMA gap.
+#include "mfma_tile.h"
+#include <stdlib.h>
+#include <type_traits>
+#include "../../include/nafae_hip.h"
+#include "hip_util.h"
+
+namespace {
+
+constexpr int WN_RP = 320;                    // LDS bytes per staged input row: 2 parity blocks of (TW + 1) 16-B slots, 20 slots
+constexpr int WN_NROWS = 28;                  // rows a workgroup's 64 tiles can need (10 tile rows in up to 4 row groups)
+constexpr int WN_NPIECE = 9;                  // 1-KB DMA pieces per plane (28 rows x 20 slots = 560 slots <= 576)
+constexpr int WN_PLANE = WN_NPIECE * 1024;    // one channel quad of one 16-channel stage
+constexpr int WN_ISTAGE = 4 * WN_PLANE;       // 36 864 B
+constexpr int WN_WSTAGE = 32768;              // one 8-channel chunk of transformed weights for 64 output channels
+constexpr int WN_LDS_W = 2 * WN_ISTAGE;
+constexpr int WN_LDS_TAB = WN_LDS_W + 2 * WN_WSTAGE;
+constexpr int WN_LDS_TOTAL = WN_LDS_TAB + 2 * 256;   // 139 776 B
+constexpr unsigned WN_OOB = 0x80000000u;
+
+struct WinoGeom {
+  int F, H, W, Cin, Cout, relu;
+  int TH, Wt;        // tile rows per frame (H / 2), tile columns per frame (W / 2)
+  int NS;            // column strips per frame (ceil(Wt / TW))
+  int NG;            // row groups = F * NS
+  int NCB;           // 64-channel output blocks
+  int units;         // (64-tile groups) x NCB
+};
+
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void *p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void wn_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+struct WinoTile {
+  unsigned voff[3];      // per-lane source offsets of this wave's input DMA pieces (piece = wave + 4 i), bit 31 = zero fill
+  unsigned abase;        // per-lane LDS byte offset of the tile's patch origin inside a stage (+ the lane's channel-quad plane)
+  const char *wsrc;      // (uniform) transformed weights of the unit's cout block
+};
+
+// Transformed weights, packed for the kernel: U[cb][chunk][pos][wc][lane][e] = (G g G^T)[pos] of (cout = 64 cb + 32 wc + (lane & 31),
+// cin = 8 chunk + 4 (lane >> 5) + e).  g: [Cout][3][3][Cin].
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict__ g, float *__restrict__ U, int Cin, int Cout) {
+  const int NC = Cin >> 3;
+  const long total = (long)(Cout >> 6) * NC * 16 * 2 * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), wc = (int)((i >> 6) & 1), pos = (int)((i >> 7) & 15);
+    const long r = i >> 11;
+    const int chunk = (int)(r % NC), cb = (int)(r / NC);
+    const int cout = cb * 64 + wc * 32 + (lane & 31), cin0 = chunk * 8 + 4 * (lane >> 5);
+    const int xi = pos >> 2, nu = pos & 3;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float *w = g + (size_t)cout * 9 * Cin + cin0 + e;
+      float t[3];   // row xi of G g: G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const float g0 = w[(0 * 3 + s) * Cin], g1 = w[(1 * 3 + s) * Cin], g2 = w[(2 * 3 + s) * Cin];
+        t[s] = xi == 0 ? g0 : xi == 1 ? 0.5f * ((g0 + g2) + g1) : xi == 2 ? 0.5f * ((g0 + g2) - g1) : g2;
+      }
+      o[e] = nu == 0 ? t[0] : nu == 1 ? 0.5f * ((t[0] + t[2]) + t[1]) : nu == 2 ? 0.5f * ((t[0] + t[2]) - t[1]) : t[2];
+    }
+    reinterpret_cast<f32x4 *>(U)[i] = o;
+  }
+}
+
+template <int TW, bool POOL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U, const float *__restrict__ bias, float *__restrict__ out,
+                      const WinoGeom g) {
+  constexpr int PH = (TW + 1) * 16;           // bytes of one parity block of a staged row
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  char *smem = reinterpret_cast<char *>(smem_f);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wave >> 1, wc = wave & 1, h = lane >> 5;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uintptr_t>(smem));
+  const int H = g.H, W = g.W, Cin = g.Cin, Cout = g.Cout, TH = g.TH, NS = g.NS;
+  const int NC = Cin >> 3, NSG = Cin >> 4;    // chunks, 16-channel stages per tile (NSG even: Cin % 32 == 0)
+  const __amdgpu_buffer_rsrc_t in_rsrc = wn_rsrc(in, (size_t)g.F * H * W * Cin * sizeof(float));
+  const size_t out_px = POOL ? (size_t)g.F * TH * g.Wt : (size_t)g.F * H * W;
+  const __amdgpu_buffer_rsrc_t out_rsrc = wn_rsrc(out, out_px * Cout * sizeof(float));
+  int *table = reinterpret_cast<int *>(smem + WN_LDS_TAB);
+  const unsigned wl16 = (unsigned)lane * 16u;
+
+  // ---- per-tile lane state (see the header): computed one tile ahead of the DMA stream
+  auto setup = [&](int u, WinoTile &t, int tabslot) {
+    const int sp = u / g.NCB, cb = u - sp * g.NCB;
+    const int T0 = sp * 64;
+    const int Ra = T0 / TW;
+    const int ga = Ra / TH, ty_a = Ra - ga * TH, n0 = TH - ty_a;   // first row group: n0 tile rows from tile row ty_a
+    const int fa = ga / NS, sa = ga - fa * NS;
+    const int b1 = 2 * n0 + 2, GRP = 2 * TH + 2;                   // LDS rows of the first group / of every later one
+    t.wsrc = reinterpret_cast<const char *>(U) + (size_t)cb * NC * WN_WSTAGE;
+    {   // patch origin of this lane's tile (wave wt, tile lane & 31)
+      const int T = T0 + 32 * wt + (lane & 31);
+      const int R = T / TW, tx = T - R * TW;
+      const int dR = R - Ra;
+      int rho;
+      if (dR < n0) {
+        rho = 2 * dR;
+      } else {
+        int d = dR - n0, k = 0;
+        if (d >= TH) { d -= TH; k++; }
+        if (d >= TH) { d -= TH; k++; }
+        rho = b1 + k * GRP + 2 * d;
+      }
+      t.abase = (unsigned)(rho * WN_RP + tx * 16 + h * WN_PLANE);
+    }
+    // row group k (0 .. 3) -> (frame, strip)
+    auto frame_strip = [&](int k, int &f, int &s) {
+      f = fa;
+      s = sa + k;
+      if (s >= NS) { s -= NS; f++; }
+      if (s >= NS) { s -= NS; f++; }
+      if (s >= NS) { s -= NS; f++; }
+    };
+    if (wave == 0) {   // output offset of every tile's first pixel (bytes; bit 31 = no such tile)
+      const int T = T0 + lane;
+      const int R = T / TW, tx = T - R * TW;
+      const int dR = R - Ra;
+      int k = 0, ty;
+      if (dR < n0) {
+        ty = ty_a + dR;
+      } else {
+        int d = dR - n0;
+        k = 1;
+        if (d >= TH) { d -= TH; k++; }
+        if (d >= TH) { d -= TH; k++; }
+        ty = d;
+      }
+      int f, s;
+      frame_strip(k, f, s);
+      const int gtx = s * TW + tx;
+      const bool ok = ga + k < g.NG && gtx < g.Wt;
+      const unsigned px = POOL ? (unsigned)((f * TH + ty) * g.Wt + gtx) : (unsigned)((f * H + 2 * ty) * W + 2 * gtx);
+      table[tabslot * 64 + lane] = ok ? (int)(px * (unsigned)Cout * 4u) : (int)WN_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int p = wave + 4 * i;                 // (i = 2: wave 0 only)
+      const int sig = 64 * p + lane;
+      const int rho = sig / 20, sr = sig - rho * 20;
+      const int par = sr >= TW + 1 ? 1 : 0, xh = sr - par * (TW + 1), x = 2 * xh + par;
+      int k = 0, y;
+      if (rho < b1) {
+        y = 2 * ty_a - 1 + rho;
+      } else {
+        int q = rho - b1;
+        k = 1;
+        if (q >= GRP) { q -= GRP; k++; }
+        if (q >= GRP) { q -= GRP; k++; }
+        y = q - 1;
+      }
+      int f, s;
+      frame_strip(k, f, s);
+      const int gx = s * 2 * TW - 1 + x;
+      const bool ok = sr < 2 * (TW + 1) && rho < WN_NROWS && ga + k < g.NG && y >= 0 && y < H && gx >= 0 && gx < W;
+      t.voff[i] = ok ? (unsigned)((f * H + y) * W + gx) * (unsigned)Cin * 4u : WN_OOB;
+    }
+  };
+
+  // ---- DMA issue (M0 = LDS destination of lane 0, written and read in ONE asm statement; tests/test_build_isa.py)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  auto dma_w = [&](const char *src, int buf, int i) {          // piece i (0 .. 7) of this wave's quarter of a weight chunk
+    const unsigned m0v = lds0 + (unsigned)(WN_LDS_W + buf * WN_WSTAGE) + (unsigned)(wave * 8 + i) * 1024u;
+    const char *b = src + (size_t)(wave * 8 + i) * 1024;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(wl16), "s"(b) : "memory", "m0");
+  };
+  auto dma_i = [&](const WinoTile &t, int stage, int buf, int q, int pi) {   // channel quad q of piece wave + 4 pi
+    const unsigned m0v = lds0 + (unsigned)(buf * WN_ISTAGE + q * WN_PLANE) + (unsigned)(wave + 4 * pi) * 1024u;
+    const unsigned soff = (unsigned)(stage * 64 + q * 16);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+                 : "memory", "m0");
+  };
+#pragma clang diagnostic pop
+
+  int u = blockIdx.x;
+  if (u >= g.units) return;
+  WinoTile cur, nxt;
+  setup(u, cur, 0);
+  nxt = cur;
+
+  f32x16 acc[16];
+  f32x4 A[2][4], B[2][4];          // operands of the current / next position row (4 positions each)
+  f32x4 r0[4], r1[4], r2[4], r3[4];   // raw patch rows of the lane's tile: 4 pixels x 4 channels each
+
+  // fragment / patch reads
+  const unsigned wrd = (unsigned)(WN_LDS_W + wc * 1024) + wl16;
+  auto read_b = [&](f32x4 (&dst)[4], int buf, int xi) {
+#pragma unroll
+    for (int nu = 0; nu < 4; nu++)
+      dst[nu] = *reinterpret_cast<const f32x4 *>(smem + wrd + buf * WN_WSTAGE + (xi * 4 + nu) * 2048);
+  };
+  // row a (0 .. 3) of the lane's 4x4 patch; ab = patch origin incl. the stage buffer, sub = which 8-channel half of the stage
+  auto read_row = [&](f32x4 (&dst)[4], unsigned ab, int sub, int a) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      dst[j] = *reinterpret_cast<const f32x4 *>(smem + ab + sub * 2 * WN_PLANE + a * WN_RP + (j & 1) * PH + (j >> 1) * 16);
+  };
+
+  // ---- prologue: what the DMA stream would have issued before the first chunk -- weight chunk 0, the first 5 pieces of weight
+  //      chunk 1, input stage 0 (chunk 0 itself then issues the rest of weight chunk 1 and input stage 1, like every even chunk)
+  {
+#pragma unroll
+    for (int i = 0; i < 8; i++) dma_w(cur.wsrc, 0, i);
+#pragma unroll
+    for (int i = 0; i < 5; i++) dma_w(cur.wsrc + WN_WSTAGE, 1, i);
+#pragma unroll
+    for (int pi = 0; pi < 3; pi++)
+      if (pi < 2 || wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) dma_i(cur, 0, 0, q, pi);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    read_b(B[0], 0, 0);
+    read_row(r0, cur.abase, 0, 0);
+    read_row(r2, cur.abase, 0, 2);
+#pragma unroll
+    for (int j = 0; j < 4; j++) r0[j] = r0[j] - r2[j];
+    A[0][0] = r0[0] - r0[2];
+    A[0][1] = r0[1] + r0[2];
+    A[0][2] = r0[2] - r0[1];
+    A[0][3] = r0[1] - r0[3];
+  }
+
+  // One 8-channel chunk = four position rows xi of 16 MFMAs; each row's gaps prepare the next row.
+  //   c: chunk index inside the tile (c & 1 == ODD); last: this is the tile's last chunk (next chunk = first of the next tile)
+  auto chunk = [&](auto first_tag, auto odd_tag, int c, bool last) {
+    constexpr bool FIRST = decltype(first_tag)::value, ODD = decltype(odd_tag)::value;
+    const int s = c >> 1;                                   // input stage of this chunk
+    const unsigned ab = cur.abase + (unsigned)((s & 1) * WN_ISTAGE);
+    // next chunk's patch origin / stage buffer
+    const unsigned abn = ODD ? (last ? nxt.abase : cur.abase + (unsigned)(((s + 1) & 1) * WN_ISTAGE)) : ab;
+    // weight chunk c + 1 / c + 2 and input stage s + 1 as seen by the DMA stream (may belong to the next tile)
+    const char *w1 = c + 1 < NC ? cur.wsrc + (size_t)(c + 1) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 1 - NC) * WN_WSTAGE;
+    const char *w2 = c + 2 < NC ? cur.wsrc + (size_t)(c + 2) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 2 - NC) * WN_WSTAGE;
+    const bool inext = s + 1 >= NSG;
+    const int is1 = inext ? s + 1 - NSG : s + 1;
+    f32x4 t[4];
+    auto mma = [&](auto xi_tag, int e, int nu, const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+      constexpr int XI = decltype(xi_tag)::value;
+      if (FIRST && e == 0) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[XI * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nu][e], b[nu][e], z, 0, 0, 0);
+      } else {
+        acc[XI * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nu][e], b[nu][e], acc[XI * 4 + nu], 0, 0, 0);
+      }
+    };
+    // 16 MFMAs of position row XI with operand set SET; slot(k) runs in the gap behind MFMA k
+    auto row = [&](auto xi_tag, auto set_tag, auto slot) {
+      constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int nu = 0; nu < 4; nu++) {
+          mma(xi_tag, e, nu, A[SET], B[SET]);
+          wn_fence();
+          slot(e * 4 + nu);
+          wn_fence();
+        }
+    };
+    // the position-row transform: t = ra (+/-) rb per pixel column (slots 5 .. 8), then the four positions of the row (slots 9 .. 12)
+    auto tcol = [&](int k, const f32x4 (&ra)[4], const f32x4 (&rb)[4], bool add) {
+      if (k >= 5 && k <= 8) t[k - 5] = add ? ra[k - 5] + rb[k - 5] : ra[k - 5] - rb[k - 5];
+    };
+    auto trow = [&](int k, f32x4 (&dst)[4]) {
+      if (k == 9) dst[0] = t[0] - t[2];
+      if (k == 10) dst[1] = t[1] + t[2];
+      if (k == 11) dst[2] = t[2] - t[1];
+      if (k == 12) dst[3] = t[1] - t[3];
+    };
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
+    using X2 = std::integral_constant<int, 2>;
+    using X3 = std::integral_constant<int, 3>;
+    // ---- xi = 0 (operands in set 0); prepares xi = 1: B <- positions 4 .. 7, row 1; t = r1 + r2.
+    //      DMAs: the last 3 pieces of weight chunk c + 1, then (even chunks) the first 3 input pieces of stage s + 1
+    row(X0{}, X0{}, [&](int k) {
+      if (k == 0) read_b(B[1], ODD ? 1 : 0, 1);
+      if (k == 1) read_row(r1, ab, ODD ? 1 : 0, 1);
+      if (k >= 2 && k <= 4) dma_w(w1, ODD ? 0 : 1, 5 + (k - 2));
+      if (!ODD && k >= 13) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 13, 0);
+      tcol(k, r1, r2, true);
+      trow(k, A[1]);
+    });
+    // ---- xi = 1 (set 1); prepares xi = 2: B <- positions 8 .. 11; t = r2 - r1.  DMAs (even chunks): 7 more input pieces
+    row(X1{}, X1{}, [&](int k) {
+      if (k == 0) read_b(B[0], ODD ? 1 : 0, 2);
+      if (!ODD) {
+        if (k == 1) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 3, 0);
+        if (k >= 2 && k <= 4) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 2, 1);
+        if (k == 13) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 3, 1);
+        if (wave == 0 && k >= 14) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 14, 2);
+      }
+      tcol(k, r2, r1, false);
+      trow(k, A[0]);
+    });
+    // ---- xi = 2 (set 0); prepares xi = 3: B <- positions 12 .. 15, row 3; t = r1 - r3.  DMAs (even chunks, wave 0): the last 2
+    row(X2{}, X0{}, [&](int k) {
+      if (k == 0) read_b(B[1], ODD ? 1 : 0, 3);
+      if (k == 1) read_row(r3, ab, ODD ? 1 : 0, 3);
+      if (!ODD && wave == 0 && (k == 2 || k == 3)) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k, 2);
+      tcol(k, r1, r3, false);
+      trow(k, A[1]);
+    });
+    // ---- xi = 3 (set 1).  Behind its first MFMA the chunk's barrier: every wave's DMAs of weight chunk c + 1 (and, odd chunks, of
+    //      input stage s + 1) have landed, and nobody reads chunk c's weights (or, odd chunks, stage s) any more.  Then it prepares
+    //      xi = 0 of chunk c + 1: B <- positions 0 .. 3 of the other weight buffer, rows 0 and 2; t = r0 - r2; and issues the first
+    //      5 pieces of weight chunk c + 2 into the buffer just freed.
+    row(X3{}, X1{}, [&](int k) {
+      if (k == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ODD) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {            // the input pieces issued in this chunk (stage s + 1) may stay in flight: 12 (wave 0) / 8
+          if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_b(B[0], ODD ? 0 : 1, 0);
+      }
+      if (k == 1) read_row(r0, abn, ODD ? 0 : 1, 0);
+      if (k == 2) read_row(r2, abn, ODD ? 0 : 1, 2);
+      if (k == 3 || k == 4) dma_w(w2, ODD ? 1 : 0, k - 3);
+      if (k >= 13) dma_w(w2, ODD ? 1 : 0, k - 11);
+      tcol(k, r0, r2, false);
+      trow(k, A[0]);
+    });
+  };
+
+  // ---- output transform Y = A^T M A of the lane's 16 tiles x 1 channel, bias, ReLU, (max-pool), store
+  const int cn = wc * 32 + (lane & 31);
+  auto epilogue = [&](int unit, int tabslot) {
+    const int cb = unit % g.NCB;
+    const int co = cb * 64 + cn;
+    const float bv = bias[co];
+    const bool relu = (g.relu & 1) != 0;
+    const unsigned cob = (unsigned)co * 4u;
+    const unsigned sx = (unsigned)Cout * 4u, sy = (unsigned)W * (unsigned)Cout * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int ti = 32 * wt + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const unsigned toff = (unsigned)table[tabslot * 64 + ti];
+      float s0[4], s1[4];
+#pragma unroll
+      for (int xi = 0; xi < 4; xi++) {
+        const float m0 = acc[xi * 4 + 0][r], m1 = acc[xi * 4 + 1][r], m2 = acc[xi * 4 + 2][r], m3 = acc[xi * 4 + 3][r];
+        s0[xi] = (m0 + m1) + m2;
+        s1[xi] = (m1 - m2) - m3;
+      }
+      float y00 = (s0[0] + s0[1]) + s0[2], y10 = (s0[1] - s0[2]) - s0[3];
+      float y01 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+      const unsigned vo = toff + cob;    // (bit 31 survives the add: cob < 2^31 and the store is dropped)
+      if (POOL) {
+        float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, vo, 0, 0);
+      } else {
+        y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+        if (relu) {
+          y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), out_rsrc, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), out_rsrc, vo, sx, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), out_rsrc, vo, sy, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), out_rsrc, vo, sy + sx, 0);
+      }
+    }
+  };
+
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  for (int it = 0;; it++) {
+    const int un = u + (int)gridDim.x;
+    const bool has_next = un < g.units;
+    chunk(T_{}, F_{}, 0, false);
+    // (behind chunk 0's barrier: every wave has left the previous tile's epilogue, whose table slot this overwrites)
+    setup(has_next ? un : u, nxt, (it + 1) & 1);
+    chunk(F_{}, T_{}, 1, false);
+    for (int s = 1; s < NSG; s++) {
+      chunk(F_{}, F_{}, 2 * s, false);
+      chunk(F_{}, T_{}, 2 * s + 1, s + 1 == NSG);
+    }
+    epilogue(u, it & 1);
+    if (!has_next) break;
+    cur = nxt;
+    u = un;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the workgroup has gone
+}
+
+inline hipStream_t WS(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int wn_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
+// strip width: 8 or 7 tiles, whichever wastes fewer tile slots on this frame width (VGG at 224^2: 112 / 56 -> 8, 28 / 14 / 7 -> 7)
+inline int wn_strip(int Wt) {
+  const int w8 = ((Wt + 7) / 8) * 8, w7 = ((Wt + 6) / 7) * 7;
+  return w7 < w8 ? 7 : 8;
+}
+
+inline bool wn_shape_ok(int F, int H, int W, int Cin, int Cout) {
+  if (F <= 0 || H < 8 || W < 8 || (H & 1) || (W & 1)) return false;
+  if (Cin < 64 || (Cin % 32) || (Cout % 64)) return false;
+  const size_t px = (size_t)F * H * W;
+  if (px * (size_t)Cin * sizeof(float) >= (1ull << 31) || px * (size_t)Cout * sizeof(float) >= (1ull << 31)) return false;
+  const long tiles = (long)F * (H / 2) * (((W / 2) + 6) / 7) * 8;    // upper bound of the padded tile count
+  return tiles * (Cout / 64) / 64 < (1L << 30);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nafae_conv3x3_wino_supported(int F, int H, int W, int Cin, int Cout) { return wn_shape_ok(F, H, W, Cin, Cout) ? 1 : 0; }
+
+int64_t nafae_conv3x3_wino_weight_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || (Cin % 8) || (Cout % 64)) return NAFAE_EINVAL;
+  return (int64_t)16 * Cin * Cout * (int64_t)sizeof(float);
+}
+
+int nafae_conv3x3_wino_pack(const float *w, float *U, int Cin, int Cout, void *stream) {
+  if (!w || !U || Cin <= 0 || Cout <= 0 || (Cin % 8) || (Cout % 64)) return NAFAE_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(U) & 15) != 0) return NAFAE_EINVAL;
+  const long total = (long)16 * Cin * Cout / 4;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, WS(stream), w, U, Cin, Cout);
+  return nafae::launch_status();
+}
+
+int nafae_conv3x3_wino(const float *in, const float *U, const float *bias, float *out, int F, int H, int W, int Cin, int Cout, int relu,
+                       void *stream) {
+  if (!in || !U || !bias || !out) return NAFAE_EINVAL;
+  if (relu & ~0x11) return NAFAE_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(U) & 15)) return NAFAE_EINVAL;
+  if (!wn_shape_ok(F, H, W, Cin, Cout)) return NAFAE_ELIMIT;
+  WinoGeom g;
+  g.F = F; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.relu = relu;
+  g.TH = H / 2;
+  g.Wt = W / 2;
+  const int TW = wn_strip(g.Wt);
+  g.NS = (g.Wt + TW - 1) / TW;
+  g.NG = F * g.NS;
+  g.NCB = Cout / 64;
+  const long tiles = (long)g.NG * g.TH * TW;
+  g.units = (int)((tiles + 63) / 64) * g.NCB;
+  // persistent workgroups, one per CU; a grid that is a multiple of NCB keeps a workgroup on one cout block
+  int grid = wn_cus();
+  if (grid > g.units) grid = g.units;
+  if (grid >= g.NCB) grid -= grid % g.NCB;
+  const bool pool = (relu & 16) != 0;
+  const void *k = pool ? (TW == 8 ? reinterpret_cast<const void *>(wino_conv_kernel<8, true>) : reinterpret_cast<const void *>(wino_conv_kernel<7, true>))
+                       : (TW == 8 ? reinterpret_cast<const void *>(wino_conv_kernel<8, false>) : reinterpret_cast<const void *>(wino_conv_kernel<7, false>));
+  if (nafae::allow_dynamic_lds(k, WN_LDS_TOTAL) != NAFAE_OK) return NAFAE_ELAUNCH;
+  NAFAE_TAG("wino_conv<%d>%s", TW, pool ? "+pool" : "");
+  if (pool) {
+    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
+    else hipLaunchKernelGGL((wino_conv_kernel<7, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
+  } else {
+    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
+    else hipLaunchKernelGGL((wino_conv_kernel<7, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
+  }
+  return nafae::launch_status();
+}
+
+}  // extern "C"

@@ -201,6 +201,38 @@ def conv3x3_relu(x_nhwc, w_ohwi, bias, relu=True, use_workspace=True, pool=False
     return out
 
 
+def wino_supported(F, H, W, Cin, Cout):
+    """True when the Winograd F(2x2,3x3) fp32 kernel takes this layer (include/nafae_hip.h)."""
+    return bool(_lib.lib().nafae_conv3x3_wino_supported(int(F), int(H), int(W), int(Cin), int(Cout)))
+
+
+def conv3x3_wino_pack(w_ohwi):
+    """w [Cout,3,3,Cin] -> transformed weights U = G g G^T in the kernel's fragment order (flat fp32 tensor)."""
+    _chk(w_ohwi)
+    Cout, Cin = w_ohwi.shape[0], w_ohwi.shape[-1]
+    if w_ohwi.numel() != Cout * 9 * Cin:
+        raise NafaeOpError("conv3x3_wino_pack: weight shape mismatch")
+    nb = int(_lib.lib().nafae_conv3x3_wino_weight_bytes(Cin, Cout))
+    if nb <= 0:
+        raise NafaeOpError("conv3x3_wino_pack: Cin %% 8 / Cout %% 64 (got %d, %d)" % (Cin, Cout))
+    U = torch.empty(nb // 4, device=w_ohwi.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_conv3x3_wino_pack(_p(w_ohwi), _p(U), Cin, Cout, _stream()), "nafae_conv3x3_wino_pack")
+    return U
+
+
+def conv3x3_wino(x_nhwc, U, bias, Cout, relu=True, pool=False):
+    """x [F,H,W,Cin], U from conv3x3_wino_pack -> [F,H,W,Cout] (or [F,H/2,W/2,Cout] with pool=True): conv + bias (+ ReLU) (+ 2x2/2
+    max-pool) as Winograd F(2x2,3x3) on the fp32 matrix cores."""
+    _chk(x_nhwc); _chk(U); _chk(bias)
+    F, H, W, Cin = x_nhwc.shape
+    if U.numel() != 16 * Cin * Cout:
+        raise NafaeOpError("conv3x3_wino: transformed-weight size mismatch")
+    out = torch.empty((F, H // 2, W // 2, Cout) if pool else (F, H, W, Cout), device=x_nhwc.device, dtype=torch.float32)
+    _rc(_lib.lib().nafae_conv3x3_wino(_p(x_nhwc), _p(U), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)) | (16 if pool else 0),
+                                      _stream()), "nafae_conv3x3_wino")
+    return out
+
+
 def maxpool2x2(x_nhwc):
     _chk(x_nhwc)
     F, H, W, C = x_nhwc.shape

@@ -1,0 +1,101 @@
+"""Winograd F(2x2,3x3) fp32 conv (nafae_conv3x3_wino, csrc/wino.hip) against the fp64 convolution of the same operands and against the
+direct implicit-GEMM kernel (nafae_conv3x3_relu_ws).  Replaces the reference's cuDNN conv layers (vgg16_rpn.py:38, rpn/rpn.py:63).
+
+Tolerance: every operation is fp32; Winograd's transforms change the summation order and add a few roundings, so the bar is
+2e-5 of the layer's largest |output| (measured 1e-6 .. 4e-6), next to the direct kernel's own error on the same case.  Every case
+is launched three times and the three results must be bit-identical (no atomics: a difference means a staging race).
+
+Shapes cover: both strip widths (8 and 7 tiles), partial strips (tile columns beyond the frame), row groups that change inside a
+workgroup (frame / strip changes: the 14^2 and 28^2 VGG layers), tile counts that are not a multiple of 64 (masked tail), one to
+many cout blocks, Cin 64 .. 512, the fused 2x2 max-pool, ReLU on / off, and every VGG16 layer shape at a reduced frame count."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPEAT = 3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from nafae_amd import ops as _ops
+    return _ops
+
+
+def _ref64(x, w, b, relu, pool):
+    y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1)
+    if relu:
+        y = torch.relu(y)
+    if pool:
+        y = torch.nn.functional.max_pool2d(y, 2, 2)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def _run(ops, F, H, W, Cin, Cout, relu, pool, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.randn(F, H, W, Cin, device='cuda', generator=g)
+    if seed & 1:
+        x = torch.relu(x)
+    w = torch.randn(Cout, 3, 3, Cin, device='cuda', generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device='cuda', generator=g) * 0.1
+    assert ops.wino_supported(F, H, W, Cin, Cout)
+    U = ops.conv3x3_wino_pack(w)
+    ys = [ops.conv3x3_wino(x, U, b, Cout, relu=relu, pool=pool) for _ in range(REPEAT)]
+    torch.cuda.synchronize()
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y), "results differ between launches"
+    ref = _ref64(x, w, b, relu, pool)
+    scale = float(ref.abs().max())
+    err = float((ys[0].double() - ref).abs().max()) / scale
+    yd = ops.conv3x3_relu(x, w, b, relu=relu, pool=pool)
+    err_d = float((yd.double() - ref).abs().max()) / scale
+    return err, err_d
+
+
+# (F, H, W, Cin, Cout): VGG16 layers 1_2 .. 5_3 + RPN at a reduced frame count (strip 8: 224, 112; strip 7: 56, 28, 14)
+VGG = [(2, 224, 224, 64, 64), (3, 112, 112, 64, 128), (3, 112, 112, 128, 128), (5, 56, 56, 128, 256), (5, 56, 56, 256, 256),
+       (9, 28, 28, 256, 512), (9, 28, 28, 512, 512), (33, 14, 14, 512, 512)]
+
+
+@pytest.mark.parametrize("shape", VGG, ids=lambda s: "F%d_%dx%d_%d-%d" % s)
+@pytest.mark.parametrize("pool", [False, True], ids=["", "pool"])
+def test_wino_vgg_layers(ops, shape, pool):
+    F, H, W, Cin, Cout = shape
+    err, err_d = _run(ops, F, H, W, Cin, Cout, True, pool, 1234 + H + Cin)
+    print("\n[wino %dx%d %d->%d F=%d%s] max err / max|y|: winograd %.2e, direct %.2e" % (H, W, Cin, Cout, F, " +pool" if pool else "", err, err_d))
+    assert err < 2e-5
+
+
+def _cases(n, seed):
+    rs = random.Random(seed)
+    out = []
+    for _ in range(n):
+        Cin = rs.choice([64, 96, 128, 256]); Cout = rs.choice([64, 128, 192, 256])
+        H = rs.choice([8, 10, 12, 14, 16, 20, 28, 30, 32, 48, 56]); W = rs.choice([8, 10, 14, 16, 18, 22, 28, 32, 36, 48, 56, 60])
+        F = rs.choice([1, 2, 3, 5, 8, 17])
+        if F * H * W * max(Cin, Cout) > 3.0e7:
+            F = max(1, int(3.0e7 / (H * W * max(Cin, Cout))))
+        out.append((F, H, W, Cin, Cout, rs.random() < 0.7, rs.random() < 0.4))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(40, 20261004),
+                         ids=lambda c: "F%d_%dx%d_%d-%d%s%s" % (c[0], c[1], c[2], c[3], c[4], "_relu" if c[5] else "", "_pool" if c[6] else ""))
+def test_wino_random_shapes(ops, case):
+    F, H, W, Cin, Cout, relu, pool = case
+    err, err_d = _run(ops, F, H, W, Cin, Cout, relu, pool, F * 131 + H * 17 + W * 3 + Cin)
+    assert err < 2e-5, "winograd %.2e (direct %.2e)" % (err, err_d)
+
+
+def test_wino_rejects_unsupported(ops):
+    assert not ops.wino_supported(4, 15, 16, 64, 64)      # odd height
+    assert not ops.wino_supported(4, 16, 16, 32, 64)      # Cin < 64
+    assert not ops.wino_supported(4, 16, 16, 64, 96)      # Cout % 64
+    assert not ops.wino_supported(4, 6, 16, 64, 64)       # fewer than 4 tile rows
+    x = torch.zeros(1, 15, 16, 64, device='cuda')
+    U = torch.zeros(16 * 64 * 64, device='cuda')
+    with pytest.raises(Exception):
+        ops.conv3x3_wino(x, U, torch.zeros(64, device='cuda'), 64)
