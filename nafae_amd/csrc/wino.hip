@@ -60,6 +60,13 @@ struct WinoGeom {
   int units;         // (64-tile groups) x NCB
 };
 
+// Variant builds only (scripts/wino_variants.sh: -DWN_DBG=bits): timing experiments whose RESULTS ARE GARBAGE -- bit 0: no weight
+// DMAs, 1: no input DMAs, 2: no barrier in the chunk loop, 3: no epilogue stores, 4: no transform adds, 5 / 6: no patch / weight
+// fragment reads.  The production and the experiments build compile with 0.
+#ifndef WN_DBG
+#define WN_DBG 0
+#endif
+
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void *p, size_t bytes) {
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
 template <int TW, bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U, const float *__restrict__ bias, float *__restrict__ out,
-                      const WinoGeom g) {
+                      const WinoGeom g, long long *__restrict__ stamps) {
   constexpr int PH = (TW + 1) * 16;           // bytes of one parity block of a staged row
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   char *smem = reinterpret_cast<char *>(smem_f);
@@ -203,12 +210,15 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   // ---- DMA issue (M0 = LDS destination of lane 0, written and read in ONE asm statement; tests/test_build_isa.py)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+  constexpr int dbg = WN_DBG;
   auto dma_w = [&](const char *src, int buf, int i) {          // piece i (0 .. 7) of this wave's quarter of a weight chunk
+    if (dbg & 1) return;
     const unsigned m0v = lds0 + (unsigned)(WN_LDS_W + buf * WN_WSTAGE) + (unsigned)(wave * 8 + i) * 1024u;
     const char *b = src + (size_t)(wave * 8 + i) * 1024;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(wl16), "s"(b) : "memory", "m0");
   };
   auto dma_i = [&](const WinoTile &t, int stage, int buf, int q, int pi) {   // channel quad q of piece wave + 4 pi
+    if (dbg & 2) return;
     const unsigned m0v = lds0 + (unsigned)(buf * WN_ISTAGE + q * WN_PLANE) + (unsigned)(wave + 4 * pi) * 1024u;
     const unsigned soff = (unsigned)(stage * 64 + q * 16);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
@@ -218,6 +228,15 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
 
   int u = blockIdx.x;
   if (u >= g.units) return;
+#ifdef NAFAE_EXPERIMENTS
+  // phase clocks (experiments build, stamps != nullptr): cycles per workgroup and wave spent in [prologue, first chunk of a tile,
+  // next-tile setup, the other chunks, epilogue], summed over the workgroup's tiles; written to memory nothing else reads
+  long long st_t0 = __builtin_amdgcn_s_memtime(), st_a = 0, st_sum[5] = {0, 0, 0, 0, 0};
+  int st_tiles = 0;
+#define WN_STAMP(i) do { if (stamps) { const long long st_b = __builtin_amdgcn_s_memtime(); st_sum[i] += st_b - st_a; st_a = st_b; } } while (0)
+#else
+#define WN_STAMP(i) do { } while (0)
+#endif
   WinoTile cur, nxt;
   setup(u, cur, 0);
   nxt = cur;
@@ -229,12 +248,14 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   // fragment / patch reads
   const unsigned wrd = (unsigned)(WN_LDS_W + wc * 1024) + wl16;
   auto read_b = [&](f32x4 (&dst)[4], int buf, int xi) {
+    if (dbg & 64) return;
 #pragma unroll
     for (int nu = 0; nu < 4; nu++)
       dst[nu] = *reinterpret_cast<const f32x4 *>(smem + wrd + buf * WN_WSTAGE + (xi * 4 + nu) * 2048);
   };
   // row a (0 .. 3) of the lane's 4x4 patch; ab = patch origin incl. the stage buffer, sub = which 8-channel half of the stage
   auto read_row = [&](f32x4 (&dst)[4], unsigned ab, int sub, int a) {
+    if (dbg & 32) return;
 #pragma unroll
     for (int j = 0; j < 4; j++)
       dst[j] = *reinterpret_cast<const f32x4 *>(smem + ab + sub * 2 * WN_PLANE + a * WN_RP + (j & 1) * PH + (j >> 1) * 16);
@@ -304,14 +325,25 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
         }
     };
     // the position-row transform: t = ra (+/-) rb per pixel column (slots 5 .. 8), then the four positions of the row (slots 9 .. 12)
+    // (the empty asm pins each result in its gap: without it the compiler sinks the adds down to the MFMA that first reads them,
+    // i.e. in front of the next row's first MFMAs, where they delay the matrix pipe instead of hiding behind it)
     auto tcol = [&](int k, const f32x4 (&ra)[4], const f32x4 (&rb)[4], bool add) {
-      if (k >= 5 && k <= 8) t[k - 5] = add ? ra[k - 5] + rb[k - 5] : ra[k - 5] - rb[k - 5];
+      if (k >= 5 && k <= 8) {
+        if (dbg & 16) t[k - 5] = ra[k - 5];
+        else t[k - 5] = add ? ra[k - 5] + rb[k - 5] : ra[k - 5] - rb[k - 5];
+        asm volatile("" : "+v"(t[k - 5]));
+      }
     };
     auto trow = [&](int k, f32x4 (&dst)[4]) {
-      if (k == 9) dst[0] = t[0] - t[2];
-      if (k == 10) dst[1] = t[1] + t[2];
-      if (k == 11) dst[2] = t[2] - t[1];
-      if (k == 12) dst[3] = t[1] - t[3];
+      if (dbg & 16) {
+        if (k >= 9 && k <= 12) dst[k - 9] = t[k - 9];
+      } else {
+        if (k == 9) dst[0] = t[0] - t[2];
+        if (k == 10) dst[1] = t[1] + t[2];
+        if (k == 11) dst[2] = t[2] - t[1];
+        if (k == 12) dst[3] = t[1] - t[3];
+      }
+      if (k >= 9 && k <= 12) asm volatile("" : "+v"(dst[k - 9]));
     };
     using X0 = std::integral_constant<int, 0>;
     using X1 = std::integral_constant<int, 1>;
@@ -360,7 +392,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
           if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         read_b(B[0], ODD ? 0 : 1, 0);
       }
@@ -395,7 +427,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
       }
       float y00 = (s0[0] + s0[1]) + s0[2], y10 = (s0[1] - s0[2]) - s0[3];
       float y01 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
-      const unsigned vo = toff + cob;    // (bit 31 survives the add: cob < 2^31 and the store is dropped)
+      const unsigned vo = (dbg & 8) ? WN_OOB : toff + cob;    // (bit 31 survives the add: cob < 2^31 and the store is dropped)
       if (POOL) {
         float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bv;
         if (relu) v = fmaxf(v, 0.f);
@@ -415,23 +447,44 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
 
   using T_ = std::true_type;
   using F_ = std::false_type;
+#ifdef NAFAE_EXPERIMENTS
+  if (stamps) st_a = st_t0;
+#endif
+  WN_STAMP(0);
   for (int it = 0;; it++) {
     const int un = u + (int)gridDim.x;
     const bool has_next = un < g.units;
     chunk(T_{}, F_{}, 0, false);
+    WN_STAMP(1);
     // (behind chunk 0's barrier: every wave has left the previous tile's epilogue, whose table slot this overwrites)
     setup(has_next ? un : u, nxt, (it + 1) & 1);
+    WN_STAMP(2);
     chunk(F_{}, T_{}, 1, false);
     for (int s = 1; s < NSG; s++) {
       chunk(F_{}, F_{}, 2 * s, false);
       chunk(F_{}, T_{}, 2 * s + 1, s + 1 == NSG);
     }
+    WN_STAMP(3);
     epilogue(u, it & 1);
+    WN_STAMP(4);
+#ifdef NAFAE_EXPERIMENTS
+    st_tiles++;
+#endif
     if (!has_next) break;
     cur = nxt;
     u = un;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the workgroup has gone
+#ifdef NAFAE_EXPERIMENTS
+  if (stamps && lane == 0) {
+    long long *o = stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    o[0] = st_tiles;
+#pragma unroll
+    for (int i = 0; i < 5; i++) o[1 + i] = st_sum[i];
+    o[6] = __builtin_amdgcn_s_memtime() - st_t0;
+    o[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 inline hipStream_t WS(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -444,6 +497,14 @@ inline int wn_cus() {
   }
   return n;
 }
+
+// experiments build: phase-clock buffer set by nafae_wino_debug_stamps (nullptr = off); the production build has none
+#ifdef NAFAE_EXPERIMENTS
+long long *g_wn_stamps = nullptr;
+inline long long *wn_stamps() { return g_wn_stamps; }
+#else
+inline long long *wn_stamps() { return nullptr; }
+#endif
 
 // strip width: 8 or 7 tiles, whichever wastes fewer tile slots on this frame width (VGG at 224^2: 112 / 56 -> 8, 28 / 14 / 7 -> 7)
 inline int wn_strip(int Wt) {
@@ -506,13 +567,18 @@ int nafae_conv3x3_wino(const float *in, const float *U, const float *bias, float
   if (nafae::allow_dynamic_lds(k, WN_LDS_TOTAL) != NAFAE_OK) return NAFAE_ELAUNCH;
   NAFAE_TAG("wino_conv<%d>%s", TW, pool ? "+pool" : "");
   if (pool) {
-    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
-    else hipLaunchKernelGGL((wino_conv_kernel<7, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
+    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
+    else hipLaunchKernelGGL((wino_conv_kernel<7, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
   } else {
-    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
-    else hipLaunchKernelGGL((wino_conv_kernel<7, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g);
+    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
+    else hipLaunchKernelGGL((wino_conv_kernel<7, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
   }
   return nafae::launch_status();
 }
+
+#ifdef NAFAE_EXPERIMENTS
+/* experiments build only: buf = device buffer of (workgroups x 4 waves x 8) int64 phase clocks, or NULL to switch them off */
+void nafae_wino_debug_stamps(void *buf) { g_wn_stamps = reinterpret_cast<long long *>(buf); }
+#endif
 
 }  // extern "C"
