@@ -60,8 +60,18 @@ MODE_INFO = {
 
 
 def flops_per_frame(Nb):
-    """Algorithmic FLOPs of the detector forward per frame."""
+    """Algorithmic FLOPs of the detector forward per frame: every 3x3 conv counted as a direct convolution."""
     return 30.693e9 + 0.939e9 + Nb * (205.5e6 + 33.55e6 + 4.19e6)
+
+
+WINO_CONV_FLOPS_PER_FRAME = (30.693e9 - 0.1734e9) + 0.9248e9     # conv1_2 .. conv5_3 + the RPN 3x3 conv, as direct convolutions
+
+
+def issued_flops_per_frame(Nb, conv_algo):
+    """Matrix-core FLOPs the detector actually issues per frame: Winograd F(2x2,3x3) issues 16 multiply-adds where the direct
+    convolution issues 36 (all layers but conv1_1 and the 1x1 heads, at 224x224 every one of them is taken by the Winograd kernel)."""
+    f = flops_per_frame(Nb)
+    return f - WINO_CONV_FLOPS_PER_FRAME * (1.0 - 1.0 / 2.25) if conv_algo == "winograd" else f
 
 
 def pmc_traffic(kernel_key):
@@ -364,6 +374,8 @@ def run_rank(a):
     Na_model = Na * world if exact else Na          # exact mode: ONE batch of world*Na segments, every rank sees all queries
     args = default_args(batch_size=Na_model, sample_num=Ns, max_ent_len=Ne, Delta=10.0, vis_lam=4.13)
     model, opt, crit, reducer = setup_training(args, device=dev, seed=1234, distributed=distributed, grad_exchange=a.grad_exchange)
+    if a.conv_algo:
+        model.fasterRCNN.conv_algo = a.conv_algo
     if exact:
         batch = shard_frames(make_batch(Na_model, Ns, Ne, seed=1234, device=dev), rank, world)
     else:
@@ -453,10 +465,17 @@ def run_rank(a):
         det_ms = sum(v["avg_ms"] for k, v in prof.items() if k in ("base", "rpn", "roi_align", "fc6", "fc7"))
         if det_ms > 0:
             alg = F * flops_per_frame(Nb) / (det_ms * 1e-3) / 1e12
-            res["detector"] = {"algorithmic_tflops": round(alg, 2), "mfma_frac": round(alg / peak, 4),
-                               "mfma_issue_util": round(nprod * alg / peak, 4), "sum_of_stage_ms": round(det_ms, 3),
-                               "note": "stages timed with HIP events on the detector stream; under the step pipeline they "
-                                       "include contention with the overlapped tail"}
+            algo = model.fasterRCNN.conv_algo if prec == "f32" else "direct"
+            iss = F * issued_flops_per_frame(Nb, algo) / (det_ms * 1e-3) / 1e12
+            res["detector"] = {"conv_algorithm": ("winograd F(2x2,3x3), fp32 (conv1_2 .. conv5_3 + RPN conv; conv1_1 direct)"
+                                                  if algo == "winograd" else "direct implicit GEMM"),
+                               "algorithmic_tflops": round(alg, 2), "issued_tflops": round(iss, 2),
+                               "mfma_frac": round(iss / peak, 4), "mfma_issue_util": round(nprod * iss / peak, 4),
+                               "direct_equivalent_frac": round(alg / peak, 4), "sum_of_stage_ms": round(det_ms, 3),
+                               "note": "mfma_frac = ISSUED matrix flops / dense peak (what the hardware does); direct_equivalent_frac "
+                                       "prices the same step as if every conv were a direct convolution (Winograd issues 1/2.25 of "
+                                       "those flops, so it may exceed 1).  Stages timed with HIP events on the detector stream; under "
+                                       "the step pipeline they include contention with the overlapped tail"}
         return res
 
     head_prec = a.precision or "f32"
@@ -482,6 +501,7 @@ def run_rank(a):
                        "grad_allreduce_bytes": reducer.nbytes if distributed else 0,
                        "grad_exchange": a.grad_exchange if distributed else None,
                        "step_pipeline": head["step_pipeline"],
+                       "conv_algorithm": model.fasterRCNN.conv_algo if head_prec == "f32" else "direct",
                        "input": ("streamed: a different pinned-host uint8 HWC batch every step (4 in rotation), H2D on a copy stream "
                                  "into two device buffers, first conv layer reads the bytes (-127.5 in-kernel)") if a.stream_input
                                 else "resident fp32 NCHW frames (the same batch every step)"},
@@ -527,6 +547,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c2 on one GPU, c4 (BASELINE's 8-GPU data-parallel config, per GPU) on several")
+    ap.add_argument("--conv-algo", default=None, choices=["winograd", "direct"],
+                    help="3x3 conv algorithm of the exact-fp32 mode (default: the library's, winograd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run detector and tail of a step back to back on one stream (default: the frozen detector of step "

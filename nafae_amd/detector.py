@@ -90,6 +90,13 @@ class _fasterRCNN(nn.Module):
         #            grounding accuracy on the own-segment detections is unchanged: test_grounding_accuracy_delta_vs_oracle);
         #   'bf16'   plain bf16 operands (BASELINE config C3; parity at bf16 tolerance only).
         self.precision = os.environ.get("NAFAE_PRECISION", "f32")
+        # algorithm of the 3x3 conv layers in 'f32' mode (conv1_1, Cin = 3, is always direct):
+        #   'winograd' (default since round 5) F(2x2,3x3) on the fp32 matrix cores (csrc/wino.hip): 2.25x fewer multiply-adds, every
+        #              operation fp32 -- the algorithm family cuDNN picks for the reference's 3x3 fp32 layers.  Agrees with 'direct'
+        #              to fp32 rounding (its error against an fp64 conv is the smaller of the two: the K sums are 9x shorter);
+        #              a layer whose shape the kernel does not take (odd sizes, Cin < 64, ...) runs 'direct'.
+        #   'direct'   implicit GEMM (csrc/gemm.hip), bit for bit an fp32 FMA chain per output.
+        self.conv_algo = os.environ.get("NAFAE_CONV_ALGO", "winograd")
         self.materialize_pooled = True     # bf16 modes: also hand out pooled_feat as fp32 (API parity)
         self.conv_streams = int(os.environ.get("NAFAE_CONV_STREAMS", "1"))
         # stream-K schedule of the quantised conv layers (nafae_conv3x3_bf16_ws with a workspace).  Which tiles it cuts -- hence
@@ -101,7 +108,7 @@ class _fasterRCNN(nn.Module):
     # ------------------------------------------------------------------ weights -> kernel layout
     def _pack_key(self):
         ps = list(self.parameters())
-        return (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.conv_algo) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate_packed(self):
         """Drop the kernel-layout copies of the weights.  `_pack_key` sees load_state_dict / .to() / in-place ops on the
@@ -135,6 +142,15 @@ class _fasterRCNN(nn.Module):
             P['fc6_b'] = fc6.bias.detach().contiguous()
             P['fc7_w'] = fc7.weight.detach().contiguous()
             P['fc7_b'] = fc7.bias.detach().contiguous()
+            if self.precision == 'f32':
+                if self.conv_algo not in ('winograd', 'direct'):
+                    raise ValueError("conv_algo must be 'winograd' or 'direct', got %r" % (self.conv_algo,))
+                if self.conv_algo == 'winograd':   # transformed weights U = G g G^T in the kernel's fragment order (None: layer stays direct)
+                    def wino(w):
+                        Cout, Cin = w.shape[0], w.shape[3]
+                        return ops.conv3x3_wino_pack(w) if (Cin >= 64 and Cin % 32 == 0 and Cout % 64 == 0) else None
+                    P['convs_u'] = [wino(w) for (w, _) in P['convs']]
+                    P['rpn_u'] = wino(P['rpn_w'])
             anc = generate_anchors(scales=np.array(r.anchor_scales), ratios=np.array(r.anchor_ratios))
             P['anchors'] = torch.from_numpy(anc).float().to(c0.weight.device)
             if self.precision != 'f32':
@@ -186,11 +202,19 @@ class _fasterRCNN(nn.Module):
                 k += 1
                 continue
             w, b = P['convs'][li]
+            u = P['convs_u'][li] if 'convs_u' in P else None
             li += 1
             fused = k + 1 < len(seq) and seq[k + 1] == 'M'          # conv + ReLU + max-pool: fused where the library can
-            x = ops.conv3x3_relu(x, w, b, relu=True, use_workspace=self.conv_stream_k, pool=fused)
+            x = self._conv_f32(x, w, u, b, pool=fused)
             k += 2 if fused else 1
         return x
+
+    def _conv_f32(self, x, w, u, b, pool=False):
+        """One 3x3 conv + ReLU (+ pool) layer in 'f32' mode: Winograd where packed and the shape is taken, else the direct kernel."""
+        F, H, W, Cin = x.shape
+        if u is not None and ops.wino_supported(F, H, W, Cin, w.shape[0]):
+            return ops.conv3x3_wino(x, u, b, w.shape[0], relu=True, pool=pool)
+        return ops.conv3x3_relu(x, w, b, relu=True, use_workspace=self.conv_stream_k, pool=pool)
 
     def base_features(self, im_data):
         """RCNN_base (vgg16_rpn.py:38) -> NHWC [F, H/16, W/16, 512] (fp32 tensor, or ops.Planes in the bf16 modes).
@@ -240,7 +264,7 @@ class _fasterRCNN(nn.Module):
             x, _ = ops.conv3x3_bf16(base_feat, P['rpn_w_h'], P['rpn_b'], relu=True, want_f32=True, want_planes=False,
                                     use_workspace=self.conv_stream_k)
         else:
-            x = ops.conv3x3_relu(base_feat, P['rpn_w'], P['rpn_b'], relu=True, use_workspace=self.conv_stream_k)
+            x = self._conv_f32(base_feat, P['rpn_w'], P.get('rpn_u'), P['rpn_b'])
         head = ops.gemm_nt(x.view(F * h * w, 512), P['head_w'], P['head_b'])
         scores, boxes = ops.rpn_decode(head, P['anchors'], im_info.contiguous().float(), F, h, w, A, r.feat_stride)
         order = ops.sort_desc(scores)

@@ -42,6 +42,8 @@ def main():
             r = fn(*a, **kw)
             tag = L.nafae_last_kernel_id().decode()
             sig = " ".join(s for s in (shape_of(x) for x in a[:nargs]) if s)
+            if name == "conv3x3_wino":                 # (x, U, bias, Cout): the transformed weights are a flat tensor
+                sig += " Cout=%d" % a[3]
             extra = ""
             if name.startswith("conv3x3") and kw.get("pool"):
                 extra = " pool"
@@ -52,7 +54,7 @@ def main():
             return r
         setattr(ops, name, wrapped)
 
-    for name, nargs in (("conv3x3_relu", 2), ("conv3x3_bf16", 2), ("gemm_nt", 2), ("gemm_nt_bf16", 2), ("sim_max_fwd_frames", 2),
+    for name, nargs in (("conv3x3_relu", 2), ("conv3x3_wino", 1), ("conv3x3_bf16", 2), ("gemm_nt", 2), ("gemm_nt_bf16", 2), ("sim_max_fwd_frames", 2),
                         ("loss_fwd_bwd", 1), ("sim_bwd", 1), ("sim_bwd_frames", 1)):
         wrap(name, nargs)
 
@@ -69,8 +71,10 @@ def main():
         for lens_kind in ("hist", "all-live"):
             lens = syn.entity_lengths(Na, Ne, seed=1234) if lens_kind == "hist" else [Ne] * Na
             batch = make_batch(Na, Ns, Ne, seed=1234, device="cuda", lens=lens)
-            for prec in (("f32", "bf16x3", "bf16") if lens_kind == "hist" else ("bf16x3",)):
-                model.fasterRCNN.precision = prec
+            # "f32" = the default exact-fp32 route (Winograd convs); "f32-direct" keeps the implicit-GEMM convs pinned as well
+            for prec in (("f32", "f32-direct", "bf16x3", "bf16") if lens_kind == "hist" else ("bf16x3",)):
+                model.fasterRCNN.precision = prec.split("-")[0]
+                model.fasterRCNN.conv_algo = "direct" if prec.endswith("-direct") else "winograd"
                 ctx["label"] = "%s/%s/%s " % (wl, prec, lens_kind)
                 train_step(model, opt, crit, batch, args, reducer)
         torch.cuda.synchronize()
