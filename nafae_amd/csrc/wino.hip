@@ -41,14 +41,20 @@
 namespace {
 
 constexpr int WN_RP = 320;                    // LDS bytes per staged input row: 2 parity blocks of (TW + 1) 16-B slots, 20 slots
-constexpr int WN_NROWS = 28;                  // rows a workgroup's 64 tiles can need (10 tile rows in up to 4 row groups)
-constexpr int WN_NPIECE = 9;                  // 1-KB DMA pieces per plane (28 rows x 20 slots = 560 slots <= 576)
-constexpr int WN_PLANE = WN_NPIECE * 1024;    // one channel quad of one 16-channel stage
-constexpr int WN_ISTAGE = 4 * WN_PLANE;       // 36 864 B
+// Staged-image geometry.  Generic: the workgroup's 64 tiles can need 28 rows (10 tile rows in up to 4 row groups).  LEAN: 8-tile
+// strips whose 8-row blocks never leave a frame (tile rows per frame % 8 == 0: the 224^2 and 112^2 VGG layers) need 18 rows -- a
+// third fewer input DMAs.
+template <bool LEAN>
+struct WnGeo {
+  static constexpr int NROWS = LEAN ? 18 : 28;
+  static constexpr int NP = LEAN ? 6 : 9;           // 1-KB DMA pieces per plane (rows x 20 slots of 16 B)
+  static constexpr int PLANE = NP * 1024;           // one channel quad of one 16-channel stage
+  static constexpr int ISTAGE = 4 * PLANE;          // 24 576 / 36 864 B
+  static constexpr int LDS_W = 2 * ISTAGE;
+  static constexpr int LDS_TAB = LDS_W + 2 * 32768;
+  static constexpr int LDS_TOTAL = LDS_TAB + 2 * 256;
+};
 constexpr int WN_WSTAGE = 32768;              // one 8-channel chunk of transformed weights for 64 output channels
-constexpr int WN_LDS_W = 2 * WN_ISTAGE;
-constexpr int WN_LDS_TAB = WN_LDS_W + 2 * WN_WSTAGE;
-constexpr int WN_LDS_TOTAL = WN_LDS_TAB + 2 * 256;   // 139 776 B
 constexpr unsigned WN_OOB = 0x80000000u;
 
 struct WinoGeom {
@@ -76,6 +82,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void *p, size_t 
 __device__ __forceinline__ void wn_fence() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// f32x4 add / subtract of the input transform.  WN_PK (variant builds): as two v_pk_add_f32 instead of four v_add_f32.
+#ifndef WN_PK
+#define WN_PK 0
+#endif
+__device__ __forceinline__ f32x4 wn_add4(f32x4 a, f32x4 b) {
+#if WN_PK
+  f32x2 lo, hi, alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(alo), "v"(blo));
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(ahi), "v"(bhi));
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
+  return a + b;
+#endif
+}
+__device__ __forceinline__ f32x4 wn_sub4(f32x4 a, f32x4 b) {
+#if WN_PK
+  f32x2 lo, hi, alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
+  return a - b;
+#endif
 }
 
 struct WinoTile {
@@ -111,10 +142,11 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
   }
 }
 
-template <int TW, bool POOL>
+template <int TW, bool LEAN, bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U, const float *__restrict__ bias, float *__restrict__ out,
                       const WinoGeom g, long long *__restrict__ stamps) {
+  using G = WnGeo<LEAN>;
   constexpr int PH = (TW + 1) * 16;           // bytes of one parity block of a staged row
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   char *smem = reinterpret_cast<char *>(smem_f);
@@ -127,7 +159,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   const __amdgpu_buffer_rsrc_t in_rsrc = wn_rsrc(in, (size_t)g.F * H * W * Cin * sizeof(float));
   const size_t out_px = POOL ? (size_t)g.F * TH * g.Wt : (size_t)g.F * H * W;
   const __amdgpu_buffer_rsrc_t out_rsrc = wn_rsrc(out, out_px * Cout * sizeof(float));
-  int *table = reinterpret_cast<int *>(smem + WN_LDS_TAB);
+  int *table = reinterpret_cast<int *>(smem + G::LDS_TAB);
   const unsigned wl16 = (unsigned)lane * 16u;
 
   // ---- per-tile lane state (see the header): computed one tile ahead of the DMA stream
@@ -152,7 +184,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
         if (d >= TH) { d -= TH; k++; }
         rho = b1 + k * GRP + 2 * d;
       }
-      t.abase = (unsigned)(rho * WN_RP + tx * 16 + h * WN_PLANE);
+      t.abase = (unsigned)(rho * WN_RP + tx * 16 + h * G::PLANE);
     }
     // row group k (0 .. 3) -> (frame, strip)
     auto frame_strip = [&](int k, int &f, int &s) {
@@ -185,7 +217,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const int p = wave + 4 * i;                 // (i = 2: wave 0 only)
+      const int p = wave + 4 * i;                 // (pieces beyond the plane: never issued)
       const int sig = 64 * p + lane;
       const int rho = sig / 20, sr = sig - rho * 20;
       const int par = sr >= TW + 1 ? 1 : 0, xh = sr - par * (TW + 1), x = 2 * xh + par;
@@ -202,7 +234,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
       int f, s;
       frame_strip(k, f, s);
       const int gx = s * 2 * TW - 1 + x;
-      const bool ok = sr < 2 * (TW + 1) && rho < WN_NROWS && ga + k < g.NG && y >= 0 && y < H && gx >= 0 && gx < W;
+      const bool ok = sr < 2 * (TW + 1) && rho < G::NROWS && ga + k < g.NG && y >= 0 && y < H && gx >= 0 && gx < W;
       t.voff[i] = ok ? (unsigned)((f * H + y) * W + gx) * (unsigned)Cin * 4u : WN_OOB;
     }
   };
@@ -213,13 +245,15 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   constexpr int dbg = WN_DBG;
   auto dma_w = [&](const char *src, int buf, int i) {          // piece i (0 .. 7) of this wave's quarter of a weight chunk
     if (dbg & 1) return;
-    const unsigned m0v = lds0 + (unsigned)(WN_LDS_W + buf * WN_WSTAGE) + (unsigned)(wave * 8 + i) * 1024u;
+    const unsigned m0v = lds0 + (unsigned)(G::LDS_W + buf * WN_WSTAGE) + (unsigned)(wave * 8 + i) * 1024u;
     const char *b = src + (size_t)(wave * 8 + i) * 1024;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(wl16), "s"(b) : "memory", "m0");
   };
+  const bool has1 = wave + 4 < G::NP, has2 = wave + 8 < G::NP;     // this wave owns a second / third input piece
   auto dma_i = [&](const WinoTile &t, int stage, int buf, int q, int pi) {   // channel quad q of piece wave + 4 pi
     if (dbg & 2) return;
-    const unsigned m0v = lds0 + (unsigned)(buf * WN_ISTAGE + q * WN_PLANE) + (unsigned)(wave + 4 * pi) * 1024u;
+    if ((pi == 1 && !has1) || (pi == 2 && !has2)) return;
+    const unsigned m0v = lds0 + (unsigned)(buf * G::ISTAGE + q * G::PLANE) + (unsigned)(wave + 4 * pi) * 1024u;
     const unsigned soff = (unsigned)(stage * 64 + q * 16);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
                  : "memory", "m0");
@@ -246,7 +280,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   f32x4 r0[4], r1[4], r2[4], r3[4];   // raw patch rows of the lane's tile: 4 pixels x 4 channels each
 
   // fragment / patch reads
-  const unsigned wrd = (unsigned)(WN_LDS_W + wc * 1024) + wl16;
+  const unsigned wrd = (unsigned)(G::LDS_W + wc * 1024) + wl16;
   auto read_b = [&](f32x4 (&dst)[4], int buf, int xi) {
     if (dbg & 64) return;
 #pragma unroll
@@ -258,7 +292,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     if (dbg & 32) return;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      dst[j] = *reinterpret_cast<const f32x4 *>(smem + ab + sub * 2 * WN_PLANE + a * WN_RP + (j & 1) * PH + (j >> 1) * 16);
+      dst[j] = *reinterpret_cast<const f32x4 *>(smem + ab + sub * 2 * G::PLANE + a * WN_RP + (j & 1) * PH + (j >> 1) * 16);
   };
 
   // ---- prologue: what the DMA stream would have issued before the first chunk -- weight chunk 0, the first 5 pieces of weight
@@ -270,7 +304,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     for (int i = 0; i < 5; i++) dma_w(cur.wsrc + WN_WSTAGE, 1, i);
 #pragma unroll
     for (int pi = 0; pi < 3; pi++)
-      if (pi < 2 || wave == 0) {
+      {
 #pragma unroll
         for (int q = 0; q < 4; q++) dma_i(cur, 0, 0, q, pi);
       }
@@ -293,9 +327,9 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   auto chunk = [&](auto first_tag, auto odd_tag, int c, bool last) {
     constexpr bool FIRST = decltype(first_tag)::value, ODD = decltype(odd_tag)::value;
     const int s = c >> 1;                                   // input stage of this chunk
-    const unsigned ab = cur.abase + (unsigned)((s & 1) * WN_ISTAGE);
+    const unsigned ab = cur.abase + (unsigned)((s & 1) * G::ISTAGE);
     // next chunk's patch origin / stage buffer
-    const unsigned abn = ODD ? (last ? nxt.abase : cur.abase + (unsigned)(((s + 1) & 1) * WN_ISTAGE)) : ab;
+    const unsigned abn = ODD ? (last ? nxt.abase : cur.abase + (unsigned)(((s + 1) & 1) * G::ISTAGE)) : ab;
     // weight chunk c + 1 / c + 2 and input stage s + 1 as seen by the DMA stream (may belong to the next tile)
     const char *w1 = c + 1 < NC ? cur.wsrc + (size_t)(c + 1) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 1 - NC) * WN_WSTAGE;
     const char *w2 = c + 2 < NC ? cur.wsrc + (size_t)(c + 2) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 2 - NC) * WN_WSTAGE;
@@ -330,7 +364,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     auto tcol = [&](int k, const f32x4 (&ra)[4], const f32x4 (&rb)[4], bool add) {
       if (k >= 5 && k <= 8) {
         if (dbg & 16) t[k - 5] = ra[k - 5];
-        else t[k - 5] = add ? ra[k - 5] + rb[k - 5] : ra[k - 5] - rb[k - 5];
+        else t[k - 5] = add ? wn_add4(ra[k - 5], rb[k - 5]) : wn_sub4(ra[k - 5], rb[k - 5]);
         asm volatile("" : "+v"(t[k - 5]));
       }
     };
@@ -338,10 +372,10 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
       if (dbg & 16) {
         if (k >= 9 && k <= 12) dst[k - 9] = t[k - 9];
       } else {
-        if (k == 9) dst[0] = t[0] - t[2];
-        if (k == 10) dst[1] = t[1] + t[2];
-        if (k == 11) dst[2] = t[2] - t[1];
-        if (k == 12) dst[3] = t[1] - t[3];
+        if (k == 9) dst[0] = wn_sub4(t[0], t[2]);
+        if (k == 10) dst[1] = wn_add4(t[1], t[2]);
+        if (k == 11) dst[2] = wn_sub4(t[2], t[1]);
+        if (k == 12) dst[3] = wn_sub4(t[1], t[3]);
       }
       if (k >= 9 && k <= 12) asm volatile("" : "+v"(dst[k - 9]));
     };
@@ -366,7 +400,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
         if (k == 1) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 3, 0);
         if (k >= 2 && k <= 4) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 2, 1);
         if (k == 13) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 3, 1);
-        if (wave == 0 && k >= 14) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 14, 2);
+        if (k >= 14) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 14, 2);
       }
       tcol(k, r2, r1, false);
       trow(k, A[0]);
@@ -375,7 +409,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     row(X2{}, X0{}, [&](int k) {
       if (k == 0) read_b(B[1], ODD ? 1 : 0, 3);
       if (k == 1) read_row(r3, ab, ODD ? 1 : 0, 3);
-      if (!ODD && wave == 0 && (k == 2 || k == 3)) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k, 2);
+      if (!ODD && (k == 2 || k == 3)) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k, 2);
       tcol(k, r1, r3, false);
       trow(k, A[1]);
     });
@@ -389,8 +423,9 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
         if (ODD) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {            // the input pieces issued in this chunk (stage s + 1) may stay in flight: 12 (wave 0) / 8
-          if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          if (has2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else if (has1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
         if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -521,6 +556,14 @@ inline bool wn_shape_ok(int F, int H, int W, int Cin, int Cout) {
   return tiles * (Cout / 64) / 64 < (1L << 30);
 }
 
+template <int TW, bool LEAN, bool POOL>
+int wn_launch(int grid, const float *in, const float *U, const float *bias, float *out, const WinoGeom &g, void *stream) {
+  const void *k = reinterpret_cast<const void *>(wino_conv_kernel<TW, LEAN, POOL>);
+  if (nafae::allow_dynamic_lds(k, WnGeo<LEAN>::LDS_TOTAL) != NAFAE_OK) return NAFAE_ELAUNCH;
+  hipLaunchKernelGGL((wino_conv_kernel<TW, LEAN, POOL>), dim3(grid), dim3(256), WnGeo<LEAN>::LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
+  return nafae::launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -562,18 +605,13 @@ int nafae_conv3x3_wino(const float *in, const float *U, const float *bias, float
   if (grid > g.units) grid = g.units;
   if (grid >= g.NCB) grid -= grid % g.NCB;
   const bool pool = (relu & 16) != 0;
-  const void *k = pool ? (TW == 8 ? reinterpret_cast<const void *>(wino_conv_kernel<8, true>) : reinterpret_cast<const void *>(wino_conv_kernel<7, true>))
-                       : (TW == 8 ? reinterpret_cast<const void *>(wino_conv_kernel<8, false>) : reinterpret_cast<const void *>(wino_conv_kernel<7, false>));
-  if (nafae::allow_dynamic_lds(k, WN_LDS_TOTAL) != NAFAE_OK) return NAFAE_ELAUNCH;
-  NAFAE_TAG("wino_conv<%d>%s", TW, pool ? "+pool" : "");
-  if (pool) {
-    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
-    else hipLaunchKernelGGL((wino_conv_kernel<7, true>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
-  } else {
-    if (TW == 8) hipLaunchKernelGGL((wino_conv_kernel<8, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
-    else hipLaunchKernelGGL((wino_conv_kernel<7, false>), dim3(grid), dim3(256), WN_LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
+  const bool lean = TW == 8 && g.TH % 8 == 0;
+  NAFAE_TAG("wino_conv<%d%s>%s", TW, lean ? ",lean" : "", pool ? "+pool" : "");
+  if (TW == 8) {
+    if (lean) return pool ? wn_launch<8, true, true>(grid, in, U, bias, out, g, stream) : wn_launch<8, true, false>(grid, in, U, bias, out, g, stream);
+    return pool ? wn_launch<8, false, true>(grid, in, U, bias, out, g, stream) : wn_launch<8, false, false>(grid, in, U, bias, out, g, stream);
   }
-  return nafae::launch_status();
+  return pool ? wn_launch<7, false, true>(grid, in, U, bias, out, g, stream) : wn_launch<7, false, false>(grid, in, U, bias, out, g, stream);
 }
 
 #ifdef NAFAE_EXPERIMENTS
