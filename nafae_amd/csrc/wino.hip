@@ -72,6 +72,10 @@ struct WinoGeom {
 #ifndef WN_DBG
 #define WN_DBG 0
 #endif
+// cache policy of the input DMAs (variant builds): 0 default, 1 nt, 2 sc1, 3 sc0 sc1
+#ifndef WN_INT
+#define WN_INT 0
+#endif
 
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 
@@ -217,7 +221,8 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const int p = wave + 4 * i;                 // (pieces beyond the plane: never issued)
+      // the pieces this wave issues (dma_i): its own, its second (generic) or its share of a split one (LEAN), the split piece 8 (generic)
+      const int p = i == 0 ? wave : i == 1 ? (LEAN ? 4 + (wave >> 1) : wave + 4) : 8;
       const int sig = 64 * p + lane;
       const int rho = sig / 20, sr = sig - rho * 20;
       const int par = sr >= TW + 1 ? 1 : 0, xh = sr - par * (TW + 1), x = 2 * xh + par;
@@ -249,14 +254,31 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     const char *b = src + (size_t)(wave * 8 + i) * 1024;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(wl16), "s"(b) : "memory", "m0");
   };
-  const bool has1 = wave + 4 < G::NP, has2 = wave + 8 < G::NP;     // this wave owns a second / third input piece
-  auto dma_i = [&](const WinoTile &t, int stage, int buf, int q, int pi) {   // channel quad q of piece wave + 4 pi
+  // Input DMA n (0 .. NI-1) of this wave for one stage: every wave issues the same number, so the chunk barrier does not wait for
+  // a slower wave (a gathered input piece costs ~110 cycles of issue; with 12 against 8 the other three waves idled ~100 cycles per
+  // chunk).  Generic (9 pieces x 4 quads): pieces wave and wave + 4 whole, quad `wave` of piece 8.  LEAN (6 x 4): piece wave whole,
+  // two quads of piece 4 + (wave >> 1).
+  constexpr int NI = LEAN ? 6 : 9;
+  auto dma_i = [&](const WinoTile &t, int stage, int buf, int n) {
     if (dbg & 2) return;
-    if ((pi == 1 && !has1) || (pi == 2 && !has2)) return;
-    const unsigned m0v = lds0 + (unsigned)(buf * G::ISTAGE + q * G::PLANE) + (unsigned)(wave + 4 * pi) * 1024u;
+    const int pi = n < 4 ? 0 : (LEAN || n < 8) ? 1 : 2;
+    const int p = pi == 0 ? wave : pi == 1 ? (LEAN ? 4 + (wave >> 1) : wave + 4) : 8;
+    const int q = n < 4 ? n : LEAN ? 2 * (wave & 1) + (n - 4) : n < 8 ? n - 4 : wave;
+    const unsigned m0v = lds0 + (unsigned)(buf * G::ISTAGE + q * G::PLANE) + (unsigned)p * 1024u;
     const unsigned soff = (unsigned)(stage * 64 + q * 16);
+#if WN_INT == 1
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+                 : "memory", "m0");
+#elif WN_INT == 2
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+                 : "memory", "m0");
+#elif WN_INT == 3
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+                 : "memory", "m0");
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
                  : "memory", "m0");
+#endif
   };
 #pragma clang diagnostic pop
 
@@ -268,8 +290,16 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   long long st_t0 = __builtin_amdgcn_s_memtime(), st_a = 0, st_sum[5] = {0, 0, 0, 0, 0};
   int st_tiles = 0;
 #define WN_STAMP(i) do { if (stamps) { const long long st_b = __builtin_amdgcn_s_memtime(); st_sum[i] += st_b - st_a; st_a = st_b; } } while (0)
+  // cycles in the chunk barrier's vmcnt wait / in the s_barrier itself, even and odd chunks apart
+  long long bw_t0 = 0, bw_t1 = 0, bw_sum[4] = {0, 0, 0, 0};
+#define WN_BAR_T0() do { if (stamps) bw_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define WN_BAR_T1() do { if (stamps) bw_t1 = __builtin_amdgcn_s_memtime(); } while (0)
+#define WN_BAR_T2(odd) do { if (stamps) { const long long bw_t2 = __builtin_amdgcn_s_memtime(); bw_sum[(odd) ? 2 : 0] += bw_t1 - bw_t0; bw_sum[(odd) ? 3 : 1] += bw_t2 - bw_t1; } } while (0)
 #else
 #define WN_STAMP(i) do { } while (0)
+#define WN_BAR_T0() do { } while (0)
+#define WN_BAR_T1() do { } while (0)
+#define WN_BAR_T2(odd) do { } while (0)
 #endif
   WinoTile cur, nxt;
   setup(u, cur, 0);
@@ -303,11 +333,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
 #pragma unroll
     for (int i = 0; i < 5; i++) dma_w(cur.wsrc + WN_WSTAGE, 1, i);
 #pragma unroll
-    for (int pi = 0; pi < 3; pi++)
-      {
-#pragma unroll
-        for (int q = 0; q < 4; q++) dma_i(cur, 0, 0, q, pi);
-      }
+    for (int n = 0; n < NI; n++) dma_i(cur, 0, 0, n);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     asm volatile("" ::: "memory");
@@ -384,32 +410,29 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     using X2 = std::integral_constant<int, 2>;
     using X3 = std::integral_constant<int, 3>;
     // ---- xi = 0 (operands in set 0); prepares xi = 1: B <- positions 4 .. 7, row 1; t = r1 + r2.
-    //      DMAs: the last 3 pieces of weight chunk c + 1, then (even chunks) the first 3 input pieces of stage s + 1
+    //      DMAs: the last 3 pieces of weight chunk c + 1, then (even chunks) the first 3 of this wave's input pieces of stage s + 1
     row(X0{}, X0{}, [&](int k) {
       if (k == 0) read_b(B[1], ODD ? 1 : 0, 1);
       if (k == 1) read_row(r1, ab, ODD ? 1 : 0, 1);
       if (k >= 2 && k <= 4) dma_w(w1, ODD ? 0 : 1, 5 + (k - 2));
-      if (!ODD && k >= 13) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 13, 0);
+      if (!ODD && k >= 13) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 13);
       tcol(k, r1, r2, true);
       trow(k, A[1]);
     });
-    // ---- xi = 1 (set 1); prepares xi = 2: B <- positions 8 .. 11; t = r2 - r1.  DMAs (even chunks): 7 more input pieces
+    // ---- xi = 1 (set 1); prepares xi = 2: B <- positions 8 .. 11; t = r2 - r1.  DMAs (even chunks): the rest of this wave's input pieces
     row(X1{}, X1{}, [&](int k) {
       if (k == 0) read_b(B[0], ODD ? 1 : 0, 2);
       if (!ODD) {
-        if (k == 1) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 3, 0);
-        if (k >= 2 && k <= 4) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 2, 1);
-        if (k == 13) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 3, 1);
-        if (k >= 14) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 14, 2);
+        if (k >= 1 && k <= 4 && 2 + k < NI) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 2 + k);
+        if (k >= 13 && k <= 14 && k - 6 < NI) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 6);
       }
       tcol(k, r2, r1, false);
       trow(k, A[0]);
     });
-    // ---- xi = 2 (set 0); prepares xi = 3: B <- positions 12 .. 15, row 3; t = r1 - r3.  DMAs (even chunks, wave 0): the last 2
+    // ---- xi = 2 (set 0); prepares xi = 3: B <- positions 12 .. 15, row 3; t = r1 - r3
     row(X2{}, X0{}, [&](int k) {
       if (k == 0) read_b(B[1], ODD ? 1 : 0, 3);
       if (k == 1) read_row(r3, ab, ODD ? 1 : 0, 3);
-      if (!ODD && (k == 2 || k == 3)) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k, 2);
       tcol(k, r1, r3, false);
       trow(k, A[1]);
     });
@@ -420,14 +443,16 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     row(X3{}, X1{}, [&](int k) {
       if (k == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WN_BAR_T0();
         if (ODD) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {            // the input pieces issued in this chunk (stage s + 1) may stay in flight: 12 (wave 0) / 8
-          if (has2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          else if (has1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {            // the NI input pieces issued in this chunk (stage s + 1) may stay in flight
+          if (LEAN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         }
+        WN_BAR_T1();
         if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+        WN_BAR_T2(ODD);
         asm volatile("" ::: "memory");
         read_b(B[0], ODD ? 0 : 1, 0);
       }
@@ -512,7 +537,9 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the workgroup has gone
 #ifdef NAFAE_EXPERIMENTS
   if (stamps && lane == 0) {
-    long long *o = stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    long long *o = stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[8 + i] = bw_sum[i];
     o[0] = st_tiles;
 #pragma unroll
     for (int i = 0; i < 5; i++) o[1 + i] = st_sum[i];

@@ -23,14 +23,14 @@ for name in names:
     U = ops.conv3x3_wino_pack(w)
     for _ in range(3):
         ops.conv3x3_wino(x, U, b, Cout, pool=pool)
-    st = torch.zeros(256 * 4 * 8, device='cuda', dtype=torch.int64)
+    st = torch.zeros(256 * 4 * 16, device='cuda', dtype=torch.int64)
     L.nafae_wino_debug_stamps(ctypes.c_void_p(st.data_ptr()))
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record(); ops.conv3x3_wino(x, U, b, Cout, pool=pool); e.record()
     torch.cuda.synchronize()
     L.nafae_wino_debug_stamps(None)
     ms = s.elapsed_time(e)
-    t = st.view(256, 4, 8).cpu().double()
+    t = st.view(256, 4, 16).cpu().double()
     t = t[t[:, 0, 0] > 0]
     tiles = t[:, :, 0]
     per = lambda i: t[:, :, i] / tiles
@@ -40,6 +40,10 @@ for name in names:
     for i, nm in ((1, "prologue (once)"), (2, "chunk 0"), (3, "setup"), (4, "chunks 1.."), (5, "epilogue")):
         v = (t[:, :, i] if i == 1 else per(i)).flatten()
         print("   %-16s per tile: median %7.0f  max %7.0f cycles" % (nm, float(v.median()), float(v.max())))
+    for i, nm in ((8, "even chunks: vmcnt wait"), (9, "even chunks: s_barrier"), (10, "odd chunks: vmcnt wait"), (11, "odd chunks: s_barrier")):
+        v = per(i)
+        print("   %-26s per tile: median %7.0f  max %7.0f | by wave (median) %s" % (nm, float(v.flatten().median()), float(v.max()),
+              " ".join("%.0f" % float(v[:, w].median()) for w in range(4))))
     tot = (t[:, :, 6] / tiles).flatten()
     rt = t[:, :, 7]
     print("   total per tile median %.0f max %.0f | kernel span %.1f us (100 MHz clock) | MFMA share of the median tile %.3f" %
