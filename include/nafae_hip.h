@@ -157,6 +157,19 @@ int64_t nafae_conv3x3_wino_weight_bytes(int Cin, int Cout);
 int nafae_conv3x3_wino_pack(const float *w, float *U, int Cin, int Cout, void *stream);
 int nafae_conv3x3_wino(const float *in, const float *U, const float *bias, float *out, int F, int H, int W, int Cin, int Cout,
                        int relu, void *stream);
+/* The same with the last, partial round of work spread over every workgroup (stream-K tail): at 64 frames the 28^2 VGG layers are 6.125
+ * units per CU and the 14^2 layers 1.53, so 12 % / 23 % of the launch idles without it.  The units of the last round are cut along
+ * the input channels; each piece leaves its output-transformed partial sums (the transform is linear: 64 KB per piece) in the
+ * workspace and the unit's last arriver adds them in workgroup order (deterministic), applies bias / ReLU / pool and stores.
+ * nafae_conv3x3_wino_workspace_bytes: bytes to pass (0 = the shape does not need it; workspace == NULL runs the plain schedule).
+ * Workspace contract = nafae_conv3x3_relu_ws's: the first 64 KB are arrival counters, ZERO when the first call on a workspace starts
+ * and left zero by every completed call; the rest needs no initialisation; one buffer may serve all the conv entry points; calls that
+ * share it must be stream-ordered.  Results equal nafae_conv3x3_wino's except in the units of the last round, where a K sum is split
+ * into 2 .. 9 fp32 chains (WHICH units those are depends on F).  With relu bit 4 (fused pool) the plain schedule runs whatever the
+ * workspace: for both, run the layer un-pooled here and nafae_maxpool2x2 behind it (bit-identical to the fused form).  */
+int64_t nafae_conv3x3_wino_workspace_bytes(int F, int H, int W, int Cin, int Cout);
+int nafae_conv3x3_wino_ws(const float *in, const float *U, const float *bias, float *out, int F, int H, int W, int Cin, int Cout,
+                          int relu, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* 2x2 stride-2 max-pool on NHWC.  H, W even; C % 4 == 0.  (RCNN_base pools, vgg16_rpn.py:38.)  */
 int nafae_maxpool2x2(const float *in, float *out, int F, int H, int W, int C, void *stream);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "nafae_conv3x3_wino_weight_bytes": (c_int64, [c_int, c_int]),
     "nafae_conv3x3_wino_pack": (c_int, [P, P, c_int, c_int, P]),
     "nafae_conv3x3_wino": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "nafae_conv3x3_wino_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "nafae_conv3x3_wino_ws": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P]),
     "nafae_maxpool2x2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "nafae_rpn_decode": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "nafae_sort_desc": (c_int, [P, P, c_int, c_int, P]),

@@ -50,8 +50,12 @@ struct WnGeo {
   static constexpr int NP = LEAN ? 6 : 9;           // 1-KB DMA pieces per plane (rows x 20 slots of 16 B)
   static constexpr int PLANE = NP * 1024;           // one channel quad of one 16-channel stage
   static constexpr int ISTAGE = 4 * PLANE;          // 24 576 / 36 864 B
-  static constexpr int LDS_W = 2 * ISTAGE;
-  static constexpr int LDS_TAB = LDS_W + 2 * 32768;
+  // LDS image: [weight chunk buffers 2 x 32 KB][input stage buffers 2 x ISTAGE][tile table].  The weights come FIRST: every fragment
+  // read is then one base register + an immediate (16-bit offset field: wc + lane part + buffer + position <= 65 520); behind the
+  // input stages the compiler kept up to 32 address registers for them and spilled inside the chunk loop.
+  static constexpr int LDS_W = 0;
+  static constexpr int LDS_I = 2 * 32768;
+  static constexpr int LDS_TAB = LDS_I + 2 * ISTAGE;
   static constexpr int LDS_TOTAL = LDS_TAB + 2 * 256;
 };
 constexpr int WN_WSTAGE = 32768;              // one 8-channel chunk of transformed weights for 64 output channels
@@ -64,6 +68,9 @@ struct WinoGeom {
   int NG;            // row groups = F * NS
   int NCB;           // 64-channel output blocks
   int units;         // (64-tile groups) x NCB
+  // stream-K tail (sk_rem > 0): rounds 0 .. sk_full-1 take whole units; the sk_rem units left (< grid) are cut along K into granules of
+  // 2 stages (32 channels) and every workgroup takes an equal contiguous share of the sk_rem * (NSG / 2) granules
+  int sk_full, sk_rem;
 };
 
 // Variant builds only (scripts/wino_variants.sh: -DWN_DBG=bits): timing experiments whose RESULTS ARE GARBAGE -- bit 0: no weight
@@ -113,8 +120,14 @@ __device__ __forceinline__ f32x4 wn_sub4(f32x4 a, f32x4 b) {
 #endif
 }
 
+// One work item of a workgroup: a whole unit, or (stream-K tail) stages [s0, s0 + ns) of remainder unit `rem`
+struct WinoItem {
+  int unit, s0, ns;      // unit; first 16-channel stage; number of stages (>= 2, even)
+  int rem;               // -1: whole unit (normal epilogue); >= 0: index of the remainder unit this piece belongs to
+  int slot;              // partial-sum slot of the piece (2 per workgroup)
+};
+
 struct WinoTile {
-  unsigned voff[3];      // per-lane source offsets of this wave's input DMA pieces (piece = wave + 4 i), bit 31 = zero fill
   unsigned abase;        // per-lane LDS byte offset of the tile's patch origin inside a stage (+ the lane's channel-quad plane)
   const char *wsrc;      // (uniform) transformed weights of the unit's cout block
 };
@@ -146,10 +159,10 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
   }
 }
 
-template <int TW, bool LEAN, bool POOL>
+template <int TW, bool LEAN, bool POOL, bool SK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U, const float *__restrict__ bias, float *__restrict__ out,
-                      const WinoGeom g, long long *__restrict__ stamps) {
+                      const WinoGeom g, float *__restrict__ partial, long long *__restrict__ stamps) {
   using G = WnGeo<LEAN>;
   constexpr int PH = (TW + 1) * 16;           // bytes of one parity block of a staged row
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -167,14 +180,16 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   const unsigned wl16 = (unsigned)lane * 16u;
 
   // ---- per-tile lane state (see the header): computed one tile ahead of the DMA stream
-  auto setup = [&](int u, WinoTile &t, int tabslot) {
+  // vo[3]: per-lane source offsets of this wave's input DMA pieces (dma_i), bit 31 = zero fill
+  auto setup = [&](const WinoItem &wi, WinoTile &t, unsigned (&vo)[3], int tabslot) {
+    const int u = wi.unit;
     const int sp = u / g.NCB, cb = u - sp * g.NCB;
     const int T0 = sp * 64;
     const int Ra = T0 / TW;
     const int ga = Ra / TH, ty_a = Ra - ga * TH, n0 = TH - ty_a;   // first row group: n0 tile rows from tile row ty_a
     const int fa = ga / NS, sa = ga - fa * NS;
     const int b1 = 2 * n0 + 2, GRP = 2 * TH + 2;                   // LDS rows of the first group / of every later one
-    t.wsrc = reinterpret_cast<const char *>(U) + (size_t)cb * NC * WN_WSTAGE;
+    t.wsrc = reinterpret_cast<const char *>(U) + ((size_t)cb * NC + 2 * wi.s0) * WN_WSTAGE;
     {   // patch origin of this lane's tile (wave wt, tile lane & 31)
       const int T = T0 + 32 * wt + (lane & 31);
       const int R = T / TW, tx = T - R * TW;
@@ -240,7 +255,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
       frame_strip(k, f, s);
       const int gx = s * 2 * TW - 1 + x;
       const bool ok = sr < 2 * (TW + 1) && rho < G::NROWS && ga + k < g.NG && y >= 0 && y < H && gx >= 0 && gx < W;
-      t.voff[i] = ok ? (unsigned)((f * H + y) * W + gx) * (unsigned)Cin * 4u : WN_OOB;
+      vo[i] = ok ? (unsigned)((f * H + y) * W + gx) * (unsigned)Cin * 4u : WN_OOB;
     }
   };
 
@@ -259,31 +274,60 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   // chunk).  Generic (9 pieces x 4 quads): pieces wave and wave + 4 whole, quad `wave` of piece 8.  LEAN (6 x 4): piece wave whole,
   // two quads of piece 4 + (wave >> 1).
   constexpr int NI = LEAN ? 6 : 9;
-  auto dma_i = [&](const WinoTile &t, int stage, int buf, int n) {
+  // (v0 / v1 / v2: the tile's three source offsets BY VALUE -- selecting a tile struct by reference made hipcc keep both structs in
+  // scratch memory and wait vmcnt(0) for every reload, i.e. for every DMA in flight)
+  auto dma_i = [&](unsigned v0, unsigned v1, unsigned v2, int stage, int buf, int n) {    // stage: absolute 16-channel stage
     if (dbg & 2) return;
     const int pi = n < 4 ? 0 : (LEAN || n < 8) ? 1 : 2;
     const int p = pi == 0 ? wave : pi == 1 ? (LEAN ? 4 + (wave >> 1) : wave + 4) : 8;
     const int q = n < 4 ? n : LEAN ? 2 * (wave & 1) + (n - 4) : n < 8 ? n - 4 : wave;
-    const unsigned m0v = lds0 + (unsigned)(buf * G::ISTAGE + q * G::PLANE) + (unsigned)p * 1024u;
+    const unsigned m0v = lds0 + (unsigned)(G::LDS_I + buf * G::ISTAGE + q * G::PLANE) + (unsigned)p * 1024u;
     const unsigned soff = (unsigned)(stage * 64 + q * 16);
+    const unsigned vsel = pi == 0 ? v0 : pi == 1 ? v1 : v2;
 #if WN_INT == 1
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m0v), "v"(vsel), "s"(in_rsrc), "s"(soff)
                  : "memory", "m0");
 #elif WN_INT == 2
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(m0v), "v"(vsel), "s"(in_rsrc), "s"(soff)
                  : "memory", "m0");
 #elif WN_INT == 3
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds" ::"s"(m0v), "v"(vsel), "s"(in_rsrc), "s"(soff)
                  : "memory", "m0");
 #else
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(t.voff[pi]), "s"(in_rsrc), "s"(soff)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(vsel), "s"(in_rsrc), "s"(soff)
                  : "memory", "m0");
 #endif
   };
 #pragma clang diagnostic pop
 
-  int u = blockIdx.x;
-  if (u >= g.units) return;
+  // ---- this workgroup's work list (uniform arithmetic): whole units blockIdx.x + j * gridDim.x, then (stream-K tail) up to two pieces
+  const unsigned G_ = gridDim.x, bid = blockIdx.x;
+  const unsigned GU = (unsigned)NSG >> 1, SG = (unsigned)g.sk_rem * GU;          // granules per unit, granules of the tail (< 2^16)
+  const int g0 = (int)(SG * bid / G_), g1 = (int)(SG * (bid + 1) / G_);           // this workgroup's share of the tail
+  // (SK = false: whole units only, the stream-K arithmetic compiles away)
+  const int nwhole = SK ? g.sk_full : (int)((g.units - bid + G_ - 1) / G_);
+  const int nitems = nwhole + (SK && g1 > g0 ? ((unsigned)g0 / GU != (unsigned)(g1 - 1) / GU ? 2 : 1) : 0);
+  auto item = [&](int j) {
+    WinoItem wi;
+    if (!SK || j < nwhole) {
+      wi.unit = (int)(bid + j * G_); wi.s0 = 0; wi.ns = NSG; wi.rem = -1; wi.slot = 0;
+    } else {
+      const int r0 = (int)((unsigned)g0 / GU), second = j - nwhole;
+      const int r = r0 + second;
+      const int ga_ = second ? 0 : g0 - r0 * (int)GU;
+      const int gb_ = (g1 - r * (int)GU) < (int)GU ? g1 - r * (int)GU : (int)GU;
+      wi.unit = g.sk_full * (int)G_ + r; wi.s0 = 2 * ga_; wi.ns = 2 * (gb_ - ga_); wi.rem = r; wi.slot = 2 * (int)bid + second;
+    }
+    // (uniform by construction; pinned to scalar registers -- as vector registers they pushed the chunk loop into spills)
+    wi.unit = __builtin_amdgcn_readfirstlane(wi.unit);
+    wi.s0 = __builtin_amdgcn_readfirstlane(wi.s0);
+    wi.ns = __builtin_amdgcn_readfirstlane(wi.ns);
+    wi.rem = __builtin_amdgcn_readfirstlane(wi.rem);
+    wi.slot = __builtin_amdgcn_readfirstlane(wi.slot);
+    return wi;
+  };
+  if (nitems <= 0) return;
+  WinoItem icur = item(0);
 #ifdef NAFAE_EXPERIMENTS
   // phase clocks (experiments build, stamps != nullptr): cycles per workgroup and wave spent in [prologue, first chunk of a tile,
   // next-tile setup, the other chunks, epilogue], summed over the workgroup's tiles; written to memory nothing else reads
@@ -302,8 +346,15 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
 #define WN_BAR_T2(odd) do { } while (0)
 #endif
   WinoTile cur, nxt;
-  setup(u, cur, 0);
+  unsigned dv[3], nv[3];       // DMA source offsets of the tile the input stream is in / of the next tile (the stream switches one stage
+                               // ahead of the MFMAs: no per-DMA select between two tiles)
+  setup(icur, cur, dv, 0);
   nxt = cur;
+#pragma unroll
+  for (int i = 0; i < 3; i++) nv[i] = dv[i];
+  // (uniform per-item scalars, kept out of the structs and pinned to scalar registers)
+  int cur_s0 = __builtin_amdgcn_readfirstlane(icur.s0), cur_nc = __builtin_amdgcn_readfirstlane(2 * icur.ns);
+  int nxt_s0 = cur_s0, nxt_nc = cur_nc;
 
   f32x16 acc[16];
   f32x4 A[2][4], B[2][4];          // operands of the current / next position row (4 positions each)
@@ -333,13 +384,13 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
 #pragma unroll
     for (int i = 0; i < 5; i++) dma_w(cur.wsrc + WN_WSTAGE, 1, i);
 #pragma unroll
-    for (int n = 0; n < NI; n++) dma_i(cur, 0, 0, n);
+    for (int n = 0; n < NI; n++) dma_i(dv[0], dv[1], dv[2], cur_s0, 0, n);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     asm volatile("" ::: "memory");
     read_b(B[0], 0, 0);
-    read_row(r0, cur.abase, 0, 0);
-    read_row(r2, cur.abase, 0, 2);
+    read_row(r0, cur.abase + (unsigned)G::LDS_I, 0, 0);
+    read_row(r2, cur.abase + (unsigned)G::LDS_I, 0, 2);
 #pragma unroll
     for (int j = 0; j < 4; j++) r0[j] = r0[j] - r2[j];
     A[0][0] = r0[0] - r0[2];
@@ -353,14 +404,15 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
   auto chunk = [&](auto first_tag, auto odd_tag, int c, bool last) {
     constexpr bool FIRST = decltype(first_tag)::value, ODD = decltype(odd_tag)::value;
     const int s = c >> 1;                                   // input stage of this chunk
-    const unsigned ab = cur.abase + (unsigned)((s & 1) * G::ISTAGE);
+    const unsigned ab = cur.abase + (unsigned)(G::LDS_I + (s & 1) * G::ISTAGE);
     // next chunk's patch origin / stage buffer
-    const unsigned abn = ODD ? (last ? nxt.abase : cur.abase + (unsigned)(((s + 1) & 1) * G::ISTAGE)) : ab;
+    const unsigned abn = ODD ? (last ? nxt.abase + (unsigned)G::LDS_I : cur.abase + (unsigned)(G::LDS_I + ((s + 1) & 1) * G::ISTAGE)) : ab;
     // weight chunk c + 1 / c + 2 and input stage s + 1 as seen by the DMA stream (may belong to the next tile)
-    const char *w1 = c + 1 < NC ? cur.wsrc + (size_t)(c + 1) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 1 - NC) * WN_WSTAGE;
-    const char *w2 = c + 2 < NC ? cur.wsrc + (size_t)(c + 2) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 2 - NC) * WN_WSTAGE;
-    const bool inext = s + 1 >= NSG;
-    const int is1 = inext ? s + 1 - NSG : s + 1;
+    const int cnc = cur_nc;
+    const char *w1 = c + 1 < cnc ? cur.wsrc + (size_t)(c + 1) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 1 - cnc) * WN_WSTAGE;
+    const char *w2 = c + 2 < cnc ? cur.wsrc + (size_t)(c + 2) * WN_WSTAGE : nxt.wsrc + (size_t)(c + 2 - cnc) * WN_WSTAGE;
+    const bool inext = 2 * (s + 1) >= cnc;
+    const int is1 = inext ? nxt_s0 + s + 1 - (cnc >> 1) : cur_s0 + s + 1;
     f32x4 t[4];
     auto mma = [&](auto xi_tag, int e, int nu, const f32x4 (&a)[4], const f32x4 (&b)[4]) {
       constexpr int XI = decltype(xi_tag)::value;
@@ -415,7 +467,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
       if (k == 0) read_b(B[1], ODD ? 1 : 0, 1);
       if (k == 1) read_row(r1, ab, ODD ? 1 : 0, 1);
       if (k >= 2 && k <= 4) dma_w(w1, ODD ? 0 : 1, 5 + (k - 2));
-      if (!ODD && k >= 13) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 13);
+      if (!ODD && k >= 13) dma_i(dv[0], dv[1], dv[2], is1, (s + 1) & 1, k - 13);
       tcol(k, r1, r2, true);
       trow(k, A[1]);
     });
@@ -423,8 +475,8 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     row(X1{}, X1{}, [&](int k) {
       if (k == 0) read_b(B[0], ODD ? 1 : 0, 2);
       if (!ODD) {
-        if (k >= 1 && k <= 4 && 2 + k < NI) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, 2 + k);
-        if (k >= 13 && k <= 14 && k - 6 < NI) dma_i(inext ? nxt : cur, is1, (s + 1) & 1, k - 6);
+        if (k >= 1 && k <= 4 && 2 + k < NI) dma_i(dv[0], dv[1], dv[2], is1, (s + 1) & 1, 2 + k);
+        if (k >= 13 && k <= 14 && k - 6 < NI) dma_i(dv[0], dv[1], dv[2], is1, (s + 1) & 1, k - 6);
       }
       tcol(k, r2, r1, false);
       trow(k, A[0]);
@@ -467,7 +519,10 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
 
   // ---- output transform Y = A^T M A of the lane's 16 tiles x 1 channel, bias, ReLU, (max-pool), store
   const int cn = wc * 32 + (lane & 31);
-  auto epilogue = [&](int unit, int tabslot) {
+  auto epilogue = [&](auto piece_tag, const WinoItem &wi, int tabslot) {
+    constexpr bool PIECE = decltype(piece_tag)::value;
+    f32x4 *pdst = PIECE ? reinterpret_cast<f32x4 *>(partial) + (size_t)wi.slot * 16 * 256 + tid : nullptr;
+    const int unit = wi.unit;
     const int cb = unit % g.NCB;
     const int co = cb * 64 + cn;
     const float bv = bias[co];
@@ -487,6 +542,10 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
       }
       float y00 = (s0[0] + s0[1]) + s0[2], y10 = (s0[1] - s0[2]) - s0[3];
       float y01 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+      if (PIECE) {     // stream-K piece: the output transform is linear, so the pieces of a unit are summed AFTER it (64 KB each)
+        pdst[(size_t)r * 256] = f32x4{y00, y01, y10, y11};   // (wino_sk_finish_kernel, the next launch on the stream, adds them)
+        continue;
+      }
       const unsigned vo = (dbg & 8) ? WN_OOB : toff + cob;    // (bit 31 survives the add: cob < 2^31 and the store is dropped)
       if (POOL) {
         float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bv;
@@ -512,27 +571,37 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
 #endif
   WN_STAMP(0);
   for (int it = 0;; it++) {
-    const int un = u + (int)gridDim.x;
-    const bool has_next = un < g.units;
+    const bool has_next = it + 1 < nitems;
+    const WinoItem inxt = has_next ? item(it + 1) : icur;
     chunk(T_{}, F_{}, 0, false);
     WN_STAMP(1);
     // (behind chunk 0's barrier: every wave has left the previous tile's epilogue, whose table slot this overwrites)
-    setup(has_next ? un : u, nxt, (it + 1) & 1);
+    setup(inxt, nxt, nv, (it + 1) & 1);
+    nxt_s0 = __builtin_amdgcn_readfirstlane(inxt.s0);
+    nxt_nc = __builtin_amdgcn_readfirstlane(2 * inxt.ns);
     WN_STAMP(2);
+    const int cns = cur_nc >> 1;              // stages of this item (>= 2)
     chunk(F_{}, T_{}, 1, false);
-    for (int s = 1; s < NSG; s++) {
+    for (int s = 1; s < cns; s++) {
+      if (s + 1 == cns) {              // the last chunk pair requests the NEXT tile's first input stage
+#pragma unroll
+        for (int i = 0; i < 3; i++) dv[i] = nv[i];
+      }
       chunk(F_{}, F_{}, 2 * s, false);
-      chunk(F_{}, T_{}, 2 * s + 1, s + 1 == NSG);
+      chunk(F_{}, T_{}, 2 * s + 1, s + 1 == cns);
     }
     WN_STAMP(3);
-    epilogue(u, it & 1);
+    if (SK && icur.rem >= 0) epilogue(T_{}, icur, it & 1);
+    else epilogue(F_{}, icur, it & 1);
     WN_STAMP(4);
 #ifdef NAFAE_EXPERIMENTS
     st_tiles++;
 #endif
     if (!has_next) break;
     cur = nxt;
-    u = un;
+    cur_s0 = nxt_s0;
+    cur_nc = nxt_nc;
+    icur = inxt;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the workgroup has gone
 #ifdef NAFAE_EXPERIMENTS
@@ -547,6 +616,71 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     o[7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
 #endif
+}
+
+// Stream-K tail, second launch: unit rr of the last round = the sum of its pieces' output-transformed partial sums (workspace slots,
+// written by wino_conv_kernel in exactly this thread order), added in workgroup order, then bias / ReLU / pool / store like the main
+// kernel's epilogue.  One workgroup per remainder unit; thread = (wave (wt, wc), lane): channel 32 wc + (lane & 31), 16 tiles.
+template <int TW, bool POOL>
+__global__ __launch_bounds__(256) void wino_sk_finish_kernel(const float *__restrict__ partial, const float *__restrict__ bias,
+                                                             float *__restrict__ out, const WinoGeom g, int grid) {
+  const int rr = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wt = wave >> 1, wc = wave & 1, h = lane >> 5;
+  const int H = g.H, W = g.W, Cout = g.Cout, TH = g.TH, NS = g.NS;
+  const int GU = (g.Cin >> 4) >> 1, SG = g.sk_rem * GU;
+  auto share0 = [&](int c) { return (int)((long)SG * c / grid); };
+  const int unit = g.sk_full * grid + rr;
+  const int sp = unit / g.NCB, cb = unit - sp * g.NCB;
+  const int co = cb * 64 + wc * 32 + (lane & 31);
+  const float bv = bias[co];
+  const bool relu = (g.relu & 1) != 0;
+  int cf = (int)((long)rr * GU * grid / SG);                   // first workgroup whose share reaches into unit rr's granules
+  while (share0(cf + 1) <= rr * GU) cf++;
+  while (cf > 0 && share0(cf) > rr * GU) cf--;
+  f32x4 sum[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) sum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = cf; c < grid && share0(c) < (rr + 1) * GU; c++) {
+    if (share0(c + 1) <= share0(c)) continue;
+    const int sl = 2 * c + ((share0(c) / GU) == rr ? 0 : 1);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(partial) + (size_t)sl * 16 * 256 + tid;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum[i] += src[(size_t)i * 256];
+  }
+  // the tiles' output pixels (the arithmetic of the main kernel's setup)
+  const int T0 = sp * 64, Ra = T0 / TW, ga = Ra / TH, ty_a = Ra - ga * TH, n0 = TH - ty_a, fa = ga / NS, sa = ga - fa * NS;
+  const size_t sx = (size_t)Cout, sy = (size_t)W * Cout;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int ti = 32 * wt + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int T = T0 + ti, R = T / TW, tx = T - R * TW, dR = R - Ra;
+    int k = 0, ty;
+    if (dR < n0) {
+      ty = ty_a + dR;
+    } else {
+      int d = dR - n0;
+      k = 1;
+      while (d >= TH) { d -= TH; k++; }
+      ty = d;
+    }
+    int f = fa, st = sa + k;
+    while (st >= NS) { st -= NS; f++; }
+    const int gtx = st * TW + tx;
+    if (ga + k >= g.NG || gtx >= g.Wt) continue;
+    float y00 = sum[r][0], y01 = sum[r][1], y10 = sum[r][2], y11 = sum[r][3];
+    if (POOL) {
+      float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      out[((size_t)(f * TH + ty) * g.Wt + gtx) * Cout + co] = v;
+    } else {
+      y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+      if (relu) {
+        y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+      }
+      float *o = out + ((size_t)(f * H + 2 * ty) * W + 2 * gtx) * Cout + co;
+      o[0] = y00; o[sx] = y01; o[sy] = y10; o[sy + sx] = y11;
+    }
+  }
 }
 
 inline hipStream_t WS(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -583,12 +717,22 @@ inline bool wn_shape_ok(int F, int H, int W, int Cin, int Cout) {
   return tiles * (Cout / 64) / 64 < (1L << 30);
 }
 
-template <int TW, bool LEAN, bool POOL>
-int wn_launch(int grid, const float *in, const float *U, const float *bias, float *out, const WinoGeom &g, void *stream) {
-  const void *k = reinterpret_cast<const void *>(wino_conv_kernel<TW, LEAN, POOL>);
+template <int TW, bool LEAN, bool POOL, bool SK>
+int wn_launch2(int grid, const float *in, const float *U, const float *bias, float *out, const WinoGeom &g, float *partial, void *stream) {
+  const void *k = reinterpret_cast<const void *>(wino_conv_kernel<TW, LEAN, POOL, SK>);
   if (nafae::allow_dynamic_lds(k, WnGeo<LEAN>::LDS_TOTAL) != NAFAE_OK) return NAFAE_ELAUNCH;
-  hipLaunchKernelGGL((wino_conv_kernel<TW, LEAN, POOL>), dim3(grid), dim3(256), WnGeo<LEAN>::LDS_TOTAL, WS(stream), in, U, bias, out, g, wn_stamps());
+  hipLaunchKernelGGL((wino_conv_kernel<TW, LEAN, POOL, SK>), dim3(grid), dim3(256), WnGeo<LEAN>::LDS_TOTAL, WS(stream), in, U, bias, out, g, partial, wn_stamps());
+  if (nafae::launch_status() != NAFAE_OK) return NAFAE_ELAUNCH;
+  if (g.sk_rem > 0) hipLaunchKernelGGL((wino_sk_finish_kernel<TW, POOL>), dim3(g.sk_rem), dim3(256), 0, WS(stream), partial, bias, out, g, grid);
   return nafae::launch_status();
+}
+
+template <int TW, bool LEAN, bool POOL>
+int wn_launch(int grid, const float *in, const float *U, const float *bias, float *out, const WinoGeom &g, float *partial, void *stream) {
+  if constexpr (!POOL) {
+    if (g.sk_rem > 0) return wn_launch2<TW, LEAN, false, true>(grid, in, U, bias, out, g, partial, stream);
+  }
+  return wn_launch2<TW, LEAN, POOL, false>(grid, in, U, bias, out, g, partial, stream);
 }
 
 }  // namespace
@@ -611,34 +755,84 @@ int nafae_conv3x3_wino_pack(const float *w, float *U, int Cin, int Cout, void *s
   return nafae::launch_status();
 }
 
-int nafae_conv3x3_wino(const float *in, const float *U, const float *bias, float *out, int F, int H, int W, int Cin, int Cout, int relu,
-                       void *stream) {
-  if (!in || !U || !bias || !out) return NAFAE_EINVAL;
-  if (relu & ~0x11) return NAFAE_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(U) & 15)) return NAFAE_EINVAL;
-  if (!wn_shape_ok(F, H, W, Cin, Cout)) return NAFAE_ELIMIT;
-  WinoGeom g;
+// stream-K tail: worth it when the last round of whole units would leave 10 % or more of the launch idle (measured at C2: the 28^2
+// layers, 12.5 % idle, -7 %; the 14^2 layers, 23 %, -9 %; the 56^2 layers, 5.8 % idle, +-0: its two launches and per-piece work eat the gain)
+static bool wn_sk_pays(long units, int grid) {
+  if (units % grid == 0) return false;
+  const long rounds = (units + grid - 1) / grid;
+  return (double)(rounds * grid - units) / (double)(rounds * grid) >= 0.10;
+}
+constexpr int64_t WN_SK_COUNTER_BYTES = 65536;     // (the layout of the other conv workspaces: one zeroed-once buffer serves all)
+constexpr int64_t WN_SK_SLOT_BYTES = 65536;        // one piece's output-transformed partial sums: 64 tiles x 4 pixels x 64 channels
+
+static int wn_grid(const WinoGeom &g) {
+  // persistent workgroups, one per CU; a grid that is a multiple of NCB keeps a workgroup on one cout block
+  int grid = wn_cus();
+  if (grid > g.units) grid = g.units;
+  if (grid >= g.NCB) grid -= grid % g.NCB;
+  return grid;
+}
+
+static bool wn_geom(WinoGeom &g, int &TW, int F, int H, int W, int Cin, int Cout, int relu) {
+  if (!wn_shape_ok(F, H, W, Cin, Cout)) return false;
   g.F = F; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.relu = relu;
   g.TH = H / 2;
   g.Wt = W / 2;
-  const int TW = wn_strip(g.Wt);
+  TW = wn_strip(g.Wt);
   g.NS = (g.Wt + TW - 1) / TW;
   g.NG = F * g.NS;
   g.NCB = Cout / 64;
   const long tiles = (long)g.NG * g.TH * TW;
   g.units = (int)((tiles + 63) / 64) * g.NCB;
-  // persistent workgroups, one per CU; a grid that is a multiple of NCB keeps a workgroup on one cout block
-  int grid = wn_cus();
-  if (grid > g.units) grid = g.units;
-  if (grid >= g.NCB) grid -= grid % g.NCB;
+  g.sk_full = 0;
+  g.sk_rem = 0;
+  return true;
+}
+
+int64_t nafae_conv3x3_wino_workspace_bytes(int F, int H, int W, int Cin, int Cout) {
+  WinoGeom g;
+  int TW;
+  if (!wn_geom(g, TW, F, H, W, Cin, Cout, 0)) return 0;
+  const int grid = wn_grid(g);
+  if (!wn_sk_pays(g.units, grid)) return 0;
+  return WN_SK_COUNTER_BYTES + (int64_t)2 * grid * WN_SK_SLOT_BYTES;
+}
+
+int nafae_conv3x3_wino(const float *in, const float *U, const float *bias, float *out, int F, int H, int W, int Cin, int Cout, int relu,
+                       void *stream) {
+  return nafae_conv3x3_wino_ws(in, U, bias, out, F, H, W, Cin, Cout, relu, nullptr, 0, stream);
+}
+
+int nafae_conv3x3_wino_ws(const float *in, const float *U, const float *bias, float *out, int F, int H, int W, int Cin, int Cout, int relu,
+                          void *workspace, int64_t workspace_bytes, void *stream) {
+  if (!in || !U || !bias || !out) return NAFAE_EINVAL;
+  if (relu & ~0x11) return NAFAE_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(U) & 15)) return NAFAE_EINVAL;
+  WinoGeom g;
+  int TW;
+  if (!wn_geom(g, TW, F, H, W, Cin, Cout, relu)) return NAFAE_ELIMIT;
+  const int grid = wn_grid(g);
+  float *partial = nullptr;
+  // (not with the fused pool: that combination of epilogues spills inside the chunk loop under hipcc 7.2 and came out SLOWER than the
+  // plain schedule; callers that want both run the layer un-pooled on this schedule and nafae_maxpool2x2 behind it -- ops.conv3x3_wino)
+  if (!(relu & 16) && workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && wn_sk_pays(g.units, grid) &&
+      workspace_bytes >= WN_SK_COUNTER_BYTES + (int64_t)2 * grid * WN_SK_SLOT_BYTES) {
+    g.sk_full = g.units / grid;
+    g.sk_rem = g.units % grid;
+    partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + WN_SK_COUNTER_BYTES);
+  }
   const bool pool = (relu & 16) != 0;
   const bool lean = TW == 8 && g.TH % 8 == 0;
-  NAFAE_TAG("wino_conv<%d%s>%s", TW, lean ? ",lean" : "", pool ? "+pool" : "");
+  NAFAE_TAG("wino_conv<%d%s>%s%s", TW, lean ? ",lean" : "", pool ? "+pool" : "", g.sk_rem > 0 ? " stream-K tail" : "");
   if (TW == 8) {
-    if (lean) return pool ? wn_launch<8, true, true>(grid, in, U, bias, out, g, stream) : wn_launch<8, true, false>(grid, in, U, bias, out, g, stream);
-    return pool ? wn_launch<8, false, true>(grid, in, U, bias, out, g, stream) : wn_launch<8, false, false>(grid, in, U, bias, out, g, stream);
+    if (lean)
+      return pool ? wn_launch<8, true, true>(grid, in, U, bias, out, g, partial, stream)
+                  : wn_launch<8, true, false>(grid, in, U, bias, out, g, partial, stream);
+    return pool ? wn_launch<8, false, true>(grid, in, U, bias, out, g, partial, stream)
+                : wn_launch<8, false, false>(grid, in, U, bias, out, g, partial, stream);
   }
-  return pool ? wn_launch<7, false, true>(grid, in, U, bias, out, g, stream) : wn_launch<7, false, false>(grid, in, U, bias, out, g, stream);
+  return pool ? wn_launch<7, false, true>(grid, in, U, bias, out, g, partial, stream)
+              : wn_launch<7, false, false>(grid, in, U, bias, out, g, partial, stream);
 }
 
 #ifdef NAFAE_EXPERIMENTS

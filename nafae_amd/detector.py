@@ -213,7 +213,7 @@ class _fasterRCNN(nn.Module):
         """One 3x3 conv + ReLU (+ pool) layer in 'f32' mode: Winograd where packed and the shape is taken, else the direct kernel."""
         F, H, W, Cin = x.shape
         if u is not None and ops.wino_supported(F, H, W, Cin, w.shape[0]):
-            return ops.conv3x3_wino(x, u, b, w.shape[0], relu=True, pool=pool)
+            return ops.conv3x3_wino(x, u, b, w.shape[0], relu=True, pool=pool, use_workspace=self.conv_stream_k)
         return ops.conv3x3_relu(x, w, b, relu=True, use_workspace=self.conv_stream_k, pool=pool)
 
     def base_features(self, im_data):

@@ -220,16 +220,23 @@ def conv3x3_wino_pack(w_ohwi):
     return U
 
 
-def conv3x3_wino(x_nhwc, U, bias, Cout, relu=True, pool=False):
+def conv3x3_wino(x_nhwc, U, bias, Cout, relu=True, pool=False, use_workspace=True):
     """x [F,H,W,Cin], U from conv3x3_wino_pack -> [F,H,W,Cout] (or [F,H/2,W/2,Cout] with pool=True): conv + bias (+ ReLU) (+ 2x2/2
-    max-pool) as Winograd F(2x2,3x3) on the fp32 matrix cores."""
+    max-pool) as Winograd F(2x2,3x3) on the fp32 matrix cores.  use_workspace=False: no stream-K tail (results then do not depend on
+    the number of frames in the last bit)."""
     _chk(x_nhwc); _chk(U); _chk(bias)
     F, H, W, Cin = x_nhwc.shape
     if U.numel() != 16 * Cin * Cout:
         raise NafaeOpError("conv3x3_wino: transformed-weight size mismatch")
+    nws = int(_lib.lib().nafae_conv3x3_wino_workspace_bytes(F, H, W, Cin, Cout)) if use_workspace else 0
+    if pool and nws > 0:
+        # the stream-K tail is offered without the fused pool (include/nafae_hip.h): where it pays (28^2 / 14^2 layers at 64 frames)
+        # run the layer un-pooled on it and pool behind it -- bit-identical, and faster than the fused form on the plain schedule
+        return maxpool2x2(conv3x3_wino(x_nhwc, U, bias, Cout, relu=relu, pool=False, use_workspace=True))
     out = torch.empty((F, H // 2, W // 2, Cout) if pool else (F, H, W, Cout), device=x_nhwc.device, dtype=torch.float32)
-    _rc(_lib.lib().nafae_conv3x3_wino(_p(x_nhwc), _p(U), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)) | (16 if pool else 0),
-                                      _stream()), "nafae_conv3x3_wino")
+    ws = _conv_workspace(nws, x_nhwc.device) if nws > 0 else None
+    _rc(_lib.lib().nafae_conv3x3_wino_ws(_p(x_nhwc), _p(U), _p(bias), _p(out), F, H, W, Cin, Cout, int(bool(relu)) | (16 if pool else 0),
+                                         _p(ws), max(nws, 0), _stream()), "nafae_conv3x3_wino_ws")
     return out
 
 

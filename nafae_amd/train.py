@@ -164,7 +164,10 @@ class FrameStreamer:
     the bytes as they are.  `host_batches`: list of pinned uint8 tensors [F,H,W,3]; `template`: a Batch whose other fields
     (im_info, GloVe rows, lengths) are reused.  next() returns a Batch carrying `ready_event` (recorded on the copy stream);
     `detector_forward` / `eval_step` -- every detector call of this module -- wait for it and set `consumed_event` once the
-    detector has read the frames; a buffer whose batch never got one is protected by a wait on the caller's stream."""
+    detector has read the frames.  A device buffer is only ever overwritten behind its batch's `consumed_event`: next() RAISES when
+    the batch that holds the buffer has none (it was never handed to a detector call of this module, or next() ran more than two
+    batches ahead) -- the reader may not even be enqueued yet, so no stream wait could protect it.  A caller that reads the frames
+    itself calls release(batch) when its reader is enqueued."""
 
     def __init__(self, host_batches, template, device):
         self.host, self.template, self.k = host_batches, template, 0
@@ -172,19 +175,33 @@ class FrameStreamer:
         self.dbuf = [torch.empty_like(host_batches[0], device=device) for _ in range(2)]
         self.last = [None, None]                    # the Batch that last used each device buffer
 
+    @staticmethod
+    def release(batch):
+        """For readers outside this module: the frames of `batch` have been read by work already enqueued on the current stream."""
+        ev = torch.cuda.Event()
+        ev.record()
+        batch.consumed_event = ev
+
+    def _claim(self, b):
+        """The event the copy into device buffer b must wait for (None: the buffer is fresh).  Pure ordering logic, no GPU call."""
+        prev = self.last[b]
+        if prev is None:
+            return None
+        ev = getattr(prev, "consumed_event", None)
+        if ev is None:
+            raise RuntimeError("FrameStreamer.next(): device buffer %d still holds a batch no detector call has consumed "
+                               "(next() called more than two batches ahead, or the batch was read outside nafae_amd.train: "
+                               "call FrameStreamer.release(batch) once its reader is enqueued)" % b)
+        return ev
+
     def next(self):
         b = self.k & 1
+        wait_for = self._claim(b)                   # (raises before anything is enqueued or any counter moves)
         src = self.host[self.k % len(self.host)]
         self.k += 1
-        prev = self.last[b]
         with torch.cuda.stream(self.copy):
-            if prev is not None:
-                if getattr(prev, "consumed_event", None) is not None:
-                    self.copy.wait_event(prev.consumed_event)
-                else:
-                    # the batch that holds this buffer was never handed to a detector call of this module (or next() ran more
-                    # than twice ahead): whatever reads it was enqueued on the caller's stream -- wait for that, never overwrite
-                    self.copy.wait_stream(torch.cuda.current_stream(self.dbuf[b].device))
+            if wait_for is not None:
+                self.copy.wait_event(wait_for)
             self.dbuf[b].copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy)

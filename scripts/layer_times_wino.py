@@ -23,7 +23,7 @@ for (name, H, Cin, Cout, n, pool) in (("conv1_2", 224, 64, 64, 1, True), ("conv2
     x = torch.relu(torch.randn(F, H, H, Cin, device='cuda', generator=g)); w = torch.randn(Cout, 3, 3, Cin, device='cuda', generator=g) * 0.02
     cb = torch.zeros(Cout, device='cuda')
     U = ops.conv3x3_wino_pack(w)
-    msw = timeit(lambda: ops.conv3x3_wino(x, U, cb, Cout, relu=True, pool=pool))
+    msw = timeit(lambda: ops.conv3x3_wino(x, U, cb, Cout, relu=True, pool=pool, use_workspace=os.environ.get("WS", "1") == "1"))
     msd = timeit(lambda: ops.conv3x3_relu(x, w, cb, pool=pool))
     fl = 2.0 * F * H * H * Cout * 9 * Cin
     units = ((F * (H // 2) * (H // 2) + 63) // 64) * (Cout // 64)

@@ -34,7 +34,7 @@ def _ref64(x, w, b, relu, pool):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-def _run(ops, F, H, W, Cin, Cout, relu, pool, seed):
+def _run(ops, F, H, W, Cin, Cout, relu, pool, seed, use_workspace=True):
     g = torch.Generator(device='cuda').manual_seed(seed)
     x = torch.randn(F, H, W, Cin, device='cuda', generator=g)
     if seed & 1:
@@ -43,7 +43,7 @@ def _run(ops, F, H, W, Cin, Cout, relu, pool, seed):
     b = torch.randn(Cout, device='cuda', generator=g) * 0.1
     assert ops.wino_supported(F, H, W, Cin, Cout)
     U = ops.conv3x3_wino_pack(w)
-    ys = [ops.conv3x3_wino(x, U, b, Cout, relu=relu, pool=pool) for _ in range(REPEAT)]
+    ys = [ops.conv3x3_wino(x, U, b, Cout, relu=relu, pool=pool, use_workspace=use_workspace) for _ in range(REPEAT)]
     torch.cuda.synchronize()
     for y in ys[1:]:
         assert torch.equal(ys[0], y), "results differ between launches"
@@ -84,10 +84,27 @@ def _cases(n, seed):
 
 @pytest.mark.parametrize("case", _cases(40, 20261004),
                          ids=lambda c: "F%d_%dx%d_%d-%d%s%s" % (c[0], c[1], c[2], c[3], c[4], "_relu" if c[5] else "", "_pool" if c[6] else ""))
-def test_wino_random_shapes(ops, case):
+@pytest.mark.parametrize("ws", [True, False], ids=["streamk", "plain"])
+def test_wino_random_shapes(ops, case, ws):
     F, H, W, Cin, Cout, relu, pool = case
-    err, err_d = _run(ops, F, H, W, Cin, Cout, relu, pool, F * 131 + H * 17 + W * 3 + Cin)
+    err, err_d = _run(ops, F, H, W, Cin, Cout, relu, pool, F * 131 + H * 17 + W * 3 + Cin, use_workspace=ws)
     assert err < 2e-5, "winograd %.2e (direct %.2e)" % (err, err_d)
+
+
+# tile counts that leave a partial last round on 256 CUs (units = tile groups x cout blocks): the stream-K tail with one, a few and many
+# pieces per unit, pieces that straddle two units, and workgroups without a piece
+@pytest.mark.parametrize("shape", [(17, 56, 56, 64, 128), (9, 28, 28, 512, 512), (64, 14, 14, 512, 512), (21, 28, 28, 128, 256),
+                                   (3, 112, 112, 64, 64), (40, 14, 14, 256, 512)], ids=lambda s: "F%d_%dx%d_%d-%d" % s)
+@pytest.mark.parametrize("pool", [False, True], ids=["", "pool"])
+def test_wino_streamk_tail(ops, shape, pool):
+    F, H, W, Cin, Cout = shape
+    from nafae_amd import _lib
+    nws = int(_lib.lib().nafae_conv3x3_wino_workspace_bytes(F, H, W, Cin, Cout))
+    err, err_d = _run(ops, F, H, W, Cin, Cout, True, pool, 77 + F + Cin, use_workspace=True)
+    err_p, _ = _run(ops, F, H, W, Cin, Cout, True, pool, 77 + F + Cin, use_workspace=False)
+    print("\n[wino stream-K %dx%d %d->%d F=%d%s] workspace %d B | err stream-K %.2e, plain %.2e, direct %.2e" %
+          (H, W, Cin, Cout, F, " +pool" if pool else "", nws, err, err_p, err_d))
+    assert err < 2e-5 and err_p < 2e-5
 
 
 def test_wino_rejects_unsupported(ops):

@@ -198,3 +198,22 @@ def test_exact_dp_word_dropout_seed_is_shared_across_ranks():
     args2.exact_seed = 7
     m2 = types.SimpleNamespace(word_ebd=types.SimpleNamespace())
     assert DropSeed(0.1, shared_word_dropout_generator(m2, args2)).seed != seeds[0][0]
+
+
+def test_frame_streamer_never_overwrites_an_unconsumed_batch():
+    """a device frame buffer may only be re-filled behind its batch's consumed_event.  The ordering decision
+    (FrameStreamer._claim) is pure Python: a fresh buffer needs no wait, a consumed batch hands over its event, and a batch no
+    detector call has consumed -- next() called a third time without one -- raises instead of copying over frames a reader that
+    is not even enqueued yet would see."""
+    import types
+
+    from nafae_amd.train import FrameStreamer
+    fs = object.__new__(FrameStreamer)
+    fs.last = [None, None]
+    assert fs._claim(0) is None and fs._claim(1) is None                  # next() #1 and #2: fresh buffers
+    fs.last = [types.SimpleNamespace(consumed_event=None), types.SimpleNamespace(consumed_event="ev1")]
+    with pytest.raises(RuntimeError, match="no detector call has consumed"):
+        fs._claim(0)                                                      # next() #3 without a detector call in between
+    assert fs._claim(1) == "ev1"
+    fs.last[0].consumed_event = "ev0"                                     # detector_forward / release() marked it
+    assert fs._claim(0) == "ev0"
