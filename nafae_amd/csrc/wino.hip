@@ -8,30 +8,41 @@
 // rpn/rpn.py:63), which picks the same algorithm family for 3x3 fp32 layers; results agree with the direct kernels to fp32 rounding
 // (tests/test_gpu_wino.py: <= 2e-5 of the layer's largest output on the VGG shapes).
 //
-// One workgroup = 4 waves, ONE wave per SIMD (512 registers per lane), owns 64 Winograd tiles (128 output pixels... x 2 = 256) x 64
-// output channels x all 16 transform positions:
+// Measured on this kernel (round 5, scripts/wino_variants.sh): vector-ALU instructions do NOT hide behind fp32
+// MFMAs -- every v_add beside them costs its ~4.7 issue cycles of matrix time (the fp32 MFMA runs on the vector datapath) --, a
+// contiguous LDS-DMA costs ~24 cycles of issue and a gathered one ~110; a v_mfma_f32_16x16x4_f32 form with half the transform adds per
+// MFMA flop was built and was SLOWER (twice the MFMA issues per chunk).  So: 32x32x2 MFMAs and as few vector instructions per MFMA as
+// the algorithm allows.
+//
+// One workgroup = 4 waves, ONE wave per SIMD (512 registers per lane), owns 64 Winograd tiles (256 output pixels) x 64 output channels
+// x all 16 transform positions:
 //   * waves 2 x 2: wave (wt, wc) = tiles 32 wt .. +31, channels 32 wc .. +31, and ALL 16 positions: sixteen 32x32 accumulator
 //     tiles = 256 AGPRs.  Because a lane holds the 16 positions of its (tile, channel) pairs, the output transform A^T M A is
 //     lane-local: no shuffle, no LDS, and the 2x2 max-pool that follows conv1_2 / 2_2 / 3_3 / 4_3 is a max over the lane's four
-//     outputs of one tile.
+//     outputs of one tile.  The channels are the MFMA's columns, so a wave's store covers whole 128-byte lines of two pixels.
 //   * MFMA "A" operand = transformed input patches: lane (t = lane & 31, h = lane >> 5) owns tile t and the k-quad h of the 8-channel
 //     chunk; it reads its raw 4x4 patch (16 B = 4 channels per pixel) from an LDS image of the input, applies B^T d B in registers
 //     (32 vector adds per position row) and feeds the results straight to the MFMAs -- the transformed patches never touch LDS.
 //   * MFMA "B" operand = transformed weights U = G g G^T, packed once (nafae_conv3x3_wino_pack) in exactly the order the fragments
 //     are read: [cout block 64][chunk of 8 cin][position 16][wc 2][lane 64][4 floats], so a chunk is 32 KB contiguous, staged by
 //     sixteen-byte LDS-DMA (global_load_lds_dwordx4) with lane-linear destinations and read back by one conflict-free ds_read_b128
-//     per fragment.
+//     per fragment.  The two weight buffers come FIRST in LDS: every fragment address is one base register + a 16-bit immediate.
 //   * input image in LDS: the workgroup's tiles are 64 consecutive tiles of the linear order (frame, column strip of TW tiles,
 //     tile row, tile-in-strip); the raw rows they need are staged 16 channels at a time as 4 planes (one per channel quad) of up
-//     to 28 rows x 320 B, columns de-interleaved by parity (row = [even columns | odd columns]) so that the 32 tiles of a wave read
-//     consecutive 16-B slots.  Staging is buffer_load_dwordx4 ... offen lds: a lane whose pixel is conv padding (or beyond the
-//     frame / strip / tensor) carries bit 31 in its offset, is out of range, and the DMA writes zeros.  Vertical neighbours inside
-//     a frame share their two overlap rows; a frame / strip change starts a new row group.
+//     to 28 rows x 320 B (18 rows in the LEAN geometry: 8-tile strips whose 8-row blocks stay inside a frame), columns
+//     de-interleaved by parity (row = [even columns | odd columns]) so that the 32 tiles of a wave read consecutive 16-B slots.
+//     Staging is buffer_load_dwordx4 ... offen lds: a lane whose pixel is conv padding (or beyond the frame / strip / tensor)
+//     carries bit 31 in its offset, is out of range, and the DMA writes zeros.  Vertical neighbours inside a frame share their two
+//     overlap rows; a frame / strip change starts a new row group.  Every wave issues the same number of DMAs.
 //   * schedule: persistent workgroups (one per CU) walk units u = blockIdx.x + i * gridDim.x, unit = (64-tile group, cout block),
 //     cout block fastest, so every workgroup -- and with round-robin dispatch every XCD -- keeps ONE cout block: its transformed
 //     weights (Cin x 4 KB) stay in that XCD's L2.  The DMA stream runs ahead of the MFMAs across tile boundaries; per 8-channel
 //     chunk (64 MFMAs per wave = 4 096 cycles) there is one barrier, the DMAs are counted with vmcnt by hand, and everything
 //     else a wave does (16 + 16 fragment reads, 128 transform adds, ~10 DMA issues) is placed one piece per MFMA gap.
+//   * stream-K tail (template SK, nafae_conv3x3_wino_ws): the units of a last partial round are cut along the input channels into
+//     granules of 32, every workgroup takes an equal share, a piece stores its OUTPUT-TRANSFORMED partial sums (the transform is
+//     linear: 64 KB instead of 256 KB of accumulators) and wino_sk_finish_kernel, the next launch, adds a unit's pieces in
+//     workgroup order and applies bias / ReLU.  Deterministic; no atomics, no flags.
 #include "mfma_tile.h"
 #include <stdlib.h>
 #include <type_traits>
