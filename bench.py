@@ -192,10 +192,24 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
     ws = ops.loss_workspace(Na, Ns, Nb, Ne, D, V.device)
 
-    # the operand planes of the many-live-column kernel come out of the embedding modules' tanh epilogue in a step (ops.dropout_tanh
-    # (..., planes=kind)): produced here once, OUTSIDE the timed graph, and attached to the tensors as those modules do
-    ops.attach_sim_planes(V, ops.sim_planes(V))
-    ops.attach_sim_planes(W, ops.sim_planes(W))
+    # the operand planes of the planes kernels come out of the embedding modules' tanh epilogue in a step (ops.dropout_tanh(...,
+    # planes=kind)): produced here once, OUTSIDE the timed graph, and attached to the tensors as those modules do -- only when this
+    # shape's similarity call reads them (ops.sim_planes_used: what GroundModel.plan_sim_planes asks every step); the stand-alone
+    # production time is reported next to the kernel's time (`planes_production_ms`: an upper bound, in a step it is the epilogue's
+    # extra writes, not a separate pass)
+    uses_planes = ops.sim_planes_used(F, Nb, Na, Ne, D, lens=lens)
+    planes_ms = None
+    if uses_planes:
+        ops.attach_sim_planes(V, ops.sim_planes(V))
+        ops.attach_sim_planes(W, ops.sim_planes(W))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.sim_planes(V); ops.sim_planes(W)
+        e1.record()
+        torch.cuda.synchronize()
+        planes_ms = e0.elapsed_time(e1) / 10
 
     def fwd():
         return ops.sim_max_fwd(V, W, lens_t, Na, Ns, Nb, Ne, lens=lens)
@@ -248,8 +262,10 @@ def sim_loss_only(Na, Ns, Nb, Ne, dev, lens=None, iters=20, pmc_key=None):
         route = "sim_planes_kernel, narrow form (few live columns on long frames: fp16-MFMA filter + exact fp32 finish; simplanes.hip)"
     else:
         route = "sim_live_kernel (few live columns: fp32 MFMA, one launch, last-arriver merge; simfused.hip)"
-    return {"R": R, "Q": Q, "kernel": route, "operand_planes": ("%s planes of V and W attached by the producer (used by the many-live-column kernel "
-                                               "only; their production is outside the timed region)" % ops.SIM_PLANES_DEFAULT),
+    return {"R": R, "Q": Q, "kernel": route,
+            "operand_planes": (("%s planes of V and W, written by the producers' tanh epilogue in a step; here produced once outside the timed "
+                                "region" % ops.SIM_PLANES_DEFAULT) if uses_planes else "none: this shape runs on the fp32 operands, no planes are emitted"),
+            "planes_production_ms": None if planes_ms is None else round(planes_ms, 5),
             "fwd_traffic": traffic,
             "fwd_traffic_source": ("static: %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/sim_only.py at this "
                                    "shape, FETCH_SIZE x2; not read in this run)" % src) if traffic else None, "pairs": R * Q, "live_query_columns": live, "timing": "hipGraph of %d back-to-back passes, best of 3" % iters,

@@ -39,7 +39,8 @@ extern "C" {
 #define NAFAE_ACT_TANH 2
 
 /* Library / device identification; fills at most `cap` bytes of `buf` (host) with a 0-terminated
- * string like "nafae_hip 0.1 gfx950".  Callable without a GPU. */
+ * string like "nafae_hip 0.2 gfx950" (0.2, round 5: Winograd conv entry points, nafae_sim_planes_used; the zero-once workspace
+ * contract of the stream-K convs dates from 0.1 / round 4).  Callable without a GPU. */
 int nafae_version(char *buf_host, int cap);
 
 /* ------------------------------------------------------------------------------------------------
@@ -354,6 +355,9 @@ int nafae_sim_max_fwd_planes(const float *V, const float *W, const int32_t *ent_
                              int max_live_cols, int kind, const void *V_planes, const float *V_stats, const void *W_planes,
                              const float *W_stats, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
                              void *stream);
+/* 1 when nafae_sim_max_fwd_planes would READ planes of `kind` for this shape and live-column count (max_live_cols as there), 0 when
+ * it would ignore them: a producer asks before spending a pass's extra writes on planes nobody reads.  */
+int nafae_sim_planes_used(int F, int Nb, int Na, int Ne, int D, int max_live_cols, int kind);
 
 /* Bytes of workspace nafae_loss_fwd_bwd needs.  */
 int64_t nafae_loss_workspace_bytes(int Na, int Ns, int Nb, int Ne, int D);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "nafae_dropout_tanh_planes": (c_int, [P, P, c_float, P, c_int, c_int, c_int, P, P, P]),
     "nafae_dropout_tanh_seeded_planes": (c_int, [P, ctypes.c_uint64, c_float, P, c_int, c_int, c_int, P, P, P]),
     "nafae_sim_max_fwd_planes": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int64, P]),
+    "nafae_sim_planes_used": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "nafae_jpeg_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "nafae_jpeg_decode_batch": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P, P]),
     "nafae_loss_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),

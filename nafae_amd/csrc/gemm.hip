@@ -1269,7 +1269,7 @@ const char *nafae_last_kernel_id(void) { return nafae::last_kernel_buf(); }
 #endif
 
 int nafae_version(char *buf, int cap) {
-  static const char v[] = "nafae_hip 0.1 gfx950";
+  static const char v[] = "nafae_hip 0.2 gfx950";
   if (!buf || cap <= 0) return NAFAE_EINVAL;
   int i = 0;
   for (; i < cap - 1 && v[i]; i++) buf[i] = v[i];

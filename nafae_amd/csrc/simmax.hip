@@ -72,6 +72,22 @@ int64_t nafae_sim_max_workspace_bytes(int F, int Nb, int Na, int Ne, int D) {
   return few > pre ? few : pre;
 }
 
+// Would nafae_sim_max_fwd_planes READ operand planes of `kind` for this shape (1), or ignore them and run the fp32 live-column /
+// fallback kernels (0)?  The producers (VisEbd / WordEbd epilogues) ask before writing planes nobody reads.
+int nafae_sim_planes_used(int F, int Nb, int Na, int Ne, int D, int max_live_cols, int kind) {
+  if (Na <= 0 || F <= 0 || Nb <= 0 || Ne <= 0 || D <= 0 || (D & 3)) return 0;
+  if (kind != NAFAE_SIMPLANES_F16 && kind != NAFAE_SIMPLANES_BF16X3) return 0;
+  const int Q = Na * Ne;
+  int Qh = (max_live_cols < 0 || max_live_cols > Q) ? Q : max_live_cols;
+  if (Qh < 1) Qh = 1;
+  const char *ne = nafae::experiment_env("NAFAE_SIM_NARROW");
+  const bool narrow_on = ne ? ne[0] != '0' : Nb >= 224;
+  if (narrow_on && kind == NAFAE_SIMPLANES_F16 && Qh <= 64 && Nb > 32 && D % 128 == 0 && D <= 512 && Na <= NA_MAX &&
+      (long)Nb * D < (1L << 30) && (long)Q * D < (1L << 30))
+    return 1;
+  return fused_route(F, Nb, Na, Ne, D, Qh) == 2 && D % (kind == NAFAE_SIMPLANES_F16 ? 128 : 64) == 0 ? 1 : 0;
+}
+
 int nafae_sim_max_fwd_ws(const float *V, const float *W, const int32_t *ent_len, int F, int Nb, int Na, int Ne, int D,
                          int max_live_cols, float *S_max, int64_t *D_ind, void *workspace, int64_t workspace_bytes,
                          void *stream) {

@@ -6,8 +6,9 @@ bit, so `decode_batch(files)` equals `[cv2.imread(f) for f in files]` stacked --
 conv layer directly (ops.conv1_3x3_relu reads uint8 HWC frames).
 
 Supported: baseline sequential DCT (SOF0), 8-bit, Huffman, one interleaved scan, 4:4:4 / 4:2:2 / 4:2:0 / grey, restart markers.
-Anything else (progressive, arithmetic coding, CMYK, 12-bit, multi-scan) raises JpegUnsupported: the caller then decodes that file
-on the host explicitly -- nothing here falls back silently.  All files of one call must share size and sampling (the frames of
+Anything else (progressive, arithmetic coding, CMYK, 12-bit, multi-scan, an EXIF orientation other than 1 -- which cv2.imread would
+apply --, truncated or corrupt headers) raises JpegUnsupported: the caller then decodes that file on the host explicitly -- nothing
+here falls back silently.  All files of one call must share size and sampling (the frames of
 a video do; genframes.py writes them with one ffmpeg command)."""
 import ctypes
 
@@ -27,9 +28,49 @@ class JpegUnsupported(ValueError):
     pass
 
 
+def _exif_orientation(seg):
+    """Orientation tag (0x0112) of an APP1 Exif segment, or 1.  cv2.imread applies it (IMREAD_COLOR honours EXIF), this decoder does
+    not rotate: anything but 1 is refused so that the caller decodes that file on the host."""
+    if len(seg) < 14 or seg[:6] != b"Exif\x00\x00":
+        return 1
+    t = seg[6:]
+    if t[:2] == b"II":
+        u16 = lambda o: t[o] | (t[o + 1] << 8)
+        u32 = lambda o: t[o] | (t[o + 1] << 8) | (t[o + 2] << 16) | (t[o + 3] << 24)
+    elif t[:2] == b"MM":
+        u16 = lambda o: (t[o] << 8) | t[o + 1]
+        u32 = lambda o: (t[o] << 24) | (t[o + 1] << 16) | (t[o + 2] << 8) | t[o + 3]
+    else:
+        return 1
+    ifd = u32(4)
+    n = u16(ifd)
+    for k in range(n):
+        e = ifd + 2 + 12 * k
+        if u16(e) == 0x0112:
+            return u16(e + 8)
+    return 1
+
+
 def parse_header(data):
     """Marker segments up to and including SOS -> dict(W, H, comps [(id, h, v, tq, td, ta)], q {slot: uint16[64] natural order},
-    dc / ac {slot: (bits[16], vals)}, restart, scan = offset of the entropy-coded data)."""
+    dc / ac {slot: (bits[16], vals)}, restart, scan = offset of the entropy-coded data).  EVERY malformed input -- truncated file,
+    empty or short segment, missing table, zero size -- raises JpegUnsupported (the documented contract: the caller catches it and
+    decodes that file on the host), never IndexError / KeyError / ValueError."""
+    try:
+        info = _parse_header(data)
+    except JpegUnsupported:
+        raise
+    except (IndexError, KeyError, ValueError, TypeError) as e:
+        raise JpegUnsupported("malformed JPEG header (%s: %s)" % (type(e).__name__, e))
+    if info.get("W", 0) <= 0 or info.get("H", 0) <= 0:
+        raise JpegUnsupported("frame size %sx%s" % (info.get("W"), info.get("H")))
+    for c in info["comps"]:
+        if c["tq"] not in info["q"] or c.get("td") not in info["dc"] or c.get("ta") not in info["ac"]:
+            raise JpegUnsupported("component %d refers to a quantisation / Huffman table the file does not define" % c["id"])
+    return info
+
+
+def _parse_header(data):
     d = bytes(data)
     if len(d) < 4 or d[0] != 0xFF or d[1] != 0xD8:
         raise JpegUnsupported("not a JPEG file (no SOI)")
@@ -48,6 +89,8 @@ def parse_header(data):
             while p < len(seg):
                 pq, tq = seg[p] >> 4, seg[p] & 15
                 n = 128 if pq else 64
+                if p + 1 + n > len(seg):
+                    raise JpegUnsupported("quantisation table segment truncated")
                 vals = np.frombuffer(seg[p + 1:p + 1 + n], dtype=">u2" if pq else np.uint8).astype(np.uint16)
                 t = np.zeros(64, dtype=np.uint16)
                 t[_ZIGZAG] = vals
@@ -59,6 +102,8 @@ def parse_header(data):
                 tc, th = seg[p] >> 4, seg[p] & 15
                 bits = list(seg[p + 1:p + 17])
                 n = sum(bits)
+                if len(bits) != 16 or n > 256 or p + 17 + n > len(seg):
+                    raise JpegUnsupported("Huffman table segment truncated or with more than 256 codes")
                 (ac if tc else dc)[th] = (bits, list(seg[p + 17:p + 17 + n]))
                 p += 17 + n
         elif m == 0xC0:
@@ -71,6 +116,10 @@ def parse_header(data):
             raise JpegUnsupported("only baseline sequential Huffman JPEG (SOF0) is decoded on the GPU, this file is SOF%d" % (m - 0xC0))
         elif m == 0xDD:
             info["restart"] = (seg[0] << 8) | seg[1]
+        elif m == 0xE1:
+            o = _exif_orientation(seg)
+            if o != 1:
+                raise JpegUnsupported("EXIF orientation %d: cv2.imread would rotate / mirror this frame, the GPU decoder does not" % o)
         elif m == 0xDA:
             if info["comps"] is None or seg[0] != len(info["comps"]):
                 raise JpegUnsupported("a single interleaved scan over all components is expected")

@@ -301,12 +301,15 @@ class VisEbd(nn.Module):
         super().__init__()
         self.fc1 = nn.Linear(args.vis_fc_dim, args.word_ebd_dim)
         self.drop = nn.Dropout(p=args.dropout_rate)
-        self.sim_planes = "auto"        # emit the similarity kernel's operand planes in the tanh epilogue (None: do not)
+        # operand planes of the similarity kernel, written by the tanh epilogue: "auto" = the default kind when `emit_planes` says the
+        # coming DVSA call will read them (GroundModel.plan_sim_planes; True until someone plans), a kind name = always, None = never
+        self.sim_planes = "auto"
+        self.emit_planes = True
 
     def forward(self, feats):
         p = self.drop.p
         drop = DropSeed(p) if (self.training and p > 0) else None
-        sp = ops.SIM_PLANES_DEFAULT if self.sim_planes == "auto" else self.sim_planes
+        sp = (ops.SIM_PLANES_DEFAULT if self.emit_planes else None) if self.sim_planes == "auto" else self.sim_planes
         # the detector hands fc7 over together with its split-bf16 planes (an attribute on the very tensor it returned)
         planes = getattr(feats, "_nafae_planes", None)
         if planes is not None and (tuple(planes.shape) != tuple(feats.shape) or not feats.is_contiguous()
@@ -322,14 +325,15 @@ class WordEbd(nn.Module):
         self.drop = nn.Dropout(p=args.dropout_rate)
         self.bn = nn.BatchNorm1d(args.word_ebd_dim)
         self.mask_generator = None      # set by train_step_exact: replicated WordEbd must draw the same mask on every rank
-        self.sim_planes = "auto"        # as VisEbd.sim_planes
+        self.sim_planes = "auto"        # as VisEbd.sim_planes / emit_planes
+        self.emit_planes = True
 
     def forward(self, feats):
         p = self.drop.p
         drop = DropSeed(p, self.mask_generator) if (self.training and p > 0) else None
         if self.training:
             self.bn.num_batches_tracked += 1
-        sp = ops.SIM_PLANES_DEFAULT if self.sim_planes == "auto" else self.sim_planes
+        sp = (ops.SIM_PLANES_DEFAULT if self.emit_planes else None) if self.sim_planes == "auto" else self.sim_planes
         return _WordEbdFn.apply(feats.contiguous(), self.fc1.weight, self.fc1.bias, self.bn.weight, self.bn.bias,
                                 self.bn.running_mean, self.bn.running_var, self.training, self.bn.momentum,
                                 self.bn.eps, drop, sp)
@@ -345,6 +349,16 @@ class GroundModel(nn.Module):
         self.vis_ebd = VisEbd(args)
         self.word_ebd = WordEbd(args)
         self.DVSA = DVSA(args, cfg_)
+
+    def plan_sim_planes(self, n_frames, n_proposals, entities_length):
+        """Tell the embedding modules whether the DVSA call of this batch will read operand planes (at the default C2 / C4
+        training shapes the similarity dispatcher takes the fp32 live-column kernel and planes written by the tanh epilogues were extra
+        HBM writes and allocations for nothing).  Call before vis_ebd / word_ebd; train.py does for every step."""
+        lens = [int(x) for x in entities_length]
+        D = self.vis_ebd.fc1.out_features
+        used = ops.sim_planes_used(n_frames, n_proposals, len(lens), self.DVSA.args.max_ent_len, D, lens=lens)
+        self.vis_ebd.emit_planes = self.word_ebd.emit_planes = used
+        return used
 
 
 # ---------------------------------------------------------------------------------------------------- helpers

@@ -590,6 +590,14 @@ def sim_planes(X, kind=None):
     return P
 
 
+def sim_planes_used(F, Nb, Na, Ne, D, lens=None, kind=None):
+    """Will the similarity call of this shape (and these host-side entity lengths) read operand planes of `kind`?  The embedding
+    modules ask before emitting them (VisEbd / WordEbd.sim_planes = "auto")."""
+    live = _live_cols(lens, Ne)
+    return bool(_lib.lib().nafae_sim_planes_used(int(F), int(Nb), int(Na), int(Ne), int(D), -1 if live is None else live,
+                                                 SIM_PLANES_KINDS[kind or SIM_PLANES_DEFAULT]))
+
+
 def attach_sim_planes(X, P):
     """Carry the planes on the tensor they describe (the B1 signature DVSA(vis_feats, word_feats, entities_length) does not change;
     the planes are dropped as soon as the tensor is modified in place: its version counter no longer matches)."""

@@ -216,6 +216,7 @@ class FrameStreamer:
 def train_step(model, optimizer, criterion, batch, args, reducer=None):
     """One iteration of model.py:684-775.  Returns the (device) loss; no host synchronisation inside."""
     rois, roi_scores, roi_feats, fc_feats = detector_forward(model, batch)     # (waits for / releases streamed frames)
+    model.plan_sim_planes(rois.shape[0], rois.shape[1], batch.entities_length)   # emit operand planes only if DVSA will read them
     vis_feats = model.vis_ebd(fc_feats)
     word_feats = model.word_ebd(batch.glove_feats)
     if reducer is not None:
@@ -272,6 +273,7 @@ def train_step_exact(model, optimizer, criterion, local_batch, args, reducer, gr
     sync, so the error would be silent).  The mask is therefore drawn from a dedicated generator re-seeded on every rank
     from the shared (exact_seed, step counter); the visual-side masks cover disjoint rows and stay per-rank."""
     rois, roi_scores, roi_feats, fc_feats = detector_forward(model, local_batch)
+    model.vis_ebd.emit_planes = model.word_ebd.emit_planes = True        # (the frame-sharded DVSA decides per rank; keep the planes)
     vis_feats = model.vis_ebd(fc_feats)                       # this rank's rows only
     we = model.word_ebd
     if we.training and we.drop.p > 0:
@@ -341,6 +343,7 @@ class PipelinedTrainer:
                     t.record_stream(tail)
         model, args = self.model, self.args
         with torch.cuda.stream(tail):
+            model.plan_sim_planes(rois.shape[0], rois.shape[1], batch.entities_length)   # emit operand planes only if DVSA will read them
             vis_feats = model.vis_ebd(fc_feats)
             word_feats = model.word_ebd(batch.glove_feats)
             self.reducer.zero_grad()
@@ -402,6 +405,7 @@ def eval_step(model, batch):
         rois, roi_scores, roi_feats, fc_feats = model.fasterRCNN(batch.im_data, batch.im_info, batch.gt_boxes,
                                                                  batch.num_boxes)
         _frames_consumed(batch)
+        model.plan_sim_planes(rois.shape[0], rois.shape[1], batch.entities_length)   # emit operand planes only if DVSA will read them
         vis_feats = model.vis_ebd(fc_feats)
         word_feats = model.word_ebd(batch.glove_feats)
         D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)
@@ -435,6 +439,7 @@ def validate_segment(model, batch, vid_entities, img_ids, args, dets, step_size=
     with torch.no_grad():
         rois, roi_feats, fc_feats = stepRCNN(batch.im_data, batch.im_info, batch.gt_boxes, batch.num_boxes, model,
                                              step_size=step_size, need_roi_feats=False)     # validate() never reads roi_feats
+        model.plan_sim_planes(rois.shape[0], rois.shape[1], batch.entities_length)   # emit operand planes only if DVSA will read them
         vis_feats = model.vis_ebd(fc_feats)
         word_feats = model.word_ebd(batch.glove_feats)
         D, D_sim, margin_loss = model.DVSA(vis_feats, word_feats, batch.entities_length)

@@ -123,3 +123,48 @@ def test_unsupported_files_are_refused_loudly():
         NJ.parse_header(b"\\x89PNG\\r\\n\\x1a\\n" + b"\\0" * 32)
     with pytest.raises(Exception):
         NJ.prepare([make_jpeg(32, 32, 90, 2), make_jpeg(32, 48, 90, 2)])        # one call = one geometry
+
+
+def test_malformed_files_raise_jpeg_unsupported():
+    """the host parser's contract is `JpegUnsupported` for every file the GPU decoder does not take -- truncated files,
+    empty segments, missing tables, zero sizes, a rotating EXIF orientation -- never IndexError / KeyError / ValueError (an untrusted
+    data-set file must not crash load_segment_gpu)."""
+    from nafae_amd import jpeg as J
+    good = make_jpeg(32, 40, 90, 2)
+    assert J.parse_header(good)["W"] == 40
+    for cut in (1, 3, 5, 20, 60, 150, len(good) // 2):                    # truncated anywhere in the headers
+        try:
+            info = J.parse_header(good[:cut])
+        except J.JpegUnsupported:
+            continue
+        assert info["scan"] <= cut                                         # (a cut behind SOS leaves a complete header)
+    # a DQT segment removed: the component refers to a missing table
+    i = good.index(b"\xff\xdb")
+    L = (good[i + 2] << 8) | good[i + 3]
+    with pytest.raises(J.JpegUnsupported):
+        J.prepare([good[:i] + good[i + 2 + L:]])
+    # every DHT segment removed
+    b = good
+    while b"\xff\xc4" in b[:b.index(b"\xff\xda")]:
+        i = b.index(b"\xff\xc4")
+        L = (b[i + 2] << 8) | b[i + 3]
+        b = b[:i] + b[i + 2 + L:]
+    with pytest.raises(J.JpegUnsupported):
+        J.prepare([b])
+    # zero height in SOF0
+    i = good.index(b"\xff\xc0")
+    with pytest.raises(J.JpegUnsupported):
+        J.parse_header(good[:i + 5] + b"\x00\x00" + good[i + 7:])
+    # an empty DRI segment (length 2)
+    i = good.index(b"\xff\xda")
+    with pytest.raises(J.JpegUnsupported):
+        J.parse_header(good[:i] + b"\xff\xdd\x00\x02" + good[i:])
+    # EXIF orientation 6 (cv2.imread would rotate): refused; orientation 1: accepted
+    def exif(o):
+        tiff = b"II*\x00\x08\x00\x00\x00" + b"\x01\x00" + b"\x12\x01\x03\x00\x01\x00\x00\x00" + bytes([o, 0, 0, 0]) + b"\x00\x00\x00\x00"
+        seg = b"Exif\x00\x00" + tiff
+        return good[:2] + b"\xff\xe1" + bytes([(len(seg) + 2) >> 8, (len(seg) + 2) & 255]) + seg + good[2:]
+    assert J.parse_header(exif(1))["W"] == 40
+    with pytest.raises(J.JpegUnsupported, match="orientation 6"):
+        J.parse_header(exif(6))
+    assert not isinstance(J.JpegUnsupported("x"), (IndexError, KeyError))
