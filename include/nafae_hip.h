@@ -132,7 +132,9 @@ int nafae_conv3x3_relu(const float *in, const float *w, const float *bias, float
  * Workspace contract (both stream-K convs, this one and nafae_conv3x3_bf16_ws; one buffer may serve both): its first 64 KB are the
  * tiles' arrival counters and must be ZERO when the first call on a workspace starts (hipMemsetAsync once, at allocation); every
  * completed call leaves them zero, whatever its shape.  The rest needs no initialisation.  Calls that share a workspace must be
- * stream-ordered; after an aborted launch zero it again.
+ * stream-ordered; after an aborted launch zero it again.  The production library cannot check this without a synchronisation and does
+ * not; the experiments build verifies the counters before every such launch when NAFAE_WS_CHECK=1 and returns NAFAE_EINVAL otherwise
+ * (tests/ws_check_worker.py).
  * relu: bit 0 = ReLU; bit 4 = also apply the 2x2/2 max-pool that follows the layer (vgg16_rpn.py:38: conv1_2, conv2_2, conv3_3,
  * conv4_3) inside the conv's epilogue -- `out` is then [F, H/2, W/2, Cout] and equals nafae_maxpool2x2(conv) bit for bit.
  * NAFAE_ELIMIT = the fused form is not offered for this call (odd H or W, tensors above 2 GiB, or a layer that goes to the

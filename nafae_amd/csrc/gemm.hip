@@ -1218,6 +1218,7 @@ int nafae_conv3x3_relu_ws(const float *in, const float *w, const float *bias, fl
       if (launched() != NAFAE_OK) return NAFAE_ELAUNCH;
     }
     int *counters = reinterpret_cast<int *>(workspace);
+    if (nafae::check_counters_zero(counters, F32_SK_COUNTER_BYTES, S(stream)) != NAFAE_OK) return NAFAE_EINVAL;   // (experiments build, NAFAE_WS_CHECK=1)
     float *partials = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + F32_SK_COUNTER_BYTES);
     hipLaunchKernelGGL((conv3x3_sk_kernel<128, 128, 2, 2>), dim3(G), dim3(NTHREADS), E::STAGE * sizeof(float), S(stream), in, w, bias, out, F,
                        H, W, Cin, Cout, relu, tiles_m, tiles_n, partials, full, rem, counters);

@@ -1738,6 +1738,7 @@ int launch_conv_run_sk(const void *Xhi, const void *Xlo, const void *Whi, const 
   NAFAE_TAG("conv3x3_run_sk<%d,%d,split=%d,il=%d,pair=%d>", BX, BW, (int)SPLIT, (int)IL, (int)PAIR);
   if (nafae::allow_dynamic_lds(reinterpret_cast<const void *>(kern), (int)R::LDS_BYTES) != NAFAE_OK) return NAFAE_ELAUNCH;
   int *counters = reinterpret_cast<int *>(scratch);
+  if (nafae::check_counters_zero(counters, SK_COUNTER_BYTES, st) != NAFAE_OK) return NAFAE_EINVAL;   // (experiments build, NAFAE_WS_CHECK=1)
   float *partials = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + SK_COUNTER_BYTES);
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT16), R::LDS_BYTES, st, (const __bf16 *)Xhi, (const __bf16 *)Xlo, (const __bf16 *)Whi,
                      (const __bf16 *)Wlo, bias, Cf, (__bf16 *)Chi, (__bf16 *)Clo, F, H, W, Cin, Cout, relu, tiles_m, tiles_n, partials,

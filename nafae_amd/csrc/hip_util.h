@@ -49,6 +49,33 @@ inline const char *experiment_env(const char *name) {
 #endif
 }
 
+// Workspace contract check: the stream-K convs and the live-column similarity kernel expect the arrival counters at the
+// start of their workspace to be ZERO when a call starts (zeroed once at allocation, left zero by every completed call).  A caller on
+// the pre-round-4 contract, or one that reuses a workspace after an aborted launch, would get silently wrong tiles.  The experiments
+// build can verify it before every such launch (NAFAE_WS_CHECK=1: a device-to-host copy and a stream synchronisation per call, so
+// never in a timing run); the production build has no check and no synchronisation.
+inline int check_counters_zero(const void *counters, size_t bytes, hipStream_t st) {
+#ifdef NAFAE_EXPERIMENTS
+  const char *e = getenv("NAFAE_WS_CHECK");
+  if (!e || e[0] != '1' || !counters) return NAFAE_OK;
+  const size_t n = bytes / sizeof(int);
+  int *h = static_cast<int *>(malloc(n * sizeof(int)));
+  if (!h) return NAFAE_ELAUNCH;
+  int rc = NAFAE_OK;
+  if (hipMemcpyAsync(h, counters, n * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    rc = NAFAE_ELAUNCH;
+  } else {
+    for (size_t i = 0; i < n; i++)
+      if (h[i] != 0) { rc = NAFAE_EINVAL; break; }
+  }
+  free(h);
+  return rc;
+#else
+  (void)counters; (void)bytes; (void)st;
+  return NAFAE_OK;
+#endif
+}
+
 // Dispatch pinning.  Which kernel family an ABI call launched is a dispatch decision (shape, alignment,
 // workspace, tile count) that no output value reveals: a regression that silently falls back to a slower generation passes every
 // parity test.  In the experiments build every dispatcher leaves a tag naming the kernel it chose; nafae_last_kernel_id() returns the

@@ -312,3 +312,17 @@ def test_frame_streamer_feeds_the_pipeline_identically(gpu):
         torch.cuda.synchronize()
         assert got == ref
         assert torch.equal(torch.cat([p.detach().reshape(-1) for p in red2.params]), want)
+
+
+def test_workspace_contract_is_checked_in_the_experiments_build(gpu):
+    """the zero-once workspace contract of the stream-K convs has no runtime check in the production library (no
+    synchronisation, no host read); the experiments build verifies it on request (NAFAE_WS_CHECK=1) and must refuse a call whose
+    arrival counters are not zero instead of finishing cut tiles from stale partials."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "nafae_amd", "csrc", "libnafae_hip_exp.so")
+    if not os.path.exists(lib):
+        pytest.skip("experiments build missing: python -m nafae_amd.build --experiments")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ws_check_worker.py")],
+                       env=dict(os.environ, NAFAE_LIB=lib, NAFAE_WS_CHECK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-1500:] + r.stderr[-3000:]
