@@ -367,7 +367,14 @@ def run_rank(a):
     dev = "cuda:%d" % local_rank
     distributed = world > 1 or a.force_dist            # --force-dist: a world-size-1 RCCL group, so that the collective path runs
     backend = "gloo" if a.test_shared_gpu else "nccl"       # nccl = RCCL on ROCm; gloo only for the shared-GPU launcher test
+    json_fd = None
     if distributed:
+        # RCCL prints a version banner on the C-level stdout of every rank (buffered, so it lands BEHIND whatever Python printed when the
+        # process exits).  The contract is ONE JSON line on rank 0's stdout: from here on file descriptor 1 is stderr for everything --
+        # Python and C alike -- and the JSON line is written straight to the real stdout (json_fd) at the end.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:         # (--force-dist outside a launcher)
             os.environ["MASTER_PORT"] = str(_free_port())
@@ -549,11 +556,17 @@ def run_rank(a):
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:      # the baseline is reporting, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
-        sys.stdout.flush()
+        line = json.dumps(out) + "\n"
+        if json_fd is not None:
+            os.write(json_fd, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if json_fd is not None:
+        os.close(json_fd)
 
 
 def main():

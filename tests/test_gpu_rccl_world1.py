@@ -53,8 +53,9 @@ def test_bench_force_dist_world1_reports_nccl():
                         "--workload", "c1", "--no-cpu-baseline", "--no-other-precisions"], env=_env(), capture_output=True,
                        text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]        # RCCL's version banner and everything else go to stderr: stdout is the JSON line only
+    out = json.loads(lines[0])
     assert out["config"]["collective_backend"] == "nccl" and out["config"]["rccl_world_size"] == 1
     assert out["config"]["grad_allreduce_bytes"] == 2201600 * 4
     assert out["value"] > 0
