@@ -86,7 +86,7 @@ struct WinoGeom {
 
 // Variant builds only (scripts/wino_variants.sh: -DWN_DBG=bits): timing experiments whose RESULTS ARE GARBAGE -- bit 0: no weight
 // DMAs, 1: no input DMAs, 2: no barrier in the chunk loop, 3: no epilogue stores, 4: no transform adds, 5 / 6: no patch / weight
-// fragment reads.  The production and the experiments build compile with 0.
+// fragment reads, 8: input DMA addresses of a channel-quad-blocked activation layout.  The production and the experiments build compile with 0.
 #ifndef WN_DBG
 #define WN_DBG 0
 #endif
@@ -266,7 +266,8 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
       frame_strip(k, f, s);
       const int gx = s * 2 * TW - 1 + x;
       const bool ok = sr < 2 * (TW + 1) && rho < G::NROWS && ga + k < g.NG && y >= 0 && y < H && gx >= 0 && gx < W;
-      vo[i] = ok ? (unsigned)((f * H + y) * W + gx) * (unsigned)Cin * 4u : WN_OOB;
+      // (WN_DBG bit 8, timing only: source addresses of a channel-quad-blocked activation layout [Cin/4][F][H][W][4])
+      vo[i] = ok ? (unsigned)((f * H + y) * W + gx) * ((WN_DBG & 256) ? 16u : (unsigned)Cin * 4u) : WN_OOB;
     }
   };
 
@@ -293,7 +294,7 @@ void wino_conv_kernel(const float *__restrict__ in, const float *__restrict__ U,
     const int p = pi == 0 ? wave : pi == 1 ? (LEAN ? 4 + (wave >> 1) : wave + 4) : 8;
     const int q = n < 4 ? n : LEAN ? 2 * (wave & 1) + (n - 4) : n < 8 ? n - 4 : wave;
     const unsigned m0v = lds0 + (unsigned)(G::LDS_I + buf * G::ISTAGE + q * G::PLANE) + (unsigned)p * 1024u;
-    const unsigned soff = (unsigned)(stage * 64 + q * 16);
+    const unsigned soff = (WN_DBG & 256) ? (unsigned)(stage * 4 + q) * (unsigned)(g.F * H * W * 16) : (unsigned)(stage * 64 + q * 16);
     const unsigned vsel = pi == 0 ? v0 : pi == 1 ? v1 : v2;
 #if WN_INT == 1
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m0v), "v"(vsel), "s"(in_rsrc), "s"(soff)
