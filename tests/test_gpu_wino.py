@@ -116,3 +116,64 @@ def test_wino_rejects_unsupported(ops):
     U = torch.zeros(16 * 64 * 64, device='cuda')
     with pytest.raises(Exception):
         ops.conv3x3_wino(x, U, torch.zeros(64, device='cuda'), 64)
+
+
+# ---- size-independent properties at BASELINE C2's full sizes (64 frames): no reference needed, every pixel and channel checked
+FULL = [(64, 224, 224, 64, 64), (64, 56, 56, 256, 256), (64, 28, 28, 512, 512), (64, 14, 14, 512, 512)]
+
+
+@pytest.mark.parametrize("shape", FULL, ids=lambda s: "F%d_%dx%d_%d-%d" % s)
+def test_wino_full_size_zero_input_gives_the_bias_exactly(ops, shape):
+    """conv(0) + b = b: every product and every transform sum is an exact zero, so ReLU(bias) must come out BIT FOR BIT at every pixel
+    of every frame -- borders, strip edges, partial tile groups and stream-K pieces included (a stale LDS row or a wrong padding lane
+    would show up as a non-bias value)."""
+    F, H, W, Cin, Cout = shape
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.zeros(F, H, W, Cin, device='cuda')
+    w = torch.randn(Cout, 3, 3, Cin, device='cuda', generator=g)
+    b = torch.randn(Cout, device='cuda', generator=g)
+    U = ops.conv3x3_wino_pack(w)
+    for pool in (False, True):
+        y = ops.conv3x3_wino(x, U, b, Cout, relu=True, pool=pool)
+        assert y.shape == ((F, H // 2, W // 2, Cout) if pool else (F, H, W, Cout))
+        assert torch.equal(y, torch.relu(b).expand_as(y))
+
+
+@pytest.mark.parametrize("shape", FULL[1:], ids=lambda s: "F%d_%dx%d_%d-%d" % s)
+def test_wino_full_size_linearity(ops, shape):
+    """Without ReLU and bias the layer is linear: conv(2 x - 0.5 z) = 2 conv(x) - 0.5 conv(z) up to fp32 rounding, at 64 frames (scaling
+    by powers of two is exact, so the only difference is the rounding of the sums: bar 2e-5 of the largest output)."""
+    F, H, W, Cin, Cout = shape
+    g = torch.Generator(device='cuda').manual_seed(6)
+    x = torch.randn(F, H, W, Cin, device='cuda', generator=g)
+    z = torch.randn(F, H, W, Cin, device='cuda', generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device='cuda', generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.zeros(Cout, device='cuda')
+    U = ops.conv3x3_wino_pack(w)
+    yx = ops.conv3x3_wino(x, U, b, Cout, relu=False)
+    yz = ops.conv3x3_wino(z, U, b, Cout, relu=False)
+    yc = ops.conv3x3_wino(2.0 * x - 0.5 * z, U, b, Cout, relu=False)
+    err = float((yc - (2.0 * yx - 0.5 * yz)).abs().max()) / float(yc.abs().max())
+    print("\n[wino linearity %dx%d %d->%d F=%d] max deviation / max|y| %.2e" % (H, W, Cin, Cout, F, err))
+    assert err < 2e-5
+
+
+def test_wino_impulse_response_is_the_kernel(ops):
+    """One 1.0 in an otherwise zero input: the output around it is the (flipped) 3x3 kernel of every output channel, everything else
+    zero -- at frame corners, edges, strip boundaries (x = 13 / 14 / 15 / 16 with 7- and 8-tile strips) and in the interior."""
+    F, H, W, Cin, Cout = 3, 32, 32, 64, 64
+    g = torch.Generator(device='cuda').manual_seed(7)
+    w = torch.randn(Cout, 3, 3, Cin, device='cuda', generator=g)
+    b = torch.zeros(Cout, device='cuda')
+    U = ops.conv3x3_wino_pack(w)
+    for (f, y0, x0, c) in ((0, 0, 0, 0), (1, 31, 31, 63), (2, 0, 31, 5), (0, 31, 0, 17), (1, 13, 13, 1), (2, 14, 15, 33), (0, 15, 16, 40), (1, 7, 20, 9)):
+        x = torch.zeros(F, H, W, Cin, device='cuda')
+        x[f, y0, x0, c] = 1.0
+        y = ops.conv3x3_wino(x, U, b, Cout, relu=False)
+        want = torch.zeros_like(y)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                yy, xx = y0 + dy, x0 + dx                  # output pixel that sees the impulse through tap (1 - dy, 1 - dx)
+                if 0 <= yy < H and 0 <= xx < W:
+                    want[f, yy, xx, :] = w[:, 1 - dy, 1 - dx, c]
+        assert float((y - want).abs().max()) <= 2e-6 * float(w.abs().max()), (f, y0, x0, c)
