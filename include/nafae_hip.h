@@ -91,6 +91,16 @@ int nafae_roi_align_backward(int aligned_height, int aligned_width, float spatia
  * chain).  K % 4 == 0; lda, ldb, ldc in elements, 16-byte aligned rows; bias may be NULL.  */
 int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
                   int M, int N, int K, float alpha, int act, void *stream);
+/* Same, with a caller-owned scratch buffer that enables a stream-K tail for launches whose 256x256 tile count leaves the last
+ * round of workgroups partly empty (fc6 / fc7 at 300 proposals x 64 frames: 1 200 tiles = 4.69 rounds on 256 CUs): the whole
+ * rounds run as before, the tiles of the last one are cut along K over all CUs and a finishing launch adds their pieces in a
+ * fixed order (deterministic; the sums of those tiles round differently from nafae_gemm_nt's, <= 1e-6 relative).  Without a
+ * workspace, or when the schedule does not pay, identical to nafae_gemm_nt.  nafae_gemm_nt_workspace_bytes: bytes this shape
+ * wants (0 = none).  The buffer may be the stream-K convs' workspace (its first 64 KB are left untouched); it must not be
+ * shared by launches that may run concurrently.  */
+int64_t nafae_gemm_nt_workspace_bytes(int M, int N, int K);
+int nafae_gemm_nt_ws(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias,
+                     int M, int N, int K, float alpha, int act, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* C[M,N] = alpha * A[K,M]^T * B[K,N] (+ C if accumulate)   (both operands K-major)
  * Weight-gradient contraction of VisEbd.fc1 / WordEbd.fc1 (autograd of model.py:626,641).

@@ -24,6 +24,8 @@ SIGNATURES = {
     "nafae_roi_align_forward": (c_int, [c_int, c_int, c_float, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
     "nafae_roi_align_backward": (c_int, [c_int, c_int, c_float, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "nafae_gemm_nt": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_float, c_int, P]),
+    "nafae_gemm_nt_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "nafae_gemm_nt_ws": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_float, c_int, P, c_int64, P]),
     "nafae_gemm_tn": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "nafae_gemm_tn_rows": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_float, P]),
     "nafae_gemm_tn_rows_acc": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_float, c_int, P]),

@@ -791,12 +791,13 @@ inline bool f32_single_buffer() {
 // the DMAs of tile + 2 are handed out one per product group over the six rows that follow.
 // The weight side is the MFMA "A" operand (as in the bf16 engine): a lane's 4 consecutive accumulator registers are 4 consecutive
 // output columns of one row -> 16-byte stores.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *__restrict__ C, int ldc, const float *__restrict__ bias,
-                      int M, int N, int K, float alpha, int act, int tiles_m, int tiles_n) {
+// (the tile as a device function: f32_gemm4_kernel runs one whole tile per workgroup; f32_gemm4_sk_kernel -- the stream-K tail below --
+// runs k-tiles [kt0, kt0 + nk) of a tile and leaves the raw accumulators in `piece`)
+template <bool PIECE>
+__device__ __forceinline__ void f32_gemm4_tile(const float *A, int lda, const float *B, int ldb, float *__restrict__ C, int ldc,
+                                               const float *__restrict__ bias, float alpha, int act, int tile_id, int tiles_m,
+                                               int tiles_n, int kt0, int nk, float *__restrict__ piece, char *smem) {
   constexpr int STAGE_B = 512 * 128;
-  extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  char *smem = reinterpret_cast<char *>(smem_f);
   f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -805,9 +806,8 @@ void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *_
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  tile_coords(tile_id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = K / BK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wx = wave >> 1, ww = wave & 1;
   // ---- staging: chunk i of this thread = 16 B at LDS byte (tid + 256 i) * 16 of the stage = row (tid >> 3) + 32 i, physical slot
@@ -817,8 +817,8 @@ void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *_
   const int lsl = (tid & 7) ^ ((r0 >> 1) & 7);
   const unsigned av = (unsigned)(((size_t)r0 * lda + lsl * 4) * sizeof(float));
   const unsigned bv = (unsigned)(((size_t)r0 * ldb + lsl * 4) * sizeof(float));
-  const char *abase = reinterpret_cast<const char *>(A) + (size_t)m0 * lda * sizeof(float);
-  const char *bbase = reinterpret_cast<const char *>(B) + (size_t)n0 * ldb * sizeof(float);
+  const char *abase = reinterpret_cast<const char *>(A) + ((size_t)m0 * lda + (size_t)kt0 * BK) * sizeof(float);
+  const char *bbase = reinterpret_cast<const char *>(B) + ((size_t)n0 * ldb + (size_t)kt0 * BK) * sizeof(float);
   const size_t astep = (size_t)32 * lda * sizeof(float), bstep = (size_t)32 * ldb * sizeof(float);
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)reinterpret_cast<uintptr_t>(smem) + wave * 1024));
   auto dma = [&](int i, int kt, int stage) {   // i: compile-time chunk index (0-7: A rows, 8-15: B rows)
@@ -936,6 +936,17 @@ void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *_
     kt++;
   }
   tile(kt, std::false_type{}, std::false_type{});
+  if (PIECE) {   // raw accumulators, thread-linear: piece[((i * 4 + j) * 4 + g) * 256 + tid] = acc[i][j][4 g .. 4 g + 3]
+    f32x4 *pd = reinterpret_cast<f32x4 *>(piece) + tid;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          pd[((i * 4 + j) * 4 + g) * 256] = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+    return;
+  }
   // ---- epilogue: acc[i][j][4 g + q] = C[m0 + wx*128 + j*32 + (lane & 31)][n0 + ww*128 + i*32 + 8 g + 4 (lane >> 5) + q]
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -950,6 +961,80 @@ void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *_
         f32x4 v;
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = apply_act(alpha * acc[i][j][4 * g + q] + bvv[q], act);
+        *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
+      }
+    }
+}
+
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void f32_gemm4_kernel(const float *A, int lda, const float *B, int ldb, float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                      int M, int N, int K, float alpha, int act, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  f32_gemm4_tile<false>(A, lda, B, ldb, C, ldc, bias, alpha, act, (int)blockIdx.x, tiles_m, tiles_n, 0, K / BK, nullptr,
+                        reinterpret_cast<char *>(smem_f));
+}
+
+// Stream-K tail of that kernel.  A launch of T tiles on G CUs runs ceil(T / G) rounds; when the last one is partial (fc6 / fc7 at
+// BASELINE C5: 1 200 tiles = 4.69 rounds, 31 % of the chip idle in the fifth) the whole rounds go to f32_gemm4_kernel and the
+// `rem` = T mod G tiles left are cut along K: the rem * nk k-tiles are shared equally by G workgroups, each runs its (at most two)
+// pieces through the same tile code and leaves the raw accumulators in `partial` (slot 2 b + {0, 1} of workgroup b, 256 KB each);
+// f32_gemm4_sk_finish_kernel, the next launch on the stream, adds a tile's pieces in workgroup order and applies alpha / bias /
+// activation.  Deterministic: the split and the summation order follow from the shapes alone; no atomics, no flags.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void f32_gemm4_sk_kernel(const float *A, int lda, const float *B, int ldb, int K, int tiles_m, int tiles_n, int tile0, int rem,
+                         float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int nk = K / BK;
+  const long U = (long)rem * nk;
+  const long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
+  if (u1 <= u0) return;
+  const int r0 = (int)(u0 / nk), r1 = (int)((u1 - 1) / nk);
+  for (int r = r0; r <= r1; r++) {            // (r1 <= r0 + 1: a share is at most nk k-tiles long when rem <= G)
+    const long a = r == r0 ? u0 : (long)r * nk, b = r == r1 ? u1 : (long)(r + 1) * nk;
+    f32_gemm4_tile<true>(A, lda, B, ldb, nullptr, 0, nullptr, 1.f, 0, tile0 + r, tiles_m, tiles_n, (int)(a - (long)r * nk), (int)(b - a),
+                         partial + ((size_t)2 * blockIdx.x + (r - r0)) * 65536, reinterpret_cast<char *>(smem_f));
+    __syncthreads();
+  }
+}
+
+// one workgroup per remainder tile rr; thread = the (wave, lane) that holds these accumulators in the tile kernel
+__global__ __launch_bounds__(256) void f32_gemm4_sk_finish_kernel(const float *__restrict__ partial, float *__restrict__ C, int ldc,
+                                                                   const float *__restrict__ bias, float alpha, int act, int nk,
+                                                                   int tiles_m, int tiles_n, int tile0, int rem, int grid) {
+  const int rr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wx = wave >> 1, ww = wave & 1;
+  const int fr = lane & 31, h = lane >> 5;
+  const long U = (long)rem * nk;
+  auto share0 = [&](long c) { return U * c / grid; };
+  long cf = (long)rr * nk * grid / U;                        // first workgroup whose share reaches into tile rr's k-tiles
+  while (share0(cf + 1) <= (long)rr * nk) cf++;
+  while (cf > 0 && share0(cf) > (long)rr * nk) cf--;
+  int tm, tn;
+  tile_coords(tile0 + rr, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++)
+#pragma unroll 1
+    for (int g = 0; g < 4; g++) {
+      f32x4 sum[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (long c = cf; c < grid && share0(c) < (long)(rr + 1) * nk; c++) {
+        if (share0(c + 1) <= share0(c)) continue;
+        const int sl = (int)(2 * c) + ((share0(c) / nk) == rr ? 0 : 1);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(partial) + (size_t)sl * 16384 + tid;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sum[j] += src[((i * 4 + j) * 4 + g) * 256];
+      }
+      const int n = n0 + ww * 128 + i * 32 + 8 * g + 4 * h;
+      f32x4 bvv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) bvv = *reinterpret_cast<const f32x4 *>(bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int m = m0 + wx * 128 + j * 32 + fr;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = apply_act(alpha * sum[j][q] + bvv[q], act);
         *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
       }
     }
@@ -1062,8 +1147,33 @@ inline int sk_num_cus() {
 
 extern "C" {
 
-int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M,
-                  int N, int K, float alpha, int act, void *stream) {
+// stream-K tail of f32_gemm4_kernel: worth it when the last round of 256x256 tiles would leave 4 % or more of the launch idle
+static bool gemm4_shape(int M, int N, int K) {
+  return M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 256 == 0 && K % BK == 0 && (long)(M / 256) * (N / 256) >= sk_num_cus();
+}
+static bool gemm4_sk_pays(long tiles, int G) {
+  const long rem = tiles % G;
+  if (rem == 0) return false;
+  const long rounds = (tiles + G - 1) / G;
+  return (double)(G - rem) / (double)(rounds * G) >= 0.04;
+}
+constexpr int64_t GEMM4_SK_COUNTER_BYTES = 65536;    // (the conv workspaces' zeroed-once counter block: one buffer serves all; not touched here)
+constexpr int64_t GEMM4_SK_SLOT_BYTES = 262144;      // one piece's raw accumulators: 256 x 256 fp32
+
+int64_t nafae_gemm_nt_workspace_bytes(int M, int N, int K) {
+  if (!gemm4_shape(M, N, K)) return 0;
+  const int G = sk_num_cus();
+  if (!gemm4_sk_pays((long)(M / 256) * (N / 256), G)) return 0;
+  return GEMM4_SK_COUNTER_BYTES + (int64_t)2 * G * GEMM4_SK_SLOT_BYTES;
+}
+
+int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M, int N, int K,
+                  float alpha, int act, void *stream) {
+  return nafae_gemm_nt_ws(A, lda, B, ldb, C, ldc, bias, M, N, K, alpha, act, nullptr, 0, stream);
+}
+
+int nafae_gemm_nt_ws(const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int M, int N, int K,
+                     float alpha, int act, void *workspace, int64_t workspace_bytes, void *stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return NAFAE_EINVAL;
   if ((K & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return NAFAE_EINVAL;
   if (lda < K || ldb < K || ldc < N) return NAFAE_EINVAL;
@@ -1080,9 +1190,26 @@ int nafae_gemm_nt(const float *A, int lda, const float *B, int ldb, float *C, in
         (size_t)256 * ldb * sizeof(float) < (1ull << 31)) {
       const void *k4 = reinterpret_cast<const void *>(f32_gemm4_kernel);
       if (nafae::allow_dynamic_lds(k4, 2 * 512 * 128) != NAFAE_OK) return NAFAE_ELAUNCH;
+      const int tiles = (M / 256) * (N / 256), G = sk_num_cus();
+      if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && gemm4_sk_pays(tiles, G) &&
+          workspace_bytes >= GEMM4_SK_COUNTER_BYTES + (int64_t)2 * G * GEMM4_SK_SLOT_BYTES) {
+        const void *ks = reinterpret_cast<const void *>(f32_gemm4_sk_kernel);
+        if (nafae::allow_dynamic_lds(ks, 2 * 512 * 128) != NAFAE_OK) return NAFAE_ELAUNCH;
+        const int rem = tiles % G, full = tiles - rem;
+        float *partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + GEMM4_SK_COUNTER_BYTES);
+        NAFAE_TAG("f32_gemm4 stream-K tail");
+        if (full > 0)
+          hipLaunchKernelGGL(f32_gemm4_kernel, dim3(full), dim3(256), 2 * 512 * 128, S(stream), A, lda, B, ldb, C, ldc, bias, M, N, K,
+                             alpha, act, M / 256, N / 256);
+        hipLaunchKernelGGL(f32_gemm4_sk_kernel, dim3(G), dim3(256), 2 * 512 * 128, S(stream), A, lda, B, ldb, K, M / 256, N / 256, full,
+                           rem, partial);
+        hipLaunchKernelGGL(f32_gemm4_sk_finish_kernel, dim3(rem), dim3(256), 0, S(stream), partial, C, ldc, bias, alpha, act, K / BK,
+                           M / 256, N / 256, full, rem, G);
+        return launched();
+      }
       NAFAE_TAG("f32_gemm4");
-      hipLaunchKernelGGL(f32_gemm4_kernel, dim3((M / 256) * (N / 256)), dim3(256), 2 * 512 * 128, S(stream), A, lda, B, ldb, C, ldc,
-                         bias, M, N, K, alpha, act, M / 256, N / 256);
+      hipLaunchKernelGGL(f32_gemm4_kernel, dim3(tiles), dim3(256), 2 * 512 * 128, S(stream), A, lda, B, ldb, C, ldc, bias, M, N, K,
+                         alpha, act, M / 256, N / 256);
       return launched();
     }
   }

@@ -79,8 +79,9 @@ def _rc(rc, what):
 
 
 # ------------------------------------------------------------------------------------------------ contractions
-def gemm_nt(A, B, bias=None, alpha=1.0, act=ACT_NONE, out=None):
-    """act(alpha * A @ B.T + bias); A [M,K], B [N,K]."""
+def gemm_nt(A, B, bias=None, alpha=1.0, act=ACT_NONE, out=None, use_workspace=True):
+    """act(alpha * A @ B.T + bias); A [M,K], B [N,K].  Shapes whose 256x256 tile count leaves the last round of workgroups partly
+    empty run the stream-K tail (nafae_gemm_nt_ws) on the stream's scratch buffer; use_workspace=False: the plain schedule."""
     _chk(A, name="A"); _chk(B, name="B"); _chk(bias, name="bias")
     M, K = A.shape
     N = B.shape[0]
@@ -89,8 +90,10 @@ def gemm_nt(A, B, bias=None, alpha=1.0, act=ACT_NONE, out=None):
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     _chk(out, name="out")
-    _rc(_lib.lib().nafae_gemm_nt(_p(A), K, _p(B), K, _p(out), N, _p(bias), M, N, K, float(alpha), int(act), _stream()),
-        "nafae_gemm_nt")
+    nws = int(_lib.lib().nafae_gemm_nt_workspace_bytes(M, N, K)) if use_workspace else 0
+    ws = _conv_workspace(nws, A.device) if nws > 0 else None
+    _rc(_lib.lib().nafae_gemm_nt_ws(_p(A), K, _p(B), K, _p(out), N, _p(bias), M, N, K, float(alpha), int(act), _p(ws), max(nws, 0),
+                                    _stream()), "nafae_gemm_nt_ws")
     return out
 
 

@@ -559,3 +559,38 @@ def test_tail_kernels_accumulate_and_row_lists(ops):
         assert torch.equal(gx2, gx) and relerr(aw.cpu(), (wt.grad + 1).cpu()) < 2e-5 and relerr(ab.cpu(), (bt.grad + 2).cpu()) < 2e-5
     ye, _, _ = ops.batchnorm_fwd(xx, w, b, rm, rv, False)
     assert relerr(ye.cpu(), torch.nn.functional.batch_norm(xx, rm, rv, w, b, False, 0.1, 1e-5).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(5120, 4096, 1024), (19200, 4096, 4096), (4096 + 256, 4096, 96), (300 * 64, 512 * 2, 32), (8192, 4096, 512)],
+                         ids=lambda s: "%dx%dx%d" % s)
+def test_gemm_nt_stream_k_tail(ops, shape):
+    """nafae_gemm_nt_ws: 256x256 tile counts that leave a partial last round on the chip's CUs (320 / 1 200 / 272 / 300 tiles) run the
+    whole rounds as before and cut the tiles of the last round along K (pieces of a few k-tiles up to whole tiles, pieces that straddle
+    two tiles, one k-tile in all: K = 32); 512 tiles = two full rounds take the plain kernel.  Against an fp64 product, against the plain
+    schedule (same values up to the rounding of the piece sums), three launches bit-identical, bias + ReLU in the finishing launch."""
+    import torch
+    from nafae_amd import _lib
+    M, N, K = shape
+    g = torch.Generator(device='cuda').manual_seed(M + K)
+    A = torch.randn(M, K, device='cuda', generator=g)
+    B = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    bias = torch.randn(N, device='cuda', generator=g)
+    nws = int(_lib.lib().nafae_gemm_nt_workspace_bytes(M, N, K))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = (M // 256) * (N // 256)
+    assert (nws > 0) == (tiles % cus != 0 and (cus - tiles % cus) / (-(-tiles // cus) * cus) >= 0.04)
+    ys = [ops.gemm_nt(A, B, bias, alpha=0.5, act=ops.ACT_RELU) for _ in range(3)]
+    plain = ops.gemm_nt(A, B, bias, alpha=0.5, act=ops.ACT_RELU, use_workspace=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    rows = torch.arange(0, M, max(1, M // 1024), device='cuda')            # (an fp64 reference of a row sample: every tile row)
+    ref = torch.relu(0.5 * (A[rows].double() @ B.double().t()) + bias.double())
+    scale = float(ref.abs().max())
+    e_sk = float((ys[0][rows].double() - ref).abs().max()) / scale
+    e_pl = float((plain[rows].double() - ref).abs().max()) / scale
+    d = float((ys[0] - plain).abs().max()) / scale
+    print("\n[gemm_nt %dx%dx%d] %d tiles, workspace %d B | err vs fp64: stream-K %.2e, plain %.2e | stream-K vs plain %.2e" %
+          (M, N, K, tiles, nws, e_sk, e_pl, d))
+    assert e_sk < 2e-6 and e_pl < 2e-6 and d < 2e-6
+    if nws == 0:
+        assert torch.equal(ys[0], plain)
