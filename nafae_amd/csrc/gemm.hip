@@ -1151,9 +1151,9 @@ extern "C" {
 static bool gemm4_shape(int M, int N, int K) {
   return M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 256 == 0 && K % BK == 0 && (long)(M / 256) * (N / 256) >= sk_num_cus();
 }
-static bool gemm4_sk_pays(long tiles, int G) {
+static bool gemm4_sk_pays(long tiles, int G, int K) {
   const long rem = tiles % G;
-  if (rem == 0) return false;
+  if (rem == 0 || K / BK < 16) return false;      // (a tile of fewer than 16 k-tiles is not worth cutting: the pieces' 256 KB round trips)
   const long rounds = (tiles + G - 1) / G;
   return (double)(G - rem) / (double)(rounds * G) >= 0.04;
 }
@@ -1163,7 +1163,7 @@ constexpr int64_t GEMM4_SK_SLOT_BYTES = 262144;      // one piece's raw accumula
 int64_t nafae_gemm_nt_workspace_bytes(int M, int N, int K) {
   if (!gemm4_shape(M, N, K)) return 0;
   const int G = sk_num_cus();
-  if (!gemm4_sk_pays((long)(M / 256) * (N / 256), G)) return 0;
+  if (!gemm4_sk_pays((long)(M / 256) * (N / 256), G, K)) return 0;
   return GEMM4_SK_COUNTER_BYTES + (int64_t)2 * G * GEMM4_SK_SLOT_BYTES;
 }
 
@@ -1191,7 +1191,7 @@ int nafae_gemm_nt_ws(const float *A, int lda, const float *B, int ldb, float *C,
       const void *k4 = reinterpret_cast<const void *>(f32_gemm4_kernel);
       if (nafae::allow_dynamic_lds(k4, 2 * 512 * 128) != NAFAE_OK) return NAFAE_ELAUNCH;
       const int tiles = (M / 256) * (N / 256), G = sk_num_cus();
-      if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && gemm4_sk_pays(tiles, G) &&
+      if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && gemm4_sk_pays(tiles, G, K) &&
           workspace_bytes >= GEMM4_SK_COUNTER_BYTES + (int64_t)2 * G * GEMM4_SK_SLOT_BYTES) {
         const void *ks = reinterpret_cast<const void *>(f32_gemm4_sk_kernel);
         if (nafae::allow_dynamic_lds(ks, 2 * 512 * 128) != NAFAE_OK) return NAFAE_ELAUNCH;

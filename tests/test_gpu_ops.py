@@ -561,12 +561,12 @@ def test_tail_kernels_accumulate_and_row_lists(ops):
     assert relerr(ye.cpu(), torch.nn.functional.batch_norm(xx, rm, rv, w, b, False, 0.1, 1e-5).cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(5120, 4096, 1024), (19200, 4096, 4096), (4096 + 256, 4096, 96), (300 * 64, 512 * 2, 32), (8192, 4096, 512)],
+@pytest.mark.parametrize("shape", [(5120, 4096, 1024), (19200, 4096, 4096), (4096 + 256, 4096, 2048), (4096 + 256, 4096, 96), (300 * 64, 512 * 2, 32), (8192, 4096, 512)],
                          ids=lambda s: "%dx%dx%d" % s)
 def test_gemm_nt_stream_k_tail(ops, shape):
-    """nafae_gemm_nt_ws: 256x256 tile counts that leave a partial last round on the chip's CUs (320 / 1 200 / 272 / 300 tiles) run the
+    """nafae_gemm_nt_ws: 256x256 tile counts that leave a partial last round on the chip's CUs (320 / 1 200 / 272 / 300 tiles; 272 = one round + 16 tiles cut into 16 pieces each) run the
     whole rounds as before and cut the tiles of the last round along K (pieces of a few k-tiles up to whole tiles, pieces that straddle
-    two tiles, one k-tile in all: K = 32); 512 tiles = two full rounds take the plain kernel.  Against an fp64 product, against the plain
+    two tiles); tiles of fewer than 16 k-tiles (K = 96, K = 32) and 512 tiles = two full rounds take the plain kernel.  Against an fp64 product, against the plain
     schedule (same values up to the rounding of the piece sums), three launches bit-identical, bias + ReLU in the finishing launch."""
     import torch
     from nafae_amd import _lib
@@ -578,7 +578,7 @@ def test_gemm_nt_stream_k_tail(ops, shape):
     nws = int(_lib.lib().nafae_gemm_nt_workspace_bytes(M, N, K))
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     tiles = (M // 256) * (N // 256)
-    assert (nws > 0) == (tiles % cus != 0 and (cus - tiles % cus) / (-(-tiles // cus) * cus) >= 0.04)
+    assert (nws > 0) == (tiles % cus != 0 and K >= 512 and (cus - tiles % cus) / (-(-tiles // cus) * cus) >= 0.04)
     ys = [ops.gemm_nt(A, B, bias, alpha=0.5, act=ops.ACT_RELU) for _ in range(3)]
     plain = ops.gemm_nt(A, B, bias, alpha=0.5, act=ops.ACT_RELU, use_workspace=False)
     torch.cuda.synchronize()
