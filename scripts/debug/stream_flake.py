@@ -15,6 +15,22 @@ host = [torch.from_numpy(rs.randint(0, 255, (Na * Ns, 96, 96, 3)).astype(np.uint
 n = 5
 bad = 0
 junk = []
+# timing perturbation (argv[2] = 1): a side stream kept busy with matmuls of random size, and random host-side pauses between the
+# feeder and the trainer -- so that the copy stream, the detector stream and the tail interleave differently every step
+import random, time
+PERTURB = len(sys.argv) > 2 and sys.argv[2] == "1"
+side = torch.cuda.Stream()
+noise_a = torch.randn(2048, 2048, device='cuda')
+rnd = random.Random(7)
+def perturb():
+    if not PERTURB:
+        return
+    with torch.cuda.stream(side):
+        for _ in range(rnd.randint(0, 3)):
+            k = rnd.choice([256, 512, 1024, 2048])
+            (noise_a[:k, :k] @ noise_a[:k, :k]).sum()
+    if rnd.random() < 0.3:
+        time.sleep(rnd.random() * 0.003)
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     if it % 3 == 1:      # perturb the allocator / the GPU's state between iterations like other tests would
         junk = [torch.randn(1 << (18 + (it % 5)), device='cuda') for _ in range(4)]
@@ -36,10 +52,16 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
             pipe = PipelinedTrainer(model2, opt2, crit2, args, red2)
             pipe.submit(feeder.next())
             for i in range(n):
-                got.append(float(pipe.step(feeder.next() if i + 1 < n else None)[0]))
+                perturb()
+                nb = feeder.next() if i + 1 < n else None
+                perturb()
+                got.append(float(pipe.step(nb)[0]))
         else:
             for i in range(n):
-                got.append(float(train_step(model2, opt2, crit2, feeder.next(), args, red2)[0]))
+                perturb()
+                nb = feeder.next()
+                perturb()
+                got.append(float(train_step(model2, opt2, crit2, nb, args, red2)[0]))
         torch.cuda.synchronize()
         peq = torch.equal(torch.cat([p.detach().reshape(-1) for p in red2.params]), want)
         if got != ref or not peq:
